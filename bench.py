@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""
+bench.py -- fwd+bwd sweeps/sec of the VGPA variational smoothing sweep on MI355X.
+
+One "step" = one pass of the hot path (vgpa_sweep: forward moment ODE -> E_obs / E_sde terms -> backward
+Lagrange ODE -> gradient w.r.t. (A_t, b_t)) over one BATCH of `--batch` independent problems that share the
+BASELINE configuration 3 (Lorenz-96, D=40, RK4, Np=1001, seed 31415926535) and differ in their variational
+parameters x.  Inputs (x) and outputs (gradient) stay resident in HBM; F comes back to the host once per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, independent problems per rank (the path shards over problems; no data-path
+collective), barrier + device sync on both sides of the timed region, MAX over ranks, weak scaling.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import os
+import sys
+import json
+import time
+import argparse
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz; measured 64 clk per v_mfma_f64_16x16x4 (profiles/)
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="independent problems per GPU per step")
+    ap.add_argument("--np", dest="n_pts", type=int, default=1001)
+    ap.add_argument("--dim", type=int, default=40)
+    ap.add_argument("--method", default="RK4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) stepping kernels")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # torch is plumbing only (process group, barrier, device sync).  It must be imported BEFORE libvgpa_hip.so
+    # is loaded so that both share one HIP runtime (same SONAME, see vgpa_amd/_lib.py).
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (vgpa_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import vgpa_amd as va
+    from vgpa_amd._lib import FLAG_FORCE_GENERIC
+    from helpers import build_problem
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    d, n_pts, dt = args.dim, args.n_pts, 0.01
+    tf = (n_pts - 1) * dt
+    p = build_problem("L96", args.method, tf, dt, d)          # seed 31415926535: the reference's config-3 inputs
+    v = p["vgp"]
+    assert v.dim_n == n_pts, (v.dim_n, n_pts)
+    x0 = v.initialization()
+    len_x = x0.size
+    B = args.batch
+    flags = FLAG_FORCE_GENERIC if args.generic else 0
+    e0 = float(p["kl0"](p["m0"], p["s0"]))
+    ctx = va.Context("L96", args.method, d, n_pts, dt, sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"],
+                     obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=B,
+                     device=local_rank, flags=flags)
+    rng = np.random.default_rng(1000 + rank)
+    xb = np.empty((B, len_x))
+    for i in range(B):                                       # problem 0 of rank 0 is exactly x0 + 0.05 N(0,1), rng(0)
+        r = np.random.default_rng(0) if (i == 0 and rank == 0) else rng
+        xb[i] = x0 + 0.05 * r.standard_normal(len_x)
+    x_dev, g_dev = ctx.alloc(B * len_x), ctx.alloc(B * len_x)
+    x_dev.upload(xb)
+
+    for _ in range(args.warmup):
+        ctx.sweep_enqueue(x_dev, g_dev)
+        ctx.fetch_f()
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    f_last = None
+    for _ in range(args.steps):
+        ctx.sweep_enqueue(x_dev, g_dev)
+        f_last = ctx.fetch_f()                               # F of every problem returns to the host each step
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness guard inside the bench: problem 0 of rank 0 must reproduce the reference's anchor
+    check = None
+    if rank == 0 and n_pts == 1001 and d == 40 and args.method.upper() == "RK4":
+        anchors = json.load(open(os.path.join(ROOT, "tests", "golden", "anchors.json")))
+        f_ref = anchors["l96d40_rk4_full_p"]["F"]
+        check = abs(np.atleast_1d(f_last)[0] - f_ref) / abs(f_ref)
+        if check > 1e-9:
+            raise SystemExit(f"bench result is WRONG: F={np.atleast_1d(f_last)[0]!r} vs reference {f_ref!r}")
+
+    # ---- single-problem latency (what one SCG evaluation costs), rank 0, outside the timed region
+    single = None
+    if rank == 0:
+        c1 = va.Context("L96", args.method, d, n_pts, dt, sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"],
+                        obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=1,
+                        device=local_rank, flags=flags)
+        x1, g1 = c1.alloc(len_x), c1.alloc(len_x)
+        x1.upload(xb[0])
+        for _ in range(2):
+            c1.sweep_dev(x1, g1)
+        c1.profile_begin()
+        ts = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            c1.sweep_dev(x1, g1)
+        t_single = (time.perf_counter() - ts) / reps
+        pr1 = c1.profile_end()
+        single = {"ms_per_sweep": 1e3 * t_single, "sweeps_per_s": 1.0 / t_single,
+                  "fwd_ms": pr1["fwd_ms"] / reps, "energy_ms": pr1["energy_ms"] / reps,
+                  "bwd_ms": pr1["bwd_ms"] / reps, "grad_ms": pr1["grad_ms"] / reps}
+        c1.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_sweeps = B * args.steps * world
+    value = total_sweeps / elapsed
+    steps = max(args.steps, 1)
+    # dominant kernel: the backward (Psi) stepping kernel; one launch integrates B problems
+    fwd_s, bwd_s = prof["fwd_ms"] / steps * 1e-3, prof["bwd_ms"] / steps * 1e-3
+    dom, dom_s = ("solve_bwd", bwd_s) if bwd_s >= fwd_s else ("solve_fwd", fwd_s)
+    alg_flop = B * (n_pts - 1) * 8.0 * d ** 3               # RK4: 4 stages x one D^3 product (symmetry) x 2 flop
+    alg_bytes_fwd = B * 8.0 * n_pts * (2 * d * d + 2 * d)   # read A,b ; write S,m
+    alg_bytes_bwd = B * 8.0 * n_pts * (3 * d * d + 2 * d)   # read A, dEsde/dS, dEsde/dm ; write Psi, lam
+    alg_bytes = alg_bytes_bwd if dom == "solve_bwd" else alg_bytes_fwd
+    tfl = alg_flop / dom_s / 1e12
+    gbs = alg_bytes / dom_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        key = f"{dom}_B{B}_D{d}_Np{n_pts}"
+        traffic = tj.get(key)
+    sweep_bytes = 8.0 * n_pts * (5 * d * d + 6 * d)         # SURVEY.md s.8d algorithmic bytes of one fused sweep
+    out = {
+        "metric": "fwd+bwd sweeps/sec (free-energy+grad eval), Lorenz96 D=40 N=1000",
+        "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (seeded Lorenz-96 path + observations, reference generator order)",
+        "config": {"workload": f"Lorenz96 D={d}, {args.method.upper()}, Np={n_pts} (BASELINE configs[2])",
+                   "batch_per_gpu": B, "sharding": "independent problems per GPU, no collective",
+                   "kernels": "generic" if args.generic else "mfma"},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tfl / FP64_PEAK_TFLOPS, "traffic": traffic,
+                     "launch_ms": 1e3 * dom_s, "alg_flop_per_launch": alg_flop,
+                     "note": "fp64 stepping kernel at D=40 is matrix-pipe bound (AI = D/2 flop/B > ridge ~10)"},
+        "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
+                         "whole_sweep_GBs": sweep_bytes * value / world / 1e9,
+                         "whole_sweep_frac": sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS},
+        "phase_ms_per_step": {"fwd": 1e3 * fwd_s, "energy+obs": prof["energy_ms"] / steps, "bwd": 1e3 * bwd_s,
+                              "reduce+grad": prof["grad_ms"] / steps},
+        "single_problem": single,
+        "parity_check_rel_err_F": check,
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import vgpa_oracle as vo
+        z = dict(model="L96", method=args.method, dt=dt, theta=8.0, sigma=p["model"].sigma, m0=p["m0"], s0=p["s0"],
+                 mu0=p["mu0"], tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"],
+                 time_window=p["model"].time_window)
+        prob = vo.Problem.from_fixture({k: np.asarray(val) for k, val in z.items()})
+        tc = time.perf_counter()
+        f_cpu, g_cpu, _ = vo.sweep(prob, xb[0], faithful=True)
+        t_faith = time.perf_counter() - tc
+        tc = time.perf_counter()
+        vo.sweep(prob, xb[0], faithful=False)
+        t_lean = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": 1.0 / t_faith, "unit": "sweeps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+                               "sample": f"1 full sweep of the same workload (L96 D={d} Np={n_pts}), numpy oracle in "
+                                         f"faithful mode (same per-step operations as the reference)",
+                               "seconds": t_faith, "lean_value": 1.0 / t_lean, "lean_seconds": t_lean,
+                               "gpu_vs_cpu_F_rel_err": abs(np.atleast_1d(f_last)[0] - f_cpu) / abs(f_cpu)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * vgpa_hip.h -- C ABI of libvgpa_hip.so: the MI355X (gfx950) implementation of VGPA's
+ * forward-backward variational smoothing sweep.
+ *
+ * The reference (vrettasm/VGPA) is pure Python and has no FFI; its plugin boundary is the
+ * duck-typed Python surface listed below.  Every entry point of this header names the reference
+ * interface it stands behind (paths relative to the reference repository root):
+ *
+ *   vgpa_solve_fwd      <- FwdOde.__call__ -> <stepper>.solve_fwd   src/var_bayes/fwd_ode.py:45-65,
+ *                          src/numerics/{euler.py:27,heun.py:28,runge_kutta2.py:25,runge_kutta4.py:25}
+ *   vgpa_solve_bwd      <- BwdOde.__call__ -> <stepper>.solve_bwd   src/var_bayes/bwd_ode.py:45-65,
+ *                          src/numerics/{euler.py:94,heun.py:113,runge_kutta2.py:104,runge_kutta4.py:115}
+ *   vgpa_energy         <- <model>.energy(A, b, m, S, obs_t)        src/dynamics/ornstein_uhlenbeck.py:165,
+ *                          double_well.py:169, lorenz_63.py:237, lorenz_96.py:316
+ *   vgpa_obs_energy     <- GaussianLikelihood.__call__ / .gradients src/var_bayes/gaussian_like.py:69-243
+ *   vgpa_free_energy    <- VarGP.free_energy(x)                     src/var_bayes/variational.py:141-200
+ *   vgpa_gradient       <- VarGP.gradient(x, eval_fun=False)        src/var_bayes/variational.py:202-289
+ *   vgpa_sweep          <- VarGP.gradient(x, eval_fun=True)  (what SCG calls, src/numerics/optim_scg.py:167)
+ *   vgpa_fetch          <- VarGP.arg_out                            src/var_bayes/variational.py:292
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all floating point data is IEEE fp64, C-contiguous;
+ *   - every function returns VGPA_OK (0) or a negative vgpa_status; no exception crosses the
+ *     boundary; vgpa_last_error() gives the message of the last failure on that context;
+ *   - host-pointer entry points copy in/out and are synchronous on return;
+ *     the *_dev entry points take DEVICE pointers (hipMalloc'ed by the caller, same device) and
+ *     enqueue on the context's stream; call vgpa_synchronize() before reading results;
+ *   - buffers are caller-owned; the context owns its device workspace; a context is not
+ *     thread-safe (one host thread per context, like the reference's single-threaded use);
+ *   - there is NO CPU fallback: without a HIP device vgpa_create fails with VGPA_ERR_DEVICE.
+ *
+ * Batching: a context may hold `batch` independent problems that share the configuration
+ * (observations, m0, S0, ...) but have different variational parameters x.  All per-problem
+ * arrays are then laid out problem-major: x[batch][len_x], mt[batch][Np][D], F[batch], ...
+ */
+#ifndef VGPA_HIP_H
+#define VGPA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGPA_ABI_VERSION 1
+
+typedef enum {
+  VGPA_OK = 0,
+  VGPA_ERR_ARG = -1,        /* bad argument / inconsistent configuration (Python: ValueError)      */
+  VGPA_ERR_DEVICE = -2,     /* no usable HIP device, or a HIP runtime call failed (RuntimeError)   */
+  VGPA_ERR_NOT_PD = -3,     /* a matrix that must be positive definite is not (LinAlgError)        */
+  VGPA_ERR_STATE = -4,      /* call order violated, e.g. gradient before free_energy (RuntimeError) */
+  VGPA_ERR_UNSUPPORTED = -5 /* valid request that this build does not implement (NotImplementedError) */
+} vgpa_status;
+
+/* model ids: dynamical_systems registry, src/var_bayes/simulation.py:20-21 */
+enum { VGPA_MODEL_NONE = -1, /* ODE-only context: solve_fwd / solve_bwd, no energy terms */
+       VGPA_MODEL_OU = 0, VGPA_MODEL_DW = 1, VGPA_MODEL_L63 = 2, VGPA_MODEL_L96 = 3 };
+/* stepper ids: num_integration registry, src/numerics/utilities.py:12-13 */
+enum { VGPA_ODE_EULER = 0, VGPA_ODE_HEUN = 1, VGPA_ODE_RK2 = 2, VGPA_ODE_RK4 = 3 };
+/* vgpa_fetch selectors: keys of VarGP.output, src/var_bayes/variational.py:189-196 */
+enum {
+  VGPA_FETCH_MT = 0, VGPA_FETCH_ST = 1, VGPA_FETCH_LAMT = 2, VGPA_FETCH_PSIT = 3,
+  VGPA_FETCH_EFX = 4, VGPA_FETCH_EDF = 5, VGPA_FETCH_DESDE_DM = 6, VGPA_FETCH_DESDE_DS = 7,
+  VGPA_FETCH_ESDE_T = 8 /* per-grid-point E_sde(t) before the trapezoid, (Np,) */
+};
+/* config flags */
+enum {
+  VGPA_FLAG_FORCE_GENERIC = 1 /* use the generic (no symmetry assumption) stepping kernels */
+};
+
+typedef struct vgpa_ctx vgpa_ctx;
+
+typedef struct {
+  int32_t abi_version;   /* VGPA_ABI_VERSION */
+  int32_t device;        /* HIP device ordinal */
+  int32_t model;         /* VGPA_MODEL_* */
+  int32_t method;        /* VGPA_ODE_* */
+  int32_t dim_d;         /* state dimension D (1 for OU/DW, 3 for L63, >=4 for L96) */
+  int32_t n_pts;         /* grid points Np = len(arange(t0, tf+dt, dt)) */
+  int32_t batch;         /* independent problems held by this context (>= 1) */
+  int32_t flags;         /* VGPA_FLAG_* */
+  double dt;             /* time step (> 0) */
+  int32_t n_theta;       /* 1 (OU, DW, L96) or 3 (L63) */
+  int32_t n_obs;         /* number of observation times M (may be 0 for ODE-only contexts) */
+  const double* theta;   /* [n_theta] drift parameters                                      */
+  const double* sigma;   /* [D*D] system noise covariance (1-D models: one value)           */
+  const double* m0;      /* [D]   initial mean       (NULL for ODE-only contexts)           */
+  const double* s0;      /* [D*D] initial covariance (NULL for ODE-only contexts)           */
+  const int64_t* obs_t;  /* [M]   observation indices into the grid, strictly increasing    */
+  const double* obs_y;   /* [M*D] observation values                                        */
+  const double* obs_noise; /* [D*D] observation noise covariance R (1-D models: one value)  */
+  const double* obs_h;   /* [D*D] observation operator H, or NULL for the identity          */
+  double e0;             /* KL(q0||p0), constant in x (src/var_bayes/prior_kl0.py:46-92)    */
+} vgpa_config;
+
+/* lifetime ------------------------------------------------------------------------------- */
+int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg);
+void vgpa_destroy(vgpa_ctx* ctx);
+const char* vgpa_last_error(const vgpa_ctx* ctx);   /* ctx == NULL: last error of vgpa_create */
+int vgpa_abi_version(void);
+int vgpa_device_count(void);                         /* 0 when no HIP device is visible */
+int vgpa_synchronize(vgpa_ctx* ctx);
+void* vgpa_stream(vgpa_ctx* ctx);                    /* the context's hipStream_t */
+
+/* operator level (host pointers; problem-major when batch > 1) ------------------------------ */
+/* (m_t, S_t) from (A, b, m0, S0, Sigma).  A:[Np,D,D] b:[Np,D] m0:[D] s0:[D,D] sigma:[D,D] */
+int vgpa_solve_fwd(vgpa_ctx* ctx, const double* lin_a, const double* off_b, const double* m0,
+                   const double* s0, const double* sigma, double* mt, double* st);
+/* (lam_t, Psi_t) from A, dEsde/dm [Np,D], dEsde/dS [Np,D,D] and the dense jump arrays of E_obs. */
+int vgpa_solve_bwd(vgpa_ctx* ctx, const double* lin_a, const double* desde_dm, const double* desde_ds,
+                   const double* deobs_dm, const double* deobs_ds, double* lam, double* psi);
+/* E_sde and its per-grid-point terms.  Any output pointer may be NULL. */
+int vgpa_energy(vgpa_ctx* ctx, const double* lin_a, const double* off_b, const double* mt,
+                const double* st, double* esde, double* efx, double* edf, double* desde_dm,
+                double* desde_ds);
+/* E_obs and the dense jump arrays dEobs/dm [Np,D], dEobs/dS [Np,D,D] (zero off the obs rows). */
+int vgpa_obs_energy(vgpa_ctx* ctx, const double* mt, const double* st, double* eobs,
+                    double* deobs_dm, double* deobs_ds);
+
+/* fused objective (state stays resident in HBM between calls) -------------------------------- */
+int vgpa_free_energy(vgpa_ctx* ctx, const double* x, double* f);       /* f:[batch] */
+int vgpa_gradient(vgpa_ctx* ctx, const double* x_or_null, double* g);  /* NULL: cached state */
+int vgpa_sweep(vgpa_ctx* ctx, const double* x, double* f, double* g);  /* df(x, eval_fun=True) */
+int vgpa_energy_parts(vgpa_ctx* ctx, double* e0, double* esde, double* eobs); /* each [batch] */
+int vgpa_fetch(vgpa_ctx* ctx, int which, double* out);
+
+/* device-pointer variants (x, g on the context's device; f written to HOST after a sync) ------ */
+int vgpa_sweep_dev(vgpa_ctx* ctx, const double* x_dev, double* f_host, double* g_dev);
+int vgpa_free_energy_dev(vgpa_ctx* ctx, const double* x_dev, double* f_host);
+/* enqueue-only form for benchmarking / pipelining: F stays on the device (vgpa_fetch_f). */
+int vgpa_sweep_enqueue(vgpa_ctx* ctx, const double* x_dev, double* g_dev);
+int vgpa_fetch_f(vgpa_ctx* ctx, double* f_host);    /* syncs, checks the device status word */
+
+/* raw device memory helpers so that hosts without a HIP binding can own device buffers */
+int vgpa_dev_alloc(vgpa_ctx* ctx, uint64_t bytes, void** out);
+int vgpa_dev_free(vgpa_ctx* ctx, void* ptr);
+int vgpa_memcpy_h2d(vgpa_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int vgpa_memcpy_d2h(vgpa_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* timing of the stepping kernel on the context's stream (HIP events), for bench.py's roofline */
+int vgpa_profile_begin(vgpa_ctx* ctx);
+int vgpa_profile_end(vgpa_ctx* ctx, double* fwd_ms, double* energy_ms, double* bwd_ms,
+                     double* grad_ms, int64_t* n_sweeps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGPA_HIP_H */

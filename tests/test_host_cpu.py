@@ -1,0 +1,134 @@
+"""CPU suite: host logic of vgpa_amd (no GPU compute) and the C-ABI library surface."""
+import os
+import re
+import json
+
+import numpy as np
+import pytest
+
+import vgpa_amd as va
+from conftest import ROOT, GOLDEN_DIR, rel_err
+from helpers import build_problem, problem_from_golden, quiet
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    lib = va.load()
+    header = open(os.path.join(ROOT, "include", "vgpa_hip.h")).read()
+    declared = set(re.findall(r"\b(vgpa_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vgpa_hip.h but not exported"
+    from vgpa_amd._lib import SYMBOLS
+    assert set(SYMBOLS) == declared
+    assert lib.vgpa_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback():
+    """Without a HIP device every compute entry point must fail loudly."""
+    if va.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        va.FwdOde(0.01, "rk4", False)(np.zeros((5, 3, 3)), np.zeros((5, 3)), np.zeros(3), np.eye(3), np.eye(3))
+    model = quiet(va.OrnsteinUhlenbeck, 0.8, 1.0, 1)
+    model.make_trajectory(0.0, 0.1, 0.01)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        model.energy(np.ones(11), np.ones(11), np.ones(11), np.ones(11), [])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vgpa_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "vgpa_oracle" not in src, f
+                assert "/root/reference" not in src, f
+
+
+def test_stepper_registry_and_errors():
+    assert set(va.num_integration) == {"euler", "heun", "rk2", "rk4"}
+    assert set(va.dynamical_systems) == {"DW", "OU", "L63", "L96"}
+    with pytest.raises(ValueError):
+        va.FwdOde(0.0, "rk4", True)
+    with pytest.raises(ValueError):
+        va.BwdOde(-0.1, "euler", True)
+    with pytest.raises(ValueError):
+        va.FwdOde(0.01, "leapfrog", True)
+    with pytest.raises(ValueError):
+        va.Euler(0.0, True)
+    assert isinstance(va.FwdOde(0.01, "RK4", False).solver, va.RungeKutta4)   # case-insensitive like the reference
+    with pytest.raises(ValueError):
+        quiet(va.OrnsteinUhlenbeck, -1.0, 1.0)
+    with pytest.raises(ValueError):
+        quiet(va.Lorenz96, [4.0] * 5, 8.0, 1, 5)
+    with pytest.raises(RuntimeError):
+        quiet(va.Lorenz63, [-1.0, 1.0, 1.0], [10.0, 28.0, 2.667])
+
+
+def test_input_generators_reproduce_reference_streams(golden):
+    """make_trajectory / collect_obs / m0 draw / initialization consume the seeded stream like the reference."""
+    name = str(golden["model"])
+    d = None if name in ("OU", "DW", "L63") else int(golden["m0"].size)
+    p = build_problem(name, str(golden["method"]), float(golden["tf"]), float(golden["dt"]), d)
+    assert np.array_equal(p["model"].time_window, golden["time_window"])
+    assert rel_err(p["model"].sample_path, golden["sample_path"]) < 1e-14
+    assert np.array_equal(np.asarray(p["obs_t"]), golden["obs_t"])
+    assert rel_err(p["obs_y"], golden["obs_y"]) < 1e-14
+    assert rel_err(p["m0"], golden["m0"]) < 1e-14
+    x0 = p["vgp"].initialization()
+    assert x0.shape == golden["x0"].shape
+    assert rel_err(x0, golden["x0"]) < 1e-13
+    assert rel_err(p["kl0"](p["m0"], p["s0"]), golden["E0"]) < 1e-13
+    assert rel_err(p["model"].inverse_sigma, golden["inverse_sigma"]) < 1e-15
+
+
+def test_full_size_inputs_match_anchors():
+    """The BASELINE-size inputs (Np=1001) regenerate identically (checked through scalar anchors)."""
+    anchors = json.load(open(os.path.join(GOLDEN_DIR, "anchors.json")))
+    for tag, name, method, d in (("ou_euler_full", "OU", "Euler", None), ("l63_rk4_full", "L63", "RK4", None),
+                                 ("l96d40_rk4_full", "L96", "RK4", 40)):
+        a = anchors[tag]
+        p = build_problem(name, method, a["tf"], a["dt"], d)
+        x0 = p["vgp"].initialization()
+        assert x0.size == a["len_x"]
+        assert abs(np.sum(x0) - a["x0_sum"]) <= 1e-11 * abs(a["x0_sum"])
+        assert abs(np.linalg.norm(x0) - a["x0_norm"]) <= 1e-12 * a["x0_norm"]
+        assert abs(np.sum(p["obs_y"]) - a["obs_y_sum"]) <= 1e-11 * abs(a["obs_y_sum"])
+        assert abs(np.sum(p["model"].sample_path) - a["path_sum"]) <= 1e-11 * abs(a["path_sum"])
+        assert abs(float(p["kl0"](p["m0"], p["s0"])) - a["E0"]) <= 1e-12 * abs(a["E0"])
+
+
+def test_scg_minimises_sphere_and_rosenbrock():
+    """Same two problems as the reference's src/tests/test_scg.py (which cannot pass there, see its header)."""
+    def sphere(x):
+        return float(np.sum(x ** 2))
+
+    def dsphere(x, eval_fun=False):
+        return 2.0 * x
+
+    opt = va.SCG(sphere, dsphere, {"max_it": 500, "x_tol": 1e-8, "f_tol": 1e-10})
+    x, fx = opt(np.random.default_rng(1).standard_normal(25) * 3)
+    assert fx < 1e-10 and np.allclose(x, 0.0, atol=1e-5)
+
+    def rosen(x):
+        return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2))
+
+    def drosen(x, eval_fun=False):
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2.0 * (1.0 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return g
+
+    opt = va.SCG(rosen, drosen, {"max_it": 5000, "x_tol": 1e-10, "f_tol": 1e-12})
+    x, fx = opt(np.array([-1.2, 1.0, -0.5, 0.8]))
+    assert fx < 1e-8 and np.allclose(x, 1.0, atol=1e-3)
+    assert opt.statistics["f_eval"] > 0 and opt.statistics["df_eval"] > 0
+
+
+def test_vargp_wiring_without_gpu(golden):
+    p = problem_from_golden(golden)
+    v = p["vgp"]
+    assert v.dim_n == golden["time_window"].size
+    assert v.dim_tot == v.dim_n * v.dim_d ** 2
+    assert set(v.arg_out) >= {"m0", "s0"}

@@ -1,0 +1,60 @@
+"""
+Builds vgpa_amd/lib/libvgpa_hip.so (the C-ABI HIP library) for gfx950 with hipcc.
+
+    python -m vgpa_amd.build            # incremental
+    python -m vgpa_amd.build --force
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libvgpa_hip.so")
+SOURCES = ["vgpa_api.hip", "ode_generic.hip", "ode_mfma.hip", "energy.hip", "assemble.hip", "host_linalg.cpp"]
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-ffp-contract=off"]
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src, *extra))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(HERE, "..", "include", "vgpa_hip.h")]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, headers):
+            cmd = [HIPCC, *CFLAGS, "-c", src, "-o", obj]
+            if s.endswith(".cpp"):
+                cmd.insert(1, "-x"); cmd.insert(2, "hip")
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for: {failed}")
+    if force or procs or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,667 @@
+// C ABI of libvgpa_hip.so (see include/vgpa_hip.h for the contract and the reference interfaces).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vgpa_internal.h"
+
+using namespace vgpa;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct vgpa_ctx {
+  vgpa_config cfg{};
+  int D = 0, Np = 0, B = 1, M = 0;
+  size_t DD = 0, len_x = 0;
+  bool single = false, full = false, sigma_diag = true, sym_inputs = true;
+  hipStream_t stream = nullptr;
+  std::string err;
+  double theta[kMaxTheta] = {0, 0, 0, 0};
+  // device buffers
+  std::vector<void*> allocs;
+  double *d_x = nullptr, *d_m = nullptr, *d_S = nullptr, *d_Ef = nullptr, *d_dEm = nullptr, *d_dEs = nullptr;
+  double *d_lam = nullptr, *d_psi = nullptr, *d_g = nullptr, *d_et = nullptr, *d_eobs = nullptr, *d_esde = nullptr;
+  double *d_f = nullptr, *d_jm = nullptr, *d_Edf = nullptr, *d_jm_dense = nullptr, *d_js_dense = nullptr;
+  double *d_m0 = nullptr, *d_S0 = nullptr, *d_Sigma = nullptr, *d_isig = nullptr, *d_isg = nullptr;
+  double *d_obs_y = nullptr, *d_Q = nullptr, *d_K = nullptr, *d_rinv = nullptr, *d_jsc = nullptr;
+  double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
+  int64_t* d_obs_t = nullptr;
+  int32_t *d_obs_idx = nullptr, *d_status = nullptr;
+  double obs_const = 0.0, sigma1 = 1.0;
+  bool have_state = false;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double prof_ms[4] = {0, 0, 0, 0};
+  int64_t prof_n = 0;
+  bool prof_pending = false;
+};
+
+namespace {
+
+int fail(vgpa_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                            \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail((c), VGPA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(vgpa_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  c->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return VGPA_OK;
+}
+
+template <typename T>
+int upload(vgpa_ctx* c, T* dst, const T* src, size_t count) {
+  HIP_TRY(c, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return VGPA_OK;
+}
+
+template <typename T>
+int download(vgpa_ctx* c, T* dst, const T* src, size_t count) {
+  HIP_TRY(c, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+  return VGPA_OK;
+}
+
+bool is_symmetric(const double* a, int n) {
+  double mx = 0.0, df = 0.0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      mx = std::fmax(mx, std::fabs(a[i * n + j]));
+      df = std::fmax(df, std::fabs(a[i * n + j] - a[j * n + i]));
+    }
+  return df <= 1e-14 * mx;
+}
+
+bool stack_symmetric(const double* a, size_t count, int n) {
+  for (size_t t = 0; t < count; t++)
+    if (!is_symmetric(a + t * n * n, n)) return false;
+  return true;
+}
+
+}  // namespace
+
+// x (host or device, [B][len_x]) -> d_A/d_b problem-major arrays.  d_x holds [B][Np*DD] of A followed
+// by [B][Np*D] of b.
+static inline double* ctx_A(vgpa_ctx* c) { return c->d_x; }
+static inline double* ctx_b(vgpa_ctx* c) { return c->d_x + (size_t)c->B * c->Np * c->DD; }
+
+static int ingest_x(vgpa_ctx* c, const double* x, bool on_device) {
+  const size_t na = (size_t)c->Np * c->DD, nb = (size_t)c->Np * c->D;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (c->B == 1) {
+    HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (na + nb) * sizeof(double), kind, c->stream));
+    return VGPA_OK;
+  }
+  HIP_TRY(c, hipMemcpy2DAsync(ctx_A(c), na * sizeof(double), x, c->len_x * sizeof(double), na * sizeof(double), c->B, kind, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(ctx_b(c), nb * sizeof(double), x + na, c->len_x * sizeof(double), nb * sizeof(double), c->B, kind, c->stream));
+  return VGPA_OK;
+}
+
+static void prof_mark(vgpa_ctx* c, int i) {
+  if (c->prof) (void)hipEventRecord(c->ev[i], c->stream);
+}
+
+static void prof_collect(vgpa_ctx* c) {
+  if (!c->prof || !c->prof_pending) return;
+  (void)hipEventSynchronize(c->ev[4]);
+  for (int i = 0; i < 4; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) c->prof_ms[i] += ms;
+  }
+  c->prof_n += c->B;
+  c->prof_pending = false;
+}
+
+static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
+  return sym && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && ode_mfma_supported(c->cfg.method, fwd, c->D);
+}
+
+static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
+  OdeArgs a{};
+  a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
+  hipError_t e = use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
+                                        : launch_ode_generic(c->cfg.method, true, a, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "forward sweep launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
+  OdeArgs a{};
+  a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
+  if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
+  else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
+  hipError_t e = use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
+                                         : launch_ode_generic(c->cfg.method, false, a, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "backward sweep launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
+  EnergyArgs a{};
+  a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
+  a.sigma1 = c->sigma1; a.isg = c->d_isg;
+  a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
+  a.e_t = c->d_et; a.Ef = c->d_Ef; a.Edf = edf; a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.status = c->d_status;
+  return a;
+}
+
+static int run_energy(vgpa_ctx* c, double* edf) {
+  EnergyArgs a = energy_args(c, edf);
+  hipError_t e = launch_energy(a, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "energy launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+static ObsArgs obs_args(vgpa_ctx* c) {
+  ObsArgs a{};
+  a.D = c->D; a.Np = c->Np; a.batch = c->B; a.n_obs = c->M; a.single = c->single ? 1 : 0;
+  a.obs_t = c->d_obs_t; a.obs_y = c->d_obs_y; a.Q = c->d_Q; a.K = c->d_K; a.rinv_diag = c->d_rinv;
+  a.obs_const = c->obs_const; a.m = c->d_m; a.S = c->d_S; a.jm_sparse = c->d_jm; a.eobs = c->d_eobs;
+  return a;
+}
+
+static int run_reduce(vgpa_ctx* c) {
+  ReduceArgs r{};
+  r.Np = c->Np; r.batch = c->B; r.dt = c->cfg.dt; r.e0 = c->cfg.e0;
+  r.pre = c->single ? 0.5 : 1.0; r.div = c->single ? c->sigma1 : 1.0;
+  r.e_t = c->d_et; r.eobs = c->d_eobs; r.esde = c->d_esde; r.f = c->d_f;
+  hipError_t e = launch_reduce(r, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "reduce launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+static int run_grad(vgpa_ctx* c, double* g_dev) {
+  GradArgs a{};
+  a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.sigma_diag = c->sigma_diag ? 1 : 0;
+  a.dt = c->cfg.dt;
+  for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
+  a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
+  a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
+  hipError_t e = launch_grad(a, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "gradient launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+// fwd -> E_obs -> E_sde terms -> bwd -> F     (VarGP.free_energy, variational.py:141-200)
+static int enqueue_free_energy(vgpa_ctx* c) {
+  if (!c->full) return fail(c, VGPA_ERR_STATE, "context was created without m0/s0/observations (ODE-only)");
+  int rc;
+  prof_collect(c);
+  HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  prof_mark(c, 0);
+  if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
+  prof_mark(c, 1);
+  hipError_t e = launch_obs(obs_args(c), c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
+  if ((rc = run_energy(c, nullptr))) return rc;
+  prof_mark(c, 2);
+  if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
+  prof_mark(c, 3);
+  if ((rc = run_reduce(c))) return rc;
+  c->have_state = true;
+  return VGPA_OK;
+}
+
+static int check_status(vgpa_ctx* c) {
+  std::vector<int32_t> st(c->B);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->d_status, sizeof(int32_t) * c->B, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int p = 0; p < c->B; p++)
+    if (st[p] & 1)
+      return fail(c, VGPA_ERR_NOT_PD, "problem %d: marginal covariance S_t is not positive definite "
+                  "(reference: LinAlgError from chol_inv, variational.py:380)", p);
+  return VGPA_OK;
+}
+
+// =====================================================================================================
+extern "C" {
+
+int vgpa_abi_version(void) { return VGPA_ABI_VERSION; }
+
+int vgpa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* vgpa_last_error(const vgpa_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void vgpa_destroy(vgpa_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, VGPA_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != VGPA_ABI_VERSION) return fail(nullptr, VGPA_ERR_ARG, "ABI version mismatch: %d != %d", cfg->abi_version, VGPA_ABI_VERSION);
+  if (!(cfg->dt > 0.0)) return fail(nullptr, VGPA_ERR_ARG, "Discrete time step should be strictly positive -> %g.", cfg->dt);
+  if (cfg->method < VGPA_ODE_EULER || cfg->method > VGPA_ODE_RK4) return fail(nullptr, VGPA_ERR_ARG, "Integration method is unknown -> %d.", cfg->method);
+  if (cfg->model < VGPA_MODEL_NONE || cfg->model > VGPA_MODEL_L96) return fail(nullptr, VGPA_ERR_ARG, "Unknown stochastic model -> %d", cfg->model);
+  if (cfg->dim_d < 1 || cfg->n_pts < 2 || cfg->batch < 1 || cfg->n_obs < 0) return fail(nullptr, VGPA_ERR_ARG, "bad sizes: D=%d Np=%d batch=%d M=%d", cfg->dim_d, cfg->n_pts, cfg->batch, cfg->n_obs);
+  const bool single = (cfg->model == VGPA_MODEL_OU || cfg->model == VGPA_MODEL_DW) ||
+                      (cfg->model == VGPA_MODEL_NONE && cfg->dim_d == 1);
+  if (single && cfg->dim_d != 1) return fail(nullptr, VGPA_ERR_ARG, "1-D model with D=%d", cfg->dim_d);
+  if (cfg->model == VGPA_MODEL_L63 && cfg->dim_d != 3) return fail(nullptr, VGPA_ERR_ARG, "Lorenz-63 needs D=3, got %d", cfg->dim_d);
+  if (cfg->model == VGPA_MODEL_L96 && cfg->dim_d < 4) return fail(nullptr, VGPA_ERR_ARG, "Insufficient state vector dimensions: %d", cfg->dim_d);
+  if (cfg->dim_d > kMaxSmallD) return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d: the large-D (multi-workgroup GEMM) path is not built yet", cfg->dim_d, kMaxSmallD);
+  const int need_theta = (cfg->model == VGPA_MODEL_L63) ? 3 : (cfg->model == VGPA_MODEL_NONE ? 0 : 1);
+  if (cfg->n_theta != need_theta || (need_theta > 0 && !cfg->theta)) return fail(nullptr, VGPA_ERR_ARG, "model needs %d drift parameter(s)", need_theta);
+  if (!cfg->sigma) return fail(nullptr, VGPA_ERR_ARG, "sigma is required");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, VGPA_ERR_DEVICE, "no HIP device is visible (libvgpa_hip has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, VGPA_ERR_DEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
+
+  vgpa_ctx* c = new vgpa_ctx();
+  c->cfg = *cfg;
+  c->D = cfg->dim_d; c->Np = cfg->n_pts; c->B = cfg->batch; c->M = cfg->n_obs;
+  c->DD = (size_t)c->D * c->D;
+  c->len_x = (size_t)c->Np * c->DD + (size_t)c->Np * c->D;
+  c->single = single;
+  for (int i = 0; i < cfg->n_theta; i++) c->theta[i] = cfg->theta[i];
+  c->full = cfg->model != VGPA_MODEL_NONE && cfg->m0 && cfg->s0 && (cfg->n_obs == 0 || (cfg->obs_t && cfg->obs_y && cfg->obs_noise));
+  const int D = c->D;
+  const size_t DD = c->DD;
+  int rc = VGPA_OK;
+#define TRY(expr) do { rc = (expr); if (rc != VGPA_OK) { g_create_error = c->err; vgpa_destroy(c); return rc; } } while (0)
+#define HTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, VGPA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); vgpa_destroy(c); return VGPA_ERR_DEVICE; } } while (0)
+  HTRY(hipSetDevice(cfg->device));
+  HTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& e : c->ev) HTRY(hipEventCreate(&e));
+
+  // ---- host-side constants -------------------------------------------------------------------
+  std::vector<double> sigma(cfg->sigma, cfg->sigma + DD), isig(DD, 0.0), isg(D, 0.0);
+  if (single) {
+    if (!(sigma[0] > 0.0)) { fail(nullptr, VGPA_ERR_ARG, "The diffusion noise value: %g, should be strictly positive.", sigma[0]); vgpa_destroy(c); return VGPA_ERR_ARG; }
+    c->sigma1 = sigma[0]; isig[0] = 1.0 / sigma[0]; isg[0] = isig[0];
+  } else {
+    if (!host_spd_inverse(D, sigma.data(), isig.data(), nullptr)) { fail(nullptr, VGPA_ERR_NOT_PD, "Noise matrix is not positive definite."); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+    for (int i = 0; i < D; i++) isg[i] = isig[(size_t)i * D + i];
+    c->sigma_diag = true;
+    for (int i = 0; i < D && c->sigma_diag; i++)
+      for (int j = 0; j < D; j++)
+        if (i != j && sigma[(size_t)i * D + j] != 0.0) { c->sigma_diag = false; break; }
+    if (c->sigma_diag)   // exact reciprocals on the diagonal, exact zeros elsewhere
+      for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) if (i != j) isig[(size_t)i * D + j] = 0.0;
+  }
+  c->sym_inputs = is_symmetric(sigma.data(), D) && (!cfg->s0 || is_symmetric(cfg->s0, D));
+
+  const size_t BN = (size_t)c->B * c->Np;
+  TRY(dev_alloc(c, &c->d_x, (size_t)c->B * c->len_x));
+  TRY(dev_alloc(c, &c->d_m, BN * D));
+  TRY(dev_alloc(c, &c->d_S, BN * DD));
+  TRY(dev_alloc(c, &c->d_Ef, BN * D));
+  TRY(dev_alloc(c, &c->d_dEm, BN * D));
+  TRY(dev_alloc(c, &c->d_dEs, BN * DD));
+  TRY(dev_alloc(c, &c->d_lam, BN * D));
+  TRY(dev_alloc(c, &c->d_psi, BN * DD));
+  TRY(dev_alloc(c, &c->d_g, (size_t)c->B * c->len_x));
+  TRY(dev_alloc(c, &c->d_et, BN));
+  TRY(dev_alloc(c, &c->d_eobs, (size_t)c->B));
+  TRY(dev_alloc(c, &c->d_esde, (size_t)c->B));
+  TRY(dev_alloc(c, &c->d_f, (size_t)c->B));
+  TRY(dev_alloc(c, &c->d_status, (size_t)c->B));
+  TRY(dev_alloc(c, &c->d_jm, (size_t)c->B * (c->M > 0 ? c->M : 1) * D));
+  TRY(dev_alloc(c, &c->d_Sigma, DD));
+  TRY(dev_alloc(c, &c->d_isig, DD));
+  TRY(dev_alloc(c, &c->d_isg, (size_t)D));
+  TRY(dev_alloc(c, &c->d_m0, (size_t)D));
+  TRY(dev_alloc(c, &c->d_S0, DD));
+  TRY(dev_alloc(c, &c->d_op_m0, (size_t)D));
+  TRY(dev_alloc(c, &c->d_op_S0, DD));
+  TRY(dev_alloc(c, &c->d_op_Sigma, DD));
+  TRY(dev_alloc(c, &c->d_obs_idx, (size_t)c->Np));
+  TRY(dev_alloc(c, &c->d_obs_t, (size_t)(c->M > 0 ? c->M : 1)));
+  TRY(dev_alloc(c, &c->d_obs_y, (size_t)(c->M > 0 ? c->M : 1) * D));
+  TRY(dev_alloc(c, &c->d_Q, DD));
+  TRY(dev_alloc(c, &c->d_K, DD));
+  TRY(dev_alloc(c, &c->d_rinv, (size_t)D));
+  TRY(dev_alloc(c, &c->d_jsc, DD));
+  HTRY(hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  HTRY(hipMemsetAsync(c->d_eobs, 0, sizeof(double) * c->B, c->stream));
+  HTRY(hipMemsetAsync(c->d_jm, 0, sizeof(double) * (size_t)c->B * (c->M > 0 ? c->M : 1) * D, c->stream));
+  HTRY(hipMemsetAsync(c->d_jsc, 0, sizeof(double) * DD, c->stream));
+
+  TRY(upload(c, c->d_Sigma, sigma.data(), DD));
+  TRY(upload(c, c->d_isig, isig.data(), DD));
+  TRY(upload(c, c->d_isg, isg.data(), (size_t)D));
+  if (cfg->m0) TRY(upload(c, c->d_m0, cfg->m0, (size_t)D));
+  if (cfg->s0) TRY(upload(c, c->d_S0, cfg->s0, DD));
+
+  std::vector<int32_t> obs_idx(c->Np, -1);
+  std::vector<double> Q(DD, 0.0), K(DD, 0.0), rinv(D, 0.0), jsc(DD, 0.0);
+  if (c->M > 0 && cfg->obs_t && cfg->obs_y && cfg->obs_noise) {
+    for (int n = 0; n < c->M; n++) {
+      const int64_t tn = cfg->obs_t[n];
+      if (tn < 0 || tn >= c->Np || (n > 0 && tn <= cfg->obs_t[n - 1])) { fail(nullptr, VGPA_ERR_ARG, "obs_t must be strictly increasing indices in [0, Np)"); vgpa_destroy(c); return VGPA_ERR_ARG; }
+      obs_idx[tn] = n;
+    }
+    if (single) {
+      const double r = cfg->obs_noise[0];
+      if (!(r > 0.0)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise must be positive"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+      const double h = cfg->obs_h ? cfg->obs_h[0] : 1.0;
+      Q[0] = 1.0 / r; K[0] = h; rinv[0] = 1.0 / r; jsc[0] = 0.5 / r;
+      c->obs_const = 0.5 * c->M * (std::log(2.0 * M_PI) + std::log(r));
+    } else {
+      std::vector<double> Rinv(DD), H(DD, 0.0), T(DD);
+      double logdet = 0.0;
+      if (!host_spd_inverse(D, cfg->obs_noise, Rinv.data(), &logdet)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise matrix is not positive definite"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+      if (cfg->obs_h) H.assign(cfg->obs_h, cfg->obs_h + DD); else for (int i = 0; i < D; i++) H[(size_t)i * D + i] = 1.0;
+      host_matmul(D, H.data(), Rinv.data(), T.data(), false, false);      // H R^-1
+      host_matmul(D, T.data(), H.data(), Q.data(), false, true);          // H R^-1 H^T
+      host_matmul(D, H.data(), Rinv.data(), T.data(), true, false);       // H^T R^-1
+      host_matmul(D, T.data(), H.data(), K.data(), false, true);          // H^T R^-1 H^T
+      host_matmul(D, T.data(), H.data(), jsc.data(), false, false);       // H^T R^-1 H
+      for (auto& v : jsc) v *= 0.5;
+      for (int i = 0; i < D; i++) rinv[i] = Rinv[(size_t)i * D + i];
+      c->obs_const = c->M * (D * std::log(2.0 * M_PI) + logdet);
+      c->sym_inputs = c->sym_inputs && is_symmetric(jsc.data(), D);
+    }
+    TRY(upload(c, c->d_obs_t, cfg->obs_t, (size_t)c->M));
+    TRY(upload(c, c->d_obs_y, cfg->obs_y, (size_t)c->M * D));
+  }
+  TRY(upload(c, c->d_obs_idx, obs_idx.data(), (size_t)c->Np));
+  TRY(upload(c, c->d_Q, Q.data(), DD));
+  TRY(upload(c, c->d_K, K.data(), DD));
+  TRY(upload(c, c->d_rinv, rinv.data(), (size_t)D));
+  TRY(upload(c, c->d_jsc, jsc.data(), DD));
+  HTRY(hipStreamSynchronize(c->stream));
+#undef TRY
+#undef HTRY
+  *out = c;
+  return VGPA_OK;
+}
+
+int vgpa_synchronize(vgpa_ctx* c) {
+  if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VGPA_OK;
+}
+
+void* vgpa_stream(vgpa_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- operator level ---------------------------------------------------------------------------------
+int vgpa_solve_fwd(vgpa_ctx* c, const double* lin_a, const double* off_b, const double* m0, const double* s0,
+                   const double* sigma, double* mt, double* st) {
+  if (!c || !lin_a || !off_b || !m0 || !s0 || !sigma || !mt || !st) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc;
+  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
+  if ((rc = upload(c, ctx_b(c), off_b, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_op_m0, m0, (size_t)c->D))) return rc;
+  if ((rc = upload(c, c->d_op_S0, s0, c->DD))) return rc;
+  if ((rc = upload(c, c->d_op_Sigma, sigma, c->DD))) return rc;
+  const bool sym = is_symmetric(s0, c->D) && is_symmetric(sigma, c->D);
+  if ((rc = run_fwd(c, c->d_op_m0, c->d_op_S0, c->d_op_Sigma, sym))) return rc;
+  if ((rc = download(c, mt, c->d_m, BN * c->D))) return rc;
+  if ((rc = download(c, st, c->d_S, BN * c->DD))) return rc;
+  c->have_state = false;
+  return vgpa_synchronize(c);
+}
+
+int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, const double* desde_ds,
+                   const double* deobs_dm, const double* deobs_ds, double* lam, double* psi) {
+  if (!c || !lin_a || !desde_dm || !desde_ds || !deobs_dm || !deobs_ds || !lam || !psi) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc;
+  if (!c->d_jm_dense) {
+    if ((rc = dev_alloc(c, &c->d_jm_dense, BN * c->D))) return rc;
+    if ((rc = dev_alloc(c, &c->d_js_dense, BN * c->DD))) return rc;
+  }
+  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
+  if ((rc = upload(c, c->d_dEm, desde_dm, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_dEs, desde_ds, BN * c->DD))) return rc;
+  if ((rc = upload(c, c->d_jm_dense, deobs_dm, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_js_dense, deobs_ds, BN * c->DD))) return rc;
+  const bool sym = stack_symmetric(desde_ds, BN, c->D) && stack_symmetric(deobs_ds, BN, c->D);
+  if ((rc = run_bwd(c, true, sym))) return rc;
+  if ((rc = download(c, lam, c->d_lam, BN * c->D))) return rc;
+  if ((rc = download(c, psi, c->d_psi, BN * c->DD))) return rc;
+  c->have_state = false;
+  return vgpa_synchronize(c);
+}
+
+int vgpa_energy(vgpa_ctx* c, const double* lin_a, const double* off_b, const double* mt, const double* st,
+                double* esde, double* efx, double* edf, double* desde_dm, double* desde_ds) {
+  if (!c || !lin_a || !off_b || !mt || !st) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc;
+  if (edf && !c->d_Edf && (rc = dev_alloc(c, &c->d_Edf, BN * c->DD))) return rc;
+  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
+  if ((rc = upload(c, ctx_b(c), off_b, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  if ((rc = run_energy(c, edf ? c->d_Edf : nullptr))) return rc;
+  if ((rc = run_reduce(c))) return rc;
+  if ((rc = check_status(c))) return rc;
+  if (esde && (rc = download(c, esde, c->d_esde, (size_t)c->B))) return rc;
+  if (efx && (rc = download(c, efx, c->d_Ef, BN * c->D))) return rc;
+  if (edf && (rc = download(c, edf, c->d_Edf, BN * c->DD))) return rc;
+  if (desde_dm && (rc = download(c, desde_dm, c->d_dEm, BN * c->D))) return rc;
+  if (desde_ds && (rc = download(c, desde_ds, c->d_dEs, BN * c->DD))) return rc;
+  c->have_state = false;
+  return vgpa_synchronize(c);
+}
+
+int vgpa_obs_energy(vgpa_ctx* c, const double* mt, const double* st, double* eobs, double* deobs_dm, double* deobs_ds) {
+  if (!c || !mt || !st) return fail(c, VGPA_ERR_ARG, "null argument");
+  if (!c->cfg.obs_t && c->M > 0) return fail(c, VGPA_ERR_STATE, "context has no observations");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc;
+  if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
+  if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
+  ObsArgs a = obs_args(c);
+  hipError_t e = launch_obs(a, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
+  if (eobs && (rc = download(c, eobs, c->d_eobs, (size_t)c->B))) return rc;
+  if (deobs_dm || deobs_ds) {
+    if (!c->d_jm_dense) {
+      if ((rc = dev_alloc(c, &c->d_jm_dense, BN * c->D))) return rc;
+      if ((rc = dev_alloc(c, &c->d_js_dense, BN * c->DD))) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_jm_dense, 0, sizeof(double) * BN * c->D, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_js_dense, 0, sizeof(double) * BN * c->DD, c->stream));
+    e = launch_obs_dense(a, c->d_jsc, c->d_jm_dense, c->d_js_dense, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs dense launch failed: %s", hipGetErrorString(e));
+    if (deobs_dm && (rc = download(c, deobs_dm, c->d_jm_dense, BN * c->D))) return rc;
+    if (deobs_ds && (rc = download(c, deobs_ds, c->d_js_dense, BN * c->DD))) return rc;
+  }
+  c->have_state = false;
+  return vgpa_synchronize(c);
+}
+
+// ---- fused objective --------------------------------------------------------------------------------
+int vgpa_free_energy(vgpa_ctx* c, const double* x, double* f) {
+  if (!c || !x || !f) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = ingest_x(c, x, false))) return rc;
+  if ((rc = enqueue_free_energy(c))) return rc;
+  return vgpa_fetch_f(c, f);
+}
+
+int vgpa_free_energy_dev(vgpa_ctx* c, const double* x_dev, double* f_host) {
+  if (!c || !x_dev || !f_host) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = ingest_x(c, x_dev, true))) return rc;
+  if ((rc = enqueue_free_energy(c))) return rc;
+  return vgpa_fetch_f(c, f_host);
+}
+
+int vgpa_fetch_f(vgpa_ctx* c, double* f_host) {
+  if (!c || !f_host) return fail(c, VGPA_ERR_ARG, "null argument");
+  int rc;
+  if ((rc = download(c, f_host, c->d_f, (size_t)c->B))) return rc;
+  return check_status(c);
+}
+
+static int finish_gradient(vgpa_ctx* c, double* g_dev) {
+  int rc = run_grad(c, g_dev);
+  if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+  return rc;
+}
+
+int vgpa_gradient(vgpa_ctx* c, const double* x_or_null, double* g) {
+  if (!c || !g) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if (x_or_null) {
+    if ((rc = ingest_x(c, x_or_null, false))) return rc;
+    if ((rc = enqueue_free_energy(c))) return rc;
+  } else if (!c->have_state) {
+    return fail(c, VGPA_ERR_STATE, "gradient(x, eval_fun=False) needs the state cached by a previous free_energy");
+  }
+  if ((rc = finish_gradient(c, c->d_g))) return rc;
+  if ((rc = download(c, g, c->d_g, (size_t)c->B * c->len_x))) return rc;
+  return check_status(c);
+}
+
+int vgpa_sweep(vgpa_ctx* c, const double* x, double* f, double* g) {
+  if (!c || !x || !f || !g) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = ingest_x(c, x, false))) return rc;
+  if ((rc = enqueue_free_energy(c))) return rc;
+  if ((rc = finish_gradient(c, c->d_g))) return rc;
+  if ((rc = download(c, g, c->d_g, (size_t)c->B * c->len_x))) return rc;
+  return vgpa_fetch_f(c, f);
+}
+
+int vgpa_sweep_enqueue(vgpa_ctx* c, const double* x_dev, double* g_dev) {
+  if (!c || !x_dev || !g_dev) return fail(c, VGPA_ERR_ARG, "null argument");
+  int rc;
+  if ((rc = ingest_x(c, x_dev, true))) return rc;
+  if ((rc = enqueue_free_energy(c))) return rc;
+  return finish_gradient(c, g_dev);
+}
+
+int vgpa_sweep_dev(vgpa_ctx* c, const double* x_dev, double* f_host, double* g_dev) {
+  if (!c || !f_host) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = vgpa_sweep_enqueue(c, x_dev, g_dev))) return rc;
+  return vgpa_fetch_f(c, f_host);
+}
+
+int vgpa_energy_parts(vgpa_ctx* c, double* e0, double* esde, double* eobs) {
+  if (!c) return VGPA_ERR_ARG;
+  if (!c->have_state) return fail(c, VGPA_ERR_STATE, "no cached state");
+  int rc;
+  if (e0) for (int p = 0; p < c->B; p++) e0[p] = c->cfg.e0;
+  if (esde && (rc = download(c, esde, c->d_esde, (size_t)c->B))) return rc;
+  if (eobs && (rc = download(c, eobs, c->d_eobs, (size_t)c->B))) return rc;
+  return vgpa_synchronize(c);
+}
+
+int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
+  if (!c || !out) return fail(c, VGPA_ERR_ARG, "null argument");
+  if (!c->have_state) return fail(c, VGPA_ERR_STATE, "no cached state: call free_energy first");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc = VGPA_OK;
+  switch (which) {
+    case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;
+    case VGPA_FETCH_ST: rc = download(c, out, c->d_S, BN * c->DD); break;
+    case VGPA_FETCH_LAMT: rc = download(c, out, c->d_lam, BN * c->D); break;
+    case VGPA_FETCH_PSIT: rc = download(c, out, c->d_psi, BN * c->DD); break;
+    case VGPA_FETCH_EFX: rc = download(c, out, c->d_Ef, BN * c->D); break;
+    case VGPA_FETCH_DESDE_DM: rc = download(c, out, c->d_dEm, BN * c->D); break;
+    case VGPA_FETCH_DESDE_DS: rc = download(c, out, c->d_dEs, BN * c->DD); break;
+    case VGPA_FETCH_ESDE_T: rc = download(c, out, c->d_et, BN); break;
+    case VGPA_FETCH_EDF: {
+      if (!c->d_Edf && (rc = dev_alloc(c, &c->d_Edf, BN * c->DD))) return rc;
+      EnergyArgs a = energy_args(c, c->d_Edf);
+      hipError_t e = launch_edf(a, c->stream);
+      if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "edf launch failed: %s", hipGetErrorString(e));
+      rc = download(c, out, c->d_Edf, BN * c->DD);
+      break;
+    }
+    default: return fail(c, VGPA_ERR_ARG, "unknown fetch selector %d", which);
+  }
+  if (rc) return rc;
+  return vgpa_synchronize(c);
+}
+
+// ---- raw device memory ------------------------------------------------------------------------------
+int vgpa_dev_alloc(vgpa_ctx* c, uint64_t bytes, void** out) {
+  if (!c || !out) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  HIP_TRY(c, hipMalloc(out, bytes ? bytes : 8));
+  return VGPA_OK;
+}
+int vgpa_dev_free(vgpa_ctx* c, void* ptr) {
+  if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipFree(ptr));
+  return VGPA_OK;
+}
+int vgpa_memcpy_h2d(vgpa_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VGPA_OK;
+}
+int vgpa_memcpy_d2h(vgpa_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VGPA_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------
+int vgpa_profile_begin(vgpa_ctx* c) {
+  if (!c) return VGPA_ERR_ARG;
+  c->prof = true; c->prof_pending = false; c->prof_n = 0;
+  for (auto& v : c->prof_ms) v = 0.0;
+  return VGPA_OK;
+}
+int vgpa_profile_end(vgpa_ctx* c, double* fwd_ms, double* energy_ms, double* bwd_ms, double* grad_ms, int64_t* n_sweeps) {
+  if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  c->prof = false;
+  if (fwd_ms) *fwd_ms = c->prof_ms[0];
+  if (energy_ms) *energy_ms = c->prof_ms[1];
+  if (bwd_ms) *bwd_ms = c->prof_ms[2];
+  if (grad_ms) *grad_ms = c->prof_ms[3];
+  if (n_sweeps) *n_sweeps = c->prof_n;
+  return VGPA_OK;
+}
+
+}  // extern "C"

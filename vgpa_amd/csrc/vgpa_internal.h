@@ -1,0 +1,112 @@
+// Internal declarations shared by the translation units of libvgpa_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vgpa_hip.h"
+
+namespace vgpa {
+
+constexpr int kMaxSmallD = 64;   // single-workgroup (LDS resident) stepping kernels
+constexpr int kMaxTheta = 4;
+
+// Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
+struct OdeArgs {
+  int D, Np, batch;
+  double dt;
+  // forward
+  const double* A;       // [B][Np][D][D]
+  const double* b;       // [B][Np][D]
+  const double* m0;      // [D]
+  const double* S0;      // [D][D]
+  const double* Sigma;   // [D][D]
+  double* m;             // [B][Np][D]
+  double* S;             // [B][Np][D][D]
+  // backward
+  const double* dEm;     // [B][Np][D]
+  const double* dEs;     // [B][Np][D][D]
+  const double* jm_dense;  // [B][Np][D]      or nullptr (then the sparse form is used)
+  const double* js_dense;  // [B][Np][D][D]   or nullptr
+  const int32_t* obs_idx;  // [Np] -> observation counter n, or -1
+  const double* jm_sparse; // [B][M][D]
+  const double* js_const;  // [D][D]
+  int n_obs;
+  double* lam;           // [B][Np][D]
+  double* psi;           // [B][Np][D][D]
+};
+
+struct EnergyArgs {
+  int model, D, Np, batch;
+  double dt;
+  double theta[kMaxTheta];
+  double sigma1;            // 1-D models: sigma
+  const double* isg;        // [D] diagonal of Sigma^-1
+  const double* A;          // [B][Np][D][D]
+  const double* b;          // [B][Np][D]
+  const double* m;          // [B][Np][D]
+  const double* S;          // [B][Np][D][D]
+  double* e_t;              // [B][Np] integrand of E_sde
+  double* Ef;               // [B][Np][D]
+  double* Edf;              // [B][Np][D][D] or nullptr
+  double* dEm;              // [B][Np][D]
+  double* dEs;              // [B][Np][D][D]
+  int32_t* status;          // [B] device status word (bit0: S_t not positive definite)
+};
+
+struct ObsArgs {
+  int D, Np, batch, n_obs, single;
+  const int64_t* obs_t;     // [M]
+  const double* obs_y;      // [M][D]
+  const double* Q;          // [D][D]  H R^-1 H^T     (1-D: 1/r)
+  const double* K;          // [D][D]  H^T R^-1 H^T   (1-D: H/r ... see obs kernel)
+  const double* rinv_diag;  // [D]     diag(R^-1)
+  double obs_const;         // M*(d*log(2pi) + logdet R)
+  const double* m;          // [B][Np][D]
+  const double* S;          // [B][Np][D][D]
+  double* jm_sparse;        // [B][M][D]
+  double* eobs;             // [B]
+};
+
+struct GradArgs {
+  int model, D, Np, batch, sigma_diag;
+  double dt;
+  double theta[kMaxTheta];
+  const double* isig;       // [D][D] Sigma^-1
+  const double* A; const double* b;
+  const double* m; const double* S;
+  const double* lam; const double* psi;
+  const double* Ef;
+  const double* Edf;        // dense [B][Np][D][D] or nullptr (then recomputed from the model)
+  double* g;                // [B][Np*D*D + Np*D]
+};
+
+struct ReduceArgs {
+  int Np, batch;
+  double dt, pre, div, e0;
+  const double* e_t;        // [B][Np]
+  const double* eobs;       // [B]
+  double* esde;             // [B]
+  double* f;                // [B]
+};
+
+// launchers (each returns hipGetLastError()) -----------------------------------------------------
+hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_t st);
+bool ode_mfma_supported(int method, bool fwd, int D);
+hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
+hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
+hipError_t launch_obs(const ObsArgs& a, hipStream_t st);
+hipError_t launch_obs_dense(const ObsArgs& a, const double* js_const, double* jm_dense, double* js_dense,
+                            hipStream_t st);
+hipError_t launch_grad(const GradArgs& a, hipStream_t st);
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
+hipError_t launch_edf(const EnergyArgs& a, hipStream_t st);   // dense <df/dx> on request
+
+// tiny host-side dense helpers (row-major, fp64) ---------------------------------------------------
+bool host_cholesky_lower(int n, const double* a, double* l);          // uses the lower triangle of a
+void host_lower_inverse(int n, const double* l, double* linv);
+bool host_spd_inverse(int n, const double* a, double* ainv, double* logdet);
+void host_matmul(int n, const double* a, const double* b, double* c, bool ta, bool tb);
+
+}  // namespace vgpa

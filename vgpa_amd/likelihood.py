@@ -1,0 +1,118 @@
+"""
+Observation likelihood and the KL term at t=0: host-side mirrors of
+src/var_bayes/likelihood.py, src/var_bayes/gaussian_like.py and src/var_bayes/prior_kl0.py.
+
+GaussianLikelihood evaluates E_obs and the jump arrays on the GPU (vgpa_obs_energy).  PriorKL0 is a
+constant of the optimisation (m0, s0 are fixed, variational.py:22-26) and is evaluated once on the host.
+"""
+import numpy as np
+
+from ._lib import Context
+
+
+class Likelihood(object):
+    """Stores observation values / times / noise / operator (src/var_bayes/likelihood.py:13-48)."""
+
+    def __init__(self, values, times, noise, operator=None) -> None:
+        self.obs_t = np.asarray(times)
+        self.obs_v = np.asarray(values)
+        self.obs_n = np.asarray(noise)
+        if operator is None:
+            y0 = self.obs_v[0]
+            self.obs_h = np.asarray(1) if y0.ndim == 0 else np.eye(y0.size)
+        else:
+            self.obs_h = np.asarray(operator)
+
+    @property
+    def values(self):
+        return self.obs_v
+
+    @property
+    def times(self):
+        return self.obs_t
+
+    @property
+    def noise(self):
+        return self.obs_n
+
+    @noise.setter
+    def noise(self, new_value):
+        self.obs_n = new_value
+
+    @property
+    def operator(self):
+        return self.obs_h
+
+
+class GaussianLikelihood(Likelihood):
+    """Gaussian likelihood (src/var_bayes/gaussian_like.py:69-243); quirk Q4 of the n-D energy is kept."""
+
+    LOG2PI = np.log(2.0 * np.pi)
+
+    def __init__(self, values, times, noise, operator, single_dim: bool = True) -> None:
+        super().__init__(values, times, noise, operator)
+        self.single_dim = single_dim
+        self._ctx = {}
+        self.device = 0
+
+    def _context(self, n_pts, dim_d):
+        key = (n_pts, dim_d, self.device)
+        ctx = self._ctx.get(key)
+        if ctx is None:
+            self._ctx.clear()
+            ctx = Context("NONE", "euler", dim_d, n_pts, 1.0, sigma=np.eye(dim_d), obs_t=self.times,
+                          obs_y=self.values, obs_noise=np.asarray(self.noise, dtype=float).reshape(dim_d, dim_d),
+                          obs_h=np.asarray(self.operator, dtype=float).reshape(dim_d, dim_d), device=self.device)
+            self._ctx[key] = ctx
+        return ctx
+
+    def _run(self, m, s, want_jumps):
+        m = np.asarray(m, dtype=float)
+        if self.single_dim:
+            n = m.size
+            ctx = self._context(n, 1)
+            if s is None:
+                s = np.zeros(n)
+            out = ctx.obs_energy(m.reshape(n, 1), np.asarray(s, dtype=float).reshape(n, 1, 1), want_jumps)
+            if not want_jumps:
+                return out
+            return out[0], out[1].reshape(n), out[2].reshape(n)
+        n, d = m.shape
+        ctx = self._context(n, d)
+        if s is None:
+            s = np.zeros((n, d, d))
+        return ctx.obs_energy(m, s, want_jumps)
+
+    def __call__(self, m, s):
+        return self._run(m, s, False)
+
+    def gradients(self, m, s=None):
+        """(dEobs_dm, dEobs_ds, dEobs_dr); dEobs_dr (unused by VarGP) is returned as None."""
+        _, jm, js = self._run(m, s, True)
+        return jm, js, None
+
+
+class PriorKL0(object):
+    """KL(q0 || p0) (src/var_bayes/prior_kl0.py:30-92), value only (its gradients have no caller)."""
+
+    def __init__(self, mu0, tau0, single_dim: bool = True) -> None:
+        self.mu0 = np.asarray(mu0)
+        self.tau0 = np.asarray(tau0)
+        self.single_dim = single_dim
+
+    def __call__(self, m0, s0):
+        z0 = m0 - self.mu0
+        if self.single_dim:
+            return -np.log(s0) - 0.5 * (1.0 - np.log(self.tau0)) + 0.5 / self.tau0 * (z0 ** 2 + s0)
+
+        def spd_inv(x):
+            c_inv = np.linalg.solve(np.linalg.cholesky(x), np.eye(x.shape[0]))
+            return c_inv.T.dot(c_inv)
+
+        def chol_logdet(x):        # Cholesky of the lower triangle, also for a non-symmetric product (Q5)
+            return 2.0 * np.sum(np.log(np.linalg.cholesky(x).diagonal()))
+
+        inv_tau0, inv_s0 = spd_inv(self.tau0), spd_inv(np.asarray(s0))
+        # Q5: z0.T.dot(z0) is a scalar that numpy broadcasts over the whole matrix.
+        return 0.5 * (chol_logdet(self.tau0.dot(inv_s0)) +
+                      np.sum(np.diag(inv_tau0.dot(z0.T.dot(z0) + s0 - self.tau0))))

@@ -1,0 +1,120 @@
+"""
+Host-side mirror of the reference's stepper plugin surface, backed by the HIP kernels.
+
+  num_integration = {"euler", "heun", "rk2", "rk4"}          src/numerics/utilities.py:12-13
+  <Stepper>(dt, single_dim).solve_fwd / .solve_bwd           src/numerics/{euler,heun,runge_kutta2,runge_kutta4}.py
+  FwdOde(dt, method, single_dim)(at, bt, m0, s0, sigma)      src/var_bayes/fwd_ode.py:14-65
+  BwdOde(dt, method, single_dim)(at, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)   src/var_bayes/bwd_ode.py:14-65
+
+Same names, argument meaning and error behaviour (ValueError for dt <= 0 and for an unknown method).
+Every call goes through libvgpa_hip.so (vgpa_solve_fwd / vgpa_solve_bwd); there is no CPU path.
+"""
+import numpy as np
+
+from ._lib import Context
+
+
+class OdeSolver(object):
+    """Parent of the four steppers (src/numerics/ode_solver.py:4-29)."""
+
+    method = None
+
+    def __init__(self, dt: float = 0.01, single_dim: bool = True) -> None:
+        if dt <= 0.0:
+            raise ValueError(f" {self.__class__.__name__}:"
+                             f" Discrete time step should be positive --> {dt}.")
+        self.dt = dt
+        self.single_dim = single_dim
+        self._ctx = {}
+        self.device = 0
+        self.flags = 0
+
+    def _context(self, dim_d, n_pts):
+        key = (dim_d, n_pts, self.device, self.flags)
+        ctx = self._ctx.get(key)
+        if ctx is None:
+            self._ctx.clear()          # one live workspace per stepper object
+            ctx = Context("NONE", self.method, dim_d, n_pts, self.dt, sigma=np.eye(dim_d), device=self.device,
+                          flags=self.flags)
+            self._ctx[key] = ctx
+        return ctx
+
+    def solve_fwd(self, lin_a, off_b, m0, s0, sigma):
+        """(m_t, S_t): same contract as <stepper>.solve_fwd of the reference."""
+        off_b = np.asarray(off_b, dtype=float)
+        if self.single_dim:
+            n = off_b.size
+            ctx = self._context(1, n)
+            mt, st = ctx.solve_fwd(np.asarray(lin_a, dtype=float).reshape(n, 1, 1), off_b.reshape(n, 1),
+                                   np.array([m0], dtype=float), np.array([s0], dtype=float),
+                                   np.array([sigma], dtype=float))
+            return mt.reshape(n), st.reshape(n)
+        n, d = off_b.shape
+        ctx = self._context(d, n)
+        return ctx.solve_fwd(lin_a, off_b, m0, s0, sigma)
+
+    def solve_bwd(self, lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds):
+        """(lam_t, Psi_t): same contract as <stepper>.solve_bwd of the reference."""
+        dEsde_dm = np.asarray(dEsde_dm, dtype=float)
+        if self.single_dim:
+            n = dEsde_dm.size
+            ctx = self._context(1, n)
+            r3 = lambda v: np.asarray(v, dtype=float).reshape(n, 1, 1)   # noqa: E731
+            r2 = lambda v: np.asarray(v, dtype=float).reshape(n, 1)      # noqa: E731
+            lam, psi = ctx.solve_bwd(r3(lin_a), r2(dEsde_dm), r3(dEsde_ds), r2(dEobs_dm), r3(dEobs_ds))
+            return lam.reshape(n), psi.reshape(n)
+        n, d = dEsde_dm.shape
+        ctx = self._context(d, n)
+        return ctx.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
+
+
+class Euler(OdeSolver):
+    method = "euler"
+
+
+class Heun(OdeSolver):
+    method = "heun"
+
+
+class RungeKutta2(OdeSolver):
+    method = "rk2"
+
+
+class RungeKutta4(OdeSolver):
+    method = "rk4"
+
+
+# Registry with the reference's keys (src/numerics/utilities.py:12-13).
+num_integration = {"euler": Euler, "heun": Heun, "rk2": RungeKutta2, "rk4": RungeKutta4}
+
+
+class _OdeFunctor(object):
+    def __init__(self, dt: float, method: str, single_dim: bool = True) -> None:
+        if dt <= 0.0:
+            raise ValueError(f" {self.__class__.__name__}:"
+                             f" Discrete time step should be strictly positive -> {dt}.")
+        self.dt = dt
+        method_str = str(method).lower()
+        try:
+            self.solver = num_integration[method_str](dt, single_dim)
+        except KeyError:
+            raise ValueError(f" {self.__class__.__name__}:"
+                             f" Integration method is unknown -> {method}.")
+        self.method = method
+
+    def __str__(self) -> str:
+        return f" {self.__class__.__name__} Id({id(self)}): dt={self.dt}, method={self.method}"
+
+
+class FwdOde(_OdeFunctor):
+    """Forward ODE functor (src/var_bayes/fwd_ode.py)."""
+
+    def __call__(self, at, bt, m0, s0, sigma):
+        return self.solver.solve_fwd(at, bt, m0, s0, sigma)
+
+
+class BwdOde(_OdeFunctor):
+    """Backward ODE functor (src/var_bayes/bwd_ode.py)."""
+
+    def __call__(self, at, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds):
+        return self.solver.solve_bwd(at, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
