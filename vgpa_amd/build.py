@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvgpa_hip.so")
-SOURCES = ["vgpa_api.hip", "ode_generic.hip", "ode_mfma.hip", "energy.hip", "assemble.hip", "host_linalg.cpp"]
+SOURCES = ["vgpa_api.hip", "ode_generic.hip", "ode_mfma.hip", "ode_mfma_m0.hip", "ode_mfma_m1.hip", "ode_mfma_m2.hip",
+           "ode_mfma_m3.hip", "energy.hip", "assemble.hip", "host_linalg.cpp"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -32,7 +33,8 @@ def _newer(src, dst, extra=()):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(HERE, "..", "include", "vgpa_hip.h")]
+    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(CSRC, "ode_mfma_impl.h"),
+               os.path.join(HERE, "..", "include", "vgpa_hip.h")]
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
