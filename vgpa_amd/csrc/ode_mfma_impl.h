@@ -30,7 +30,91 @@ namespace mfma {
 
 constexpr int NT = 256;
 constexpr int NW = 4;
+
+// Diagnostic build only (tools/ubench/ode_stamp.hip): per-segment cycle sums of one wave.  Never defined in the
+// product build, so no stamp executes there.
+#ifdef VGPA_STAMPS
+__device__ long long g_stamp[4][16];
+#define VGPA_STAMP(i)                                                                         \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    const long long t_ = clock64();                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamp[threadIdx.x >> 6][i] += t_ - stamp_prev_; \
+    stamp_prev_ = clock64();                                                                  \
+  } while (0)
+#define VGPA_STAMP_DECL long long stamp_prev_ = clock64()
+#define VGPA_STAMP_ARG , long long& stamp_prev_
+#define VGPA_STAMP_PASS , stamp_prev_
+#else
+#define VGPA_STAMP(i) do {} while (0)
+#define VGPA_STAMP_DECL do {} while (0)
+#define VGPA_STAMP_ARG
+#define VGPA_STAMP_PASS
+#endif
 constexpr int kMaxNB = 11;   // D <= 44: beyond that the backward kernel spills registers (generic path instead)
+
+// ---- dealing units to (wave, slot) -------------------------------------------------------------------------
+// Units are numbered group-major: NQ full column groups of NB units each, then NLEFT left-over units.  All units of
+// a group share one B fragment.  Every wave loads TWO B fragments per k-step and slot s uses the first one when
+// s < S1 and the second one otherwise -- a compile-time choice (a per-slot run-time select between MFMAs costs
+// ~20 cycles per MFMA, measured).  The greedy below gives each wave units of at most two groups such that each
+// group fits one of the two slot ranges; a wave fed by one group uses both ranges for it.
+struct WaveDeal { int uA, nA, gA, uB, nB, gB; };   // first unit / count / group of the A-range and of the B-range
+
+__host__ __device__ constexpr int deal_group_size(int nb, int nq, int nleft, int g) { return g < nq ? nb : (g == nq ? nleft : 0); }
+
+// Returns the deal of wave `want` (0..3); *done = all units dealt after four waves.
+__host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int maxu, int want, bool* done) {
+  const int ngroups = nq + (nleft ? 1 : 0);
+  const int s1 = maxu / 2, s2 = maxu - s1;
+  int g = 0, off = 0;
+  WaveDeal res{0, 0, 0, 0, 0, 0};
+  for (int w = 0; w < 4; w++) {
+    WaveDeal d{0, 0, 0, 0, 0, 0};
+    while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
+    if (g < ngroups) {
+      const int rem = deal_group_size(nb, nq, nleft, g) - off;
+      const int a = rem < maxu ? rem : maxu;
+      if (a <= s1 || a <= s2) {
+        const bool first_in_a = a <= s1;
+        const int u_first = g * nb + off, g_first = g;
+        off += a;
+        while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
+        int b = 0, u_second = 0, g_second = g_first;
+        if (g < ngroups) {
+          const int cap = first_in_a ? s2 : s1;
+          const int rem2 = deal_group_size(nb, nq, nleft, g) - off;
+          b = rem2 < cap ? rem2 : cap;
+          u_second = g * nb + off; g_second = g;
+          off += b;
+        }
+        if (first_in_a) d = WaveDeal{u_first, a, g_first, u_second, b, g_second};
+        else d = WaveDeal{u_second, b, g_second, u_first, a, g_first};
+      } else {
+        const int na = a < s1 ? a : s1;
+        d = WaveDeal{g * nb + off, na, g, g * nb + off + na, a - na, g};
+        off += a;
+      }
+    }
+    if (w == want) res = d;
+  }
+  while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
+  if (done) *done = (g >= ngroups);
+  return res;
+}
+
+__host__ __device__ constexpr bool deal_fits(int nb, int nq, int nleft, int maxu) {
+  bool ok = false;
+  (void)deal_units(nb, nq, nleft, maxu, 0, &ok);
+  return ok;
+}
+
+__host__ __device__ constexpr int deal_min_slots(int nb, int nq, int nleft, int nu) {
+  int m = (nu + 3) / 4;
+  while (!deal_fits(nb, nq, nleft, m)) m++;
+  return m;
+}
 
 // Compile-time geometry of the padded problem: NB = ceil(D/4) 4x4 blocks per dimension.
 template <int NB_>
@@ -41,7 +125,8 @@ struct Geo {
   static constexpr int G = REM ? 4 / REM : 0;             // block-rows packed into one left-over unit
   static constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
   static constexpr int NU = NB * NQ + NLEFT;              // units (MFMA accumulators) per product
-  static constexpr int MAXU = (NU + NW - 1) / NW;         // unit slots per wave
+  static constexpr int MAXU = deal_min_slots(NB, NQ, NLEFT, NU);   // unit slots per wave (>= ceil(NU/4))
+  static constexpr int S1 = MAXU / 2;                     // slots [0,S1) use B fragment 0, slots [S1,MAXU) fragment 1
   static constexpr int P = 4 * NB;                        // padded dimension
   static constexpr int PC = 16 * ((P + 15) / 16);
   static constexpr int LDX = (PC % 32 == 16) ? PC : PC + 16;   // = 16 (mod 32): conflict-free 16-wide rows
@@ -54,8 +139,9 @@ struct Geo {
   static constexpr int KKE = NB + (NB & 1);               // k-steps rounded up to even (extra rows are zero)
   static constexpr int ROWS = 4 * KKE;                    // rows allocated per LDS matrix (zero padded)
   static constexpr int EPT = (P * P + NT - 1) / NT;       // A entries per thread for the HBM -> LDS staging
+  static constexpr int TRASH = NT;                        // one scratch double per thread for lanes without an element
   static constexpr size_t LDS_DOUBLES = (size_t)ROWS * LDX + (size_t)P * LDW + 3 * (size_t)ROWS * LDA +
-                                        (size_t)(2 + NW) * P + 8;
+                                        (size_t)(2 + NW) * P + TRASH + 8;
 };
 
 template <int NB>
@@ -67,10 +153,11 @@ struct Lds {
   double* A1;    // [ROWS][LDA]  operand of A at the step's end point
   double* xv;    // [P]          stage vector (m or lam)
   double* pv;    // [NW][P]      partial mat-vec sums
+  double* trash; // [NT]         write/read target of lanes that own no matrix element in a slot
   __device__ __forceinline__ void carve(double* smem) {
     using g = Geo<NB>;
     X = smem; W = X + g::ROWS * g::LDX; A0 = W + g::P * g::LDW; AM = A0 + g::ROWS * g::LDA;
-    A1 = AM + g::ROWS * g::LDA; xv = A1 + g::ROWS * g::LDA; pv = xv + 2 * g::P;
+    A1 = AM + g::ROWS * g::LDA; xv = A1 + g::ROWS * g::LDA; pv = xv + 2 * g::P; trash = pv + NW * g::P;
   }
 };
 
@@ -78,13 +165,12 @@ template <int NB>
 struct Tab {
   static constexpr int MAXU = Geo<NB>::MAXU;
   int colA[MAXU];   // 4*I_b + (l&3)
-  int colB0, colB1; // B-fragment columns of the wave's first / second column group
+  int colB0, colB1; // B-fragment columns of the group feeding slots [0,S1) / slots [S1,MAXU)
   int offWw[MAXU];  // row*LDW + col
   int offWr[MAXU];  // col*LDW + row
   int offX[MAXU];   // row*LDX + col
   int gofs[MAXU];   // row*D + col   (global element offset inside a D x D matrix)
   unsigned valid;   // per-lane bit s: this lane owns a real matrix element in slot s
-  int nfirst;       // wave-uniform: slots [0, nfirst) use the first B fragment, the others the second
 };
 
 template <int NB>
@@ -92,40 +178,44 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
   using g = Geo<NB>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = (lane >> 2) & 3, r4 = lane >> 4, c4 = lane & 3;
-  const int u0 = (wave * g::NU) / NW, u1 = ((wave + 1) * g::NU) / NW;
+  const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, wave, nullptr);
+  constexpr int rem = g::REM ? g::REM : 1;
+  auto group_col = [&](int grp) { return (grp < g::NQ) ? (16 * grp + (lane & 15)) : (4 * (4 * g::NQ + b % rem) + c4); };
+  T.colB0 = group_col(deal.gA);
+  T.colB1 = group_col(deal.gB);
   T.valid = 0u;
-  T.colB0 = T.colB1 = c4;
-  int first_group = -1, nfirst = 0;
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) {
-    const int u = u0 + s;
-    int Ib = 0, Jb = 0, group = first_group;
+    const bool in_a = s < g::S1;
+    const int t = in_a ? s : s - g::S1;
+    const bool have = in_a ? (t < deal.nA) : (t < deal.nB);
+    const int u = (in_a ? deal.uA : deal.uB) + t;
+    int Ib = 0, Jb = 0;
     bool ok = false;
-    if (u < u1) {
+    if (have) {
       if (u < g::NB * g::NQ) {
         const int q = u / g::NB;
-        Ib = u - q * g::NB; Jb = 4 * q + b; group = q; ok = true;
+        Ib = u - q * g::NB; Jb = 4 * q + b; ok = true;
       } else {
-        constexpr int rem = g::REM ? g::REM : 1;
         const int v = u - g::NB * g::NQ;
         const int i0 = v * g::G;
-        Ib = i0 + b / rem; Jb = 4 * g::NQ + b % rem; group = g::NQ;
+        Ib = i0 + b / rem; Jb = 4 * g::NQ + b % rem;
         ok = (b < g::G * g::REM) && (Ib < g::NB);
         if (!ok) { Ib = i0; Jb = 4 * g::NQ; }
       }
-      if (s == 0) { first_group = group; T.colB0 = T.colB1 = 4 * Jb + c4; }
-      if (group == first_group) nfirst = s + 1;
-      else T.colB1 = 4 * Jb + c4;
     }
     const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+    const bool own = ok && row < D && col < D;
+    // offsets are relative to the LDS base; lanes without an element are pointed at their private trash word
+    constexpr int W_BASE = g::ROWS * g::LDX;
+    constexpr int TRASH_BASE = g::ROWS * g::LDX + g::P * g::LDW + 3 * g::ROWS * g::LDA + (2 + NW) * g::P;
     T.colA[s] = 4 * Ib + c4;
-    T.offWw[s] = row * g::LDW + col;
-    T.offWr[s] = col * g::LDW + row;
-    T.offX[s] = row * g::LDX + col;
+    T.offWw[s] = own ? (W_BASE + row * g::LDW + col) : (TRASH_BASE + (int)threadIdx.x);
+    T.offWr[s] = own ? (W_BASE + col * g::LDW + row) : (TRASH_BASE + (int)threadIdx.x);
+    T.offX[s] = own ? (row * g::LDX + col) : (TRASH_BASE + (int)threadIdx.x);
     T.gofs[s] = row * D + col;
-    if (ok && row < D && col < D) T.valid |= (1u << s);
+    if (own) T.valid |= (1u << s);
   }
-  T.nfirst = __builtin_amdgcn_readfirstlane(nfirst);
 }
 
 // ---- one D^3 product on the matrix cores: w[s] = sum_kk Aop-block x X-block ---------------------------------
@@ -155,29 +245,33 @@ __device__ __forceinline__ void mfma_product(const double* __restrict__ Aop, con
     }
 #pragma unroll
     for (int s = 0; s < MAXU; s++) {
-      const double b = (s < T.nfirst) ? bf[cur][0] : bf[cur][1];
+      const double b = (s < g::S1) ? bf[cur][0] : bf[cur][1];      // compile-time choice
+#if defined(VGPA_STAMPS) && defined(VGPA_ABL_NOMFMA)
+      w[s] += af[cur][s] * 1e-300 + b * 1e-300;                     // timing-only ablation (wrong results)
+#else
       w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[cur][s], b, w[s], 0, 0, 0);
+#endif
     }
   }
 }
 
-// partial mat-vec of this wave (k-range = its quarter): forward sum_k Aop[k][i] v[k], backward sum_k Aop[i][k] v[k]
+// partial mat-vec of this wave (k-range = its quarter of the padded dimension, P = 4*NB = NW*NB; padding rows and
+// padding entries of xv are zero): forward sum_k Aop[k][i] v[k], backward sum_k Aop[i][k] v[k].  Branch-free.
 template <int NB, bool FWD>
-__device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop, const double* __restrict__ xv, int D) {
+__device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop, const double* __restrict__ xv) {
   using g = Geo<NB>;
+  static_assert(NW * NB == g::P, "the four waves split the padded k range evenly");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int KQ = (g::P + NW - 1) / NW;     // rows of padding are zero, so the padded range is harmless
-  const int k0 = wave * KQ;
+  const int k0 = wave * NB;
   const int li = (lane < g::P) ? lane : 0;
+  const double* pa = FWD ? (Aop + k0 * g::LDA + li) : (Aop + li * g::LDA + k0);
+  const double* pv = xv + k0;
+  double av[NB], xk[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) { av[k] = FWD ? pa[k * g::LDA] : pa[k]; xk[k] = pv[k]; }
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < KQ; k++) {
-    if (k0 + k < g::P) {
-      const double av = FWD ? Aop[(k0 + k) * g::LDA + li] : Aop[li * g::LDA + (k0 + k)];
-      s = __builtin_fma(av, xv[k0 + k], s);
-    }
-  }
-  (void)D;
+  for (int k = 0; k < NB; k++) s = __builtin_fma(av[k], xk[k], s);
   return s;
 }
 
@@ -186,32 +280,39 @@ __device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop,
 template <int NB, bool FWD, int LDAOP>
 __device__ __forceinline__ void stage_products(const Lds<NB>& L, int D, const double* Aop, const Tab<NB>& T,
                                                const double* Avec, double (&w)[Geo<NB>::MAXU],
-                                               double (&wt)[Geo<NB>::MAXU], double& vsum) {
+                                               double (&wt)[Geo<NB>::MAXU], double& vsum VGPA_STAMP_ARG) {
   using g = Geo<NB>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  VGPA_STAMP(0);                       // elementwise work since the last publish
   mfma_product<NB, LDAOP>(Aop, L.X, T, w);
-  const double part = matvec_partial<NB, FWD>(Avec, L.xv, D);
+  VGPA_STAMP(1);                       // MFMA product
+  const double part = matvec_partial<NB, FWD>(Avec, L.xv);
+  VGPA_STAMP(2);                       // mat-vec
 #pragma unroll
-  for (int s = 0; s < g::MAXU; s++)
-    if ((T.valid >> s) & 1u) L.W[T.offWw[s]] = w[s];
-  if (lane < g::P) L.pv[wave * g::P + lane] = part;
+  for (int s = 0; s < g::MAXU; s++) L.X[T.offWw[s]] = w[s];          // (offsets are LDS-base relative; X is the base)
+  L.pv[wave * g::P + ((lane < g::P) ? lane : 0)] = part;            // lanes >= P hold the same value as lane 0
+  VGPA_STAMP(3);                       // W / pv stores
   __syncthreads();
+  VGPA_STAMP(4);                       // barrier A
 #pragma unroll
-  for (int s = 0; s < g::MAXU; s++) wt[s] = ((T.valid >> s) & 1u) ? L.W[T.offWr[s]] : 0.0;
+  for (int s = 0; s < g::MAXU; s++) wt[s] = L.X[T.offWr[s]];
   vsum = 0.0;
   if (wave == 0 && lane < D)
     vsum = ((L.pv[lane] + L.pv[g::P + lane]) + L.pv[2 * g::P + lane]) + L.pv[3 * g::P + lane];
+  VGPA_STAMP(5);                       // W^T / pv loads
 }
 
 // publish the next stage state (matrix elements owned by this lane + vector entries of wave 0).  ONE barrier.
 template <int NB>
 __device__ __forceinline__ void publish(const Lds<NB>& L, int D, const Tab<NB>& T,
-                                        const double (&xn)[Geo<NB>::MAXU], double vn) {
+                                        const double (&xn)[Geo<NB>::MAXU], double vn VGPA_STAMP_ARG) {
+  VGPA_STAMP(6);                       // elementwise work of the stage
 #pragma unroll
-  for (int s = 0; s < Geo<NB>::MAXU; s++)
-    if ((T.valid >> s) & 1u) L.X[T.offX[s]] = xn[s];
+  for (int s = 0; s < Geo<NB>::MAXU; s++) L.X[T.offX[s]] = xn[s];
   if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < D) L.xv[threadIdx.x & 63] = vn;
+  VGPA_STAMP(7);                       // X stores
   __syncthreads();
+  VGPA_STAMP(8);                       // barrier B
 }
 
 // A(t) from HBM into registers, coalesced (thread e <-> A[e / D][e % D])
@@ -263,6 +364,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   const double dt = a.dt, h = 0.5 * a.dt;
   const bool vlane = (wave == 0) && (lane < D);
 
+  VGPA_STAMP_DECL;
   Tab<NB> T;
   build_tab<NB>(D, T);
   int aofs[EPT];
@@ -279,7 +381,8 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
     sk[s] = ok ? a.S0[T.gofs[s]] : 0.0;
     sig[s] = ok ? a.Sigma[T.gofs[s]] : 0.0;
     acc1[s] = acc2[s] = 0.0;
-    if (ok) { st[T.gofs[s]] = sk[s]; L.X[T.offX[s]] = sk[s]; }
+    if (ok) st[T.gofs[s]] = sk[s];
+    L.X[T.offX[s]] = sk[s];
   }
   if (vlane) { mk = a.m0[lane]; mt[lane] = mk; L.xv[lane] = mk; }
   load_a<NB>(A, DD, aC);
@@ -299,51 +402,51 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
     double mnew = 0.0;
 
     if (METHOD == VGPA_ODE_EULER) {
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + ((-w[s] - wt[s]) + sig[s]) * dt;
       mnew = mk + (-vs + b0) * dt;
     } else if (METHOD == VGPA_ODE_HEUN) {
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pm = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + acc1[s] * dt; }
-      publish<NB>(L, D, T, xn, mk + pm * dt);
-      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs);
+      publish<NB>(L, D, T, xn, mk + pm * dt VGPA_STAMP_PASS);
+      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double cm = -vs + b1;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + h * (acc1[s] + ((-w[s] - wt[s]) + sig[s]));
       mnew = mk + h * (pm + cm);
     } else if (METHOD == VGPA_ODE_RK2) {
       // covariance predictor: S_k stands in for A_k (Q2): operand = X itself (S symmetric); mean predictor: A_k
-      stage_products<NB, true, g::LDX>(L, D, L.X, T, L.A0, w, wt, vs);
+      stage_products<NB, true, g::LDX>(L, D, L.X, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pm = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) xn[s] = sk[s] + h * ((-w[s] - wt[s]) + sig[s]);
-      publish<NB>(L, D, T, xn, mk + h * pm);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, mk + h * pm VGPA_STAMP_PASS);
+      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double cm = -vs + 0.5 * (b0 + b1);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + dt * ((-w[s] - wt[s]) + sig[s]);
       mnew = mk + dt * cm;
     } else {  // RK4
       const double bmid = 0.5 * (b0 + b1);
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double k1 = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + h * acc1[s]; }
-      publish<NB>(L, D, T, xn, mk + h * k1);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, mk + h * k1 VGPA_STAMP_PASS);
+      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k2 = -vs + bmid;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc2[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + h * acc2[s]; }
-      publish<NB>(L, D, T, xn, mk + h * k2);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, mk + h * k2 VGPA_STAMP_PASS);
+      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k3 = -vs + bmid;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { r[s] = (-w[s] - wt[s]) + sig[s]; acc2[s] = acc2[s] + r[s]; xn[s] = sk[s] + dt * r[s]; }
-      publish<NB>(L, D, T, xn, mk + dt * k3);
-      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs);
+      publish<NB>(L, D, T, xn, mk + dt * k3 VGPA_STAMP_PASS);
+      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double k4 = -vs + b1;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -358,7 +461,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
     for (int s = 0; s < MAXU; s++)
       if ((T.valid >> s) & 1u) so[T.gofs[s]] = sk[s];
     if (vlane) mt[(size_t)(k + 1) * D + lane] = mk;
-    publish<NB>(L, D, T, sk, mk);
+    publish<NB>(L, D, T, sk, mk VGPA_STAMP_PASS);
     // rotate operand buffers: A_{k+1} becomes the start-point operand of the next step
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
   }
@@ -382,6 +485,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
   const double dt = a.dt, h = 0.5 * a.dt;
   const bool vlane = (wave == 0) && (lane < D);
 
+  VGPA_STAMP_DECL;
   Tab<NB> T;
   build_tab<NB>(D, T);
   int aofs[EPT];
@@ -432,48 +536,48 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
     double lnew = 0.0;
 
     if (METHOD == VGPA_ODE_EULER) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - ((-gC[s] + wt[s]) + w[s]) * dt + js[s];
       lnew = lk - (-g0 + vs) * dt + jm;
     } else if (METHOD == VGPA_ODE_HEUN) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pl = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-gC[s] + wt[s]) + w[s]; xn[s] = pk[s] - acc1[s] * dt; }
-      publish<NB>(L, D, T, xn, lk - pl * dt);
-      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs);
+      publish<NB>(L, D, T, xn, lk - pl * dt VGPA_STAMP_PASS);
+      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double cl = -g1 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - h * (acc1[s] + ((-gN[s] + wt[s]) + w[s])) + js[s];
       lnew = lk - h * (pl + cl) + jm;
     } else if (METHOD == VGPA_ODE_RK2) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pl = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) xn[s] = pk[s] - h * ((-gC[s] + wt[s]) + w[s]);
-      publish<NB>(L, D, T, xn, lk - h * pl);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, lk - h * pl VGPA_STAMP_PASS);
+      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double cl = -(0.5 * (g1 + g0)) + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - dt * ((-(0.5 * (gN[s] + gC[s])) + wt[s]) + w[s]) + js[s];
       lnew = lk - dt * cl + jm;
     } else {  // RK4
       const double gmid = 0.5 * (g1 + g0);
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs);
+      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double k1 = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-gC[s] + wt[s]) + w[s]; xn[s] = pk[s] - h * acc1[s]; }
-      publish<NB>(L, D, T, xn, lk - h * k1);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, lk - h * k1 VGPA_STAMP_PASS);
+      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k2 = -gmid + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
         acc2[s] = (-(0.5 * (gN[s] + gC[s])) + wt[s]) + w[s];
         xn[s] = pk[s] - h * acc2[s];
       }
-      publish<NB>(L, D, T, xn, lk - h * k2);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs);
+      publish<NB>(L, D, T, xn, lk - h * k2 VGPA_STAMP_PASS);
+      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k3 = -gmid + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -481,8 +585,8 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
         acc2[s] = acc2[s] + r[s];
         xn[s] = pk[s] - dt * r[s];
       }
-      publish<NB>(L, D, T, xn, lk - dt * k3);
-      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs);
+      publish<NB>(L, D, T, xn, lk - dt * k3 VGPA_STAMP_PASS);
+      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double k4 = -g1 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -500,7 +604,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
       gN[s] = (((T.valid >> s) & 1u) && t >= 2) ? gs[(size_t)(t - 2) * DD + T.gofs[s]] : 0.0;
     }
     if (vlane) lam[(size_t)(t - 1) * D + lane] = lk;
-    publish<NB>(L, D, T, pk, lk);
+    publish<NB>(L, D, T, pk, lk VGPA_STAMP_PASS);
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
   }
 }
