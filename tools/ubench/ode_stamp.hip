@@ -28,6 +28,9 @@ int main(int argc, char** argv) {
   hipEventRecord(e0); mfma::launch_nb<3, true, 10>(a, 0); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   long long st[4][16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(mfma::g_stamp), sizeof(st));
+  long long ck[4]; (void)hipMemcpyFromSymbol(ck, HIP_SYMBOL(mfma::g_clk), sizeof(ck));
+  printf("in-kernel clock: %.3f GHz (s_memtime %lld ticks over %lld x 10 ns)\n", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1,
+         ck[2] - ck[0], ck[3] - ck[1]);
   const char* names[9] = {"elementwise(final)", "mfma product", "mat-vec", "W/pv stores", "barrier A", "W^T/pv loads", "elementwise(stage)", "X stores", "barrier B"};
   printf("fwd RK4 D=40 Np=%d B=%d: %.3f ms  (%.0f cycles/step at 2.4 GHz)\n", Np, B, ms, ms * 1e-3 * 2.4e9 / (Np - 1));
   for (int w = 0; w < 4; w++) {

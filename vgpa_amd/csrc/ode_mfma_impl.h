@@ -35,6 +35,7 @@ constexpr int NW = 4;
 // product build, so no stamp executes there.
 #ifdef VGPA_STAMPS
 __device__ long long g_stamp[4][16];
+__device__ long long g_clk[4];   // s_memtime / s_memrealtime at kernel start and end (block 0, thread 0)
 #define VGPA_STAMP(i)                                                                         \
   do {                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -365,6 +366,9 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   const bool vlane = (wave == 0) && (lane < D);
 
   VGPA_STAMP_DECL;
+#ifdef VGPA_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) { g_clk[0] = __builtin_amdgcn_s_memtime(); g_clk[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   Tab<NB> T;
   build_tab<NB>(D, T);
   int aofs[EPT];
@@ -388,6 +392,9 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   load_a<NB>(A, DD, aC);
   store_a<NB, true, false>(L.A0, D, aofs, aC, aC);
   if (Np > 1) load_a<NB>(A + DD, DD, aN);
+  // offset vectors: b0 = b_k, b1 = b_{k+1}; b_{k+2} is fetched one step ahead (HBM latency off the critical path)
+  double b0 = vlane ? bb[lane] : 0.0;
+  double b1 = (vlane && Np > 1) ? bb[D + lane] : 0.0;
   __syncthreads();
 
   for (int k = 0; k < Np - 1; k++) {
@@ -397,8 +404,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (k + 2 < Np) load_a<NB>(A + (size_t)(k + 2) * DD, DD, aN);
-    const double b0 = vlane ? bb[(size_t)k * D + lane] : 0.0;
-    const double b1 = vlane ? bb[(size_t)(k + 1) * D + lane] : 0.0;
+    const double b2 = (vlane && k + 2 < Np) ? bb[(size_t)(k + 2) * D + lane] : 0.0;
     double mnew = 0.0;
 
     if (METHOD == VGPA_ODE_EULER) {
@@ -464,7 +470,11 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
     publish<NB>(L, D, T, sk, mk VGPA_STAMP_PASS);
     // rotate operand buffers: A_{k+1} becomes the start-point operand of the next step
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
+    b0 = b1; b1 = b2;
   }
+#ifdef VGPA_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) { g_clk[2] = __builtin_amdgcn_s_memtime(); g_clk[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // =================================================================================================================
@@ -510,6 +520,15 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
   load_a<NB>(A + (size_t)(Np - 1) * DD, DD, aC);
   store_a<NB, false, false>(L.A0, D, aofs, aC, aC);
   if (Np > 1) load_a<NB>(A + (size_t)(Np - 2) * DD, DD, aN);
+  // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
+  double g0 = vlane ? gm[(size_t)(Np - 1) * D + lane] : 0.0;
+  double g1 = (vlane && Np > 1) ? gm[(size_t)(Np - 2) * D + lane] : 0.0;
+  int n_obs_cur = (!a.js_dense && a.obs_idx && Np > 1) ? a.obs_idx[Np - 2] : -1;
+  double jm = 0.0;
+  if (Np > 1) {
+    if (a.js_dense) { if (vlane) jm = a.jm_dense[((size_t)prob * Np + (Np - 2)) * D + lane]; }
+    else if (vlane && n_obs_cur >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_cur) * D + lane];
+  }
   __syncthreads();
 
   for (int t = Np - 1; t > 0; t--) {
@@ -518,20 +537,22 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (t >= 2) load_a<NB>(A + (size_t)(t - 2) * DD, DD, aN);
-    const double g0 = vlane ? gm[(size_t)t * D + lane] : 0.0;          // dEsde_dm[t]
-    const double g1 = vlane ? gm[(size_t)(t - 1) * D + lane] : 0.0;    // dEsde_dm[t-1]
-    // jumps of index t-1
-    double js[MAXU], jm = 0.0;
+    const double g2 = (vlane && t >= 2) ? gm[(size_t)(t - 2) * D + lane] : 0.0;   // for the next step
+    const int n_obs_next = (!a.js_dense && a.obs_idx && t >= 2) ? a.obs_idx[t - 2] : -1;
+    double jm_next = 0.0;
+    if (t >= 2) {
+      if (a.js_dense) { if (vlane) jm_next = a.jm_dense[((size_t)prob * Np + (t - 2)) * D + lane]; }
+      else if (vlane && n_obs_next >= 0) jm_next = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_next) * D + lane];
+    }
+    // matrix jump of index t-1
+    double js[MAXU];
     if (a.js_dense) {
       const double* jp = a.js_dense + ((size_t)prob * Np + (t - 1)) * DD;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) js[s] = ((T.valid >> s) & 1u) ? jp[T.gofs[s]] : 0.0;
-      if (vlane) jm = a.jm_dense[((size_t)prob * Np + (t - 1)) * D + lane];
     } else {
-      const int n = a.obs_idx ? a.obs_idx[t - 1] : -1;
 #pragma unroll
-      for (int s = 0; s < MAXU; s++) js[s] = (n >= 0) ? jsc[s] : 0.0;
-      if (vlane && n >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n) * D + lane];
+      for (int s = 0; s < MAXU; s++) js[s] = (n_obs_cur >= 0) ? jsc[s] : 0.0;
     }
     double lnew = 0.0;
 
@@ -606,6 +627,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
     if (vlane) lam[(size_t)(t - 1) * D + lane] = lk;
     publish<NB>(L, D, T, pk, lk VGPA_STAMP_PASS);
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
+    g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
   }
 }
 
