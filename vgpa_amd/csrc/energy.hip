@@ -165,172 +165,250 @@ __global__ void __launch_bounds__(64) k_energy_l63(EnergyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-//  Lorenz-96: one workgroup per grid point
+//  Lorenz-96: ONE WAVE per grid point (64-thread workgroups, no workgroup barrier anywhere).
+//
+//  Per-wave LDS: Lm (c*S -> its lower Cholesky factor L, later q_k * L^-1[k][j]) and Gm (A, then A.L in place,
+//  later L^-1), both [D][LD] with LD odd, plus a few vectors.  Phases and the lane mapping of each:
+//    1. Cholesky, left-looking by columns            lane = row i        (cross-lane: pivot row reads, wave_sync)
+//    2. A.m and G = A.L in place on A (ascending r)  lane = row i        (lane-private rows)
+//    3. v_p = sum_i isg_i (l96_flat(chi)_pi + (A chi_p)_i - b_i)^2
+//                                                    lane = SIGMA POINT p (two passes: p < 64, p >= 64); the sum
+//       over i runs sequentially inside the lane with a sliding window over chi(p, i-2..i+1): no reduction.
+//       The flat np.roll of the reference (quirk Q1) makes row p's neighbours at the row ends come from rows p-1, p+1.
+//    4. L^-1 by forward substitution                 lane = column c     (lane-private columns)
+//    5. dE/dm = (c/2) L^-T delta, dE/dS = (c/2) L^-T diag(q) L^-1        lane = column j
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wrap(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
-__global__ void __launch_bounds__(NT) k_energy_l96(EnergyArgs a) {
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct L96Lds {
+  double *Lm, *Gm, *mv, *bv, *am, *sg, *vv, *dl, *qq, *rd;
+};
+
+__host__ __device__ inline int l96_dp(int D) { return 4 * ((D + 3) / 4); }          // padded to a multiple of 4
+__host__ __device__ inline int l96_ld(int D) { return l96_dp(D) + 1; }               // odd leading dimension
+__host__ __device__ inline size_t l96_lds_doubles(int D) {
+  return (size_t)2 * l96_dp(D) * l96_ld(D) + 7 * (size_t)l96_dp(D) + (2 * D + 1) + 8;
+}
+
+// Register blocking: every inner k-iteration below feeds FOUR independent fma chains from FIVE LDS reads (one
+// lane-private operand + four wave-uniform ones), which both cuts LDS traffic (the binding resource of this
+// kernel) and gives the scheduler independent work to hide the LDS latency behind.
+__global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int D = a.D, LD = D + 1, M = 2 * D + 1, MD = M * D;
-  const int t = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
+  const int D = a.D, Dp = l96_dp(D), LD = l96_ld(D), M = 2 * D + 1;
+  const int l = threadIdx.x;
+  const long long wid = blockIdx.x;
+  const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
   const size_t o = (size_t)prob * a.Np + t;
-  double* L = smem;                 // [D][LD]  c*S -> lower Cholesky factor
-  double* G = L + D * LD;           // [D][LD]  A.L, later L^-1
-  double* chi = G + D * LD;         // [M*D]    sigma points, row-major, CONTIGUOUS (flat roll, Q1)
-  double* am = chi + MD;            // [D]  A.m
-  double* mv = am + D;              // [D]  m
-  double* vv = mv + D;              // [M]  v_p
-  double* dl = vv + M;              // [D]  delta
-  double* qq = dl + D;              // [D]  q
-  double* sc = qq + D;              // [4]  scalars: e_t, flag
-  double* pv = sc + 4;              // [M*parts] partial sums of v_p
+  L96Lds S;
+  S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
+  S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
   const double* At = a.A + o * D * D;
-  const double* bt = a.b + o * D;
-  const double* mt = a.m + o * D;
   const double* St = a.S + o * D * D;
   const double theta = a.theta[0];
   const double kappa = 1.05 * D, c = D + kappa;
+  const bool act = l < D;                  // lane owns a real row / column
+  const bool pad = l < Dp;                 // lane owns a row / column of the padded problem
+  const int li = pad ? l : Dp - 1;         // clamped index so that idle lanes read valid memory
 
-  for (int e = tid; e < D * D; e += NT) { const int i = e / D, j = e - i * D; L[i * LD + j] = c * St[e]; }
-  if (tid < D) mv[tid] = mt[tid];
-  if (tid == 0) sc[1] = 0.0;
-  __syncthreads();
-
-  // --- right-looking Cholesky on the lower triangle (numpy.linalg.cholesky reads the lower triangle)
-  for (int j = 0; j < D; j++) {
-    const double piv = L[j * LD + j];
-    if (!(piv > 0.0)) { if (tid == 0) sc[1] = 1.0; }
-    const double d = sqrt(piv);
-    __syncthreads();
-    if (tid == 0) L[j * LD + j] = d;
-    for (int i = j + 1 + tid; i < D; i += NT) L[i * LD + j] = L[i * LD + j] / d;
-    __syncthreads();
-    const int n = D - 1 - j;   // trailing size
-    for (int e = tid; e < n * n; e += NT) {
-      const int r = e / n, cidx = e - r * n;
-      if (cidx <= r) {
-        const int i = j + 1 + r, k = j + 1 + cidx;
-        L[i * LD + k] = __builtin_fma(-L[i * LD + j], L[k * LD + j], L[i * LD + k]);
-      }
+  // ---- stage c*S and A into LDS (coalesced); padding: identity for c*S, zero for A and the vectors
+  for (int e = l; e < Dp * LD; e += 64) { S.Lm[e] = 0.0; S.Gm[e] = 0.0; }
+  if (pad) { S.mv[l] = 0.0; S.bv[l] = 0.0; S.sg[l] = 0.0; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
+  wave_sync();
+  {
+    int r = 0, cc = l;
+    while (cc >= D) { cc -= D; r++; }
+    for (int e = l; e < D * D; e += 64) {
+      S.Lm[r * LD + cc] = c * St[e];
+      S.Gm[r * LD + cc] = At[e];
+      cc += 64;
+      while (cc >= D) { cc -= D; r++; }
     }
-    __syncthreads();
   }
-  if (sc[1] != 0.0) {
-    // S_t is not positive definite: the reference raises LinAlgError from chol_inv(S_t)
-    // (variational.py:380) after its diagonal fallback (utilities.py:279); report and stop.
-    if (tid == 0) atomicOr(a.status + prob, 1);
+  if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
+  if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[o * D + l]; S.sg[l] = a.isg[l]; }
+  wave_sync();
+
+  // ---- 1. Cholesky, left-looking in panels of four columns (numpy.linalg.cholesky reads the lower triangle);
+  //         the strict upper triangle is zeroed on the way.
+  bool bad = false;
+  for (int j0 = 0; j0 < Dp && !bad; j0 += 4) {
+    const double* rowi = S.Lm + li * LD;
+    double s0 = rowi[j0], s1 = rowi[j0 + 1], s2 = rowi[j0 + 2], s3 = rowi[j0 + 3];
+    const double* p0 = S.Lm + j0 * LD;
+    const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
+#pragma unroll 2
+    for (int k = 0; k < j0; k++) {
+      const double av = rowi[k];
+      s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
+      s2 = __builtin_fma(-av, p2[k], s2); s3 = __builtin_fma(-av, p3[k], s3);
+    }
+    double lq[4], sq[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = j0 + q;
+      double s = sq[q];
+#pragma unroll
+      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], __shfl(lq[q2], j, 64), s);
+      const double piv = __shfl(s, j, 64);
+      if (!(piv > 0.0)) bad = true;
+      const double d = sqrt(piv), rdv = 1.0 / d;
+      lq[q] = (l > j) ? s * rdv : 0.0;
+      if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
+      if (l == j) S.rd[j] = rdv;
+    }
+    wave_sync();
+  }
+  if (bad) {
+    // S_t is not positive definite: the reference raises LinAlgError from chol_inv(S_t) (variational.py:380)
+    // after its diagonal fallback (utilities.py:279); report and stop.
+    if (l == 0) atomicOr(a.status + prob, 1);
     return;
   }
-  // zero the strict upper triangle so that L can be used as a dense operand
-  for (int e = tid; e < D * D; e += NT) { const int i = e / D, j = e - i * D; if (j > i) L[i * LD + j] = 0.0; }
-  __syncthreads();
 
-  // --- sigma points chi (rows: m, m + L[:,r], m - L[:,r]); A.m; A.L
-  for (int e = tid; e < D * D; e += NT) {
-    const int r = e / D, i = e - r * D;          // sigma point r, coordinate i  -> L[i][r]
-    const double lv = L[i * LD + r];
-    chi[(1 + r) * D + i] = mv[i] + lv;
-    chi[(1 + D + r) * D + i] = mv[i] - lv;
-  }
-  if (tid < D) {
-    chi[tid] = mv[tid];
-    double s = 0.0;
-    for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
-    am[tid] = s;
-  }
-  for (int e = tid; e < D * D; e += NT) {
-    const int i = e / D, r = e - i * D;
-    double s = 0.0;
-    for (int k = r; k < D; k++) s = __builtin_fma(At[i * D + k], L[k * LD + r], s);
-    G[i * LD + r] = s;
-  }
-  __syncthreads();
-
-  // --- v_p = sum_i isg_i (l96_flat(chi)[p,i] + (A chi_p)_i - b_i)^2   (deterministic two-level sum)
+  // ---- 2. A.m ; G = A.L in place (row i is private to lane i; ascending r never reads what it overwrote)
   {
-    const int parts = (NT / M) < 1 ? 1 : ((NT / M) > 4 ? 4 : (NT / M));
-    const int chunk = (D + parts - 1) / parts;
-    for (int u = tid; u < M * parts; u += NT) {
-      const int p = u / parts, part = u - p * parts;
-      const int i0 = part * chunk, i1 = (i0 + chunk < D) ? (i0 + chunk) : D;
-      double acc = 0.0;
-      for (int i = i0; i < i1; i++) {
-        const int w = p * D + i;
-        const double xf1 = chi[wrap(w + 1, MD)], xb1 = chi[wrap(w - 1, MD)], xb2 = chi[wrap(w - 2, MD)];
-        const double drift = (xf1 - xb2) * xb1 - chi[w] + theta;
-        double lin = am[i];
-        if (p >= 1) lin = (p <= D) ? (lin + G[i * LD + (p - 1)]) : (lin - G[i * LD + (p - 1 - D)]);
-        const double res = drift + lin - bt[i];
-        acc = __builtin_fma(a.isg[i], res * res, acc);
+    double* gi = S.Gm + li * LD;
+    double s = 0.0;
+    for (int k = 0; k < D; k++) s = __builtin_fma(gi[k], S.mv[k], s);
+    if (act) S.am[l] = s;
+    for (int r0 = 0; r0 < Dp; r0 += 4) {
+      double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+      const double* lr = S.Lm + r0;
+#pragma unroll 2
+      for (int k = r0; k < Dp; k++) {
+        const double av = gi[k];
+        const double* lk = lr + k * LD;
+        g0 = __builtin_fma(av, lk[0], g0); g1 = __builtin_fma(av, lk[1], g1);
+        g2 = __builtin_fma(av, lk[2], g2); g3 = __builtin_fma(av, lk[3], g3);
       }
-      pv[u] = acc;
+      if (pad) { gi[r0] = g0; gi[r0 + 1] = g1; gi[r0 + 2] = g2; gi[r0 + 3] = g3; }
     }
-    __syncthreads();
-    for (int p = tid; p < M; p += NT) {
-      double acc = 0.0;
-      for (int q = 0; q < parts; q++) acc += pv[p * parts + q];
-      vv[p] = acc;
-    }
-    __syncthreads();
   }
-  const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
-  if (tid == 0) {
+  wave_sync();
+
+  // ---- 3. v_p, lane = sigma point.  chi(p, i) = m_i + sgn_p L[i][r_p]  (p = 0: the mean)
+  for (int pass = 0; pass < 2; pass++) {
+    const int p = pass * 64 + l;
+    const bool pact = p < M;
+    const int pc = pact ? p : 0;
+    auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
+    auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
+    auto chi = [&](int q, int i) { return S.mv[i] + sgn_of(q) * S.Lm[i * LD + col_of(q)]; };
+    const int rp = col_of(pc);
+    const double sp = sgn_of(pc);
+    const int pm = wrap(pc - 1, M), pp = wrap(pc + 1, M);
+    // window: xm2 = X(w-2), xm1 = X(w-1), x0 = X(w), x1 = X(w+1) with w = p*D + i (flat, wrapping over M*D)
+    double xm2 = chi(pm, D - 2), xm1 = chi(pm, D - 1), x0 = chi(pc, 0), x1 = (D > 1) ? chi(pc, 1) : chi(pp, 0);
     double acc = 0.0;
-    for (int r = 0; r < D; r++) acc += (vv[1 + r] + vv[1 + D + r]);
-    sc[0] = 0.5 * (w0 * vv[0] + w1 * acc);
-  }
-  __syncthreads();
-  const double e_t = sc[0];
-  if (tid < D) {
-    dl[tid] = w1 * (vv[1 + tid] - vv[1 + D + tid]);
-    qq[tid] = 0.5 * c * (w1 * (vv[1 + tid] + vv[1 + D + tid])) - e_t;
-  }
-  if (tid == 0) a.e_t[o] = e_t;
+    for (int i = 0; i < D; i++) {
+      const double lin = S.am[i] + sp * S.Gm[i * LD + rp];
+      const double res = ((x1 - xm2) * xm1 - x0 + theta) + lin - S.bv[i];
+      acc = __builtin_fma(S.sg[i], res * res, acc);
+      xm2 = xm1; xm1 = x0; x0 = x1;
+      const int in = i + 2;
+      x1 = (in < D) ? chi(pc, in) : chi(pp, in - D);
+    }
+    if (pact) S.vv[p] = acc;
 
-  // --- L^-1 by forward substitution, one column per thread, into G (A.L is no longer needed)
-  __syncthreads();
-  if (tid < D) {
-    const int cc = tid;
-    for (int i = 0; i < cc; i++) G[i * LD + cc] = 0.0;
-    for (int i = cc; i < D; i++) {
-      double sacc = (i == cc) ? 1.0 : 0.0;
-      for (int k = cc; k < i; k++) sacc = __builtin_fma(-L[i * LD + k], G[k * LD + cc], sacc);
-      G[i * LD + cc] = sacc / L[i * LD + i];
+  }
+  wave_sync();
+  const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
+  double e_part = act ? (S.vv[1 + l] + S.vv[1 + D + l]) : 0.0;
+  const double e_t = 0.5 * (w0 * S.vv[0] + w1 * wave_sum(e_part));
+  if (act) {
+    S.dl[l] = w1 * (S.vv[1 + l] - S.vv[1 + D + l]);
+    S.qq[l] = 0.5 * c * (w1 * (S.vv[1 + l] + S.vv[1 + D + l])) - e_t;
+  }
+  if (l == 0) a.e_t[o] = e_t;
+  wave_sync();
+
+  // ---- 4. X = L^-1 into Gm, lane = column c (private), four rows at a time; entries above the diagonal come
+  //         out as exact zeros (every term of their sums is zero).
+  for (int i0 = 0; i0 < Dp; i0 += 4) {
+    const double* r0p = S.Lm + i0 * LD;
+    const double* r1p = r0p + LD; const double* r2p = r1p + LD; const double* r3p = r2p + LD;
+    double s0 = (i0 == l) ? 1.0 : 0.0, s1 = (i0 + 1 == l) ? 1.0 : 0.0, s2 = (i0 + 2 == l) ? 1.0 : 0.0,
+           s3 = (i0 + 3 == l) ? 1.0 : 0.0;
+    const double* xc = S.Gm + li;
+#pragma unroll 2
+    for (int k = 0; k < i0; k++) {
+      const double xv = xc[k * LD];
+      s0 = __builtin_fma(-r0p[k], xv, s0); s1 = __builtin_fma(-r1p[k], xv, s1);
+      s2 = __builtin_fma(-r2p[k], xv, s2); s3 = __builtin_fma(-r3p[k], xv, s3);
+    }
+    const double x0 = s0 * S.rd[i0];
+    s1 = __builtin_fma(-r1p[i0], x0, s1);
+    const double x1 = s1 * S.rd[i0 + 1];
+    s2 = __builtin_fma(-r2p[i0], x0, s2); s2 = __builtin_fma(-r2p[i0 + 1], x1, s2);
+    const double x2 = s2 * S.rd[i0 + 2];
+    s3 = __builtin_fma(-r3p[i0], x0, s3); s3 = __builtin_fma(-r3p[i0 + 1], x1, s3); s3 = __builtin_fma(-r3p[i0 + 2], x2, s3);
+    const double x3 = s3 * S.rd[i0 + 3];
+    if (pad) {
+      double* xw = S.Gm + i0 * LD + l;
+      xw[0] = x0; xw[LD] = x1; xw[2 * LD] = x2; xw[3 * LD] = x3;
     }
   }
-  __syncthreads();
+  wave_sync();
 
-  // --- dE/dm = (c/2) L^-T delta ;  dE/dS = (c/2) L^-T diag(q) L^-1
-  if (tid < D) {
-    double sacc = 0.0;
-    for (int k = tid; k < D; k++) sacc = __builtin_fma(G[k * LD + tid], dl[k], sacc);
-    a.dEm[o * D + tid] = 0.5 * c * sacc;
+  // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X.  Lm <- diag(q) X (L is no longer needed).
+  {
+    double s = 0.0;
+    for (int k = 0; k < Dp; k++) s = __builtin_fma(S.Gm[k * LD + li], S.dl[k], s);   // X[k][l] = 0 for k < l
+    if (act) a.dEm[o * D + l] = 0.5 * c * s;
   }
+  for (int k = 0; k < Dp; k++)
+    if (pad) S.Lm[k * LD + l] = S.qq[k] * S.Gm[k * LD + l];
+  wave_sync();
   double* ds = a.dEs + o * D * D;
-  for (int e = tid; e < D * D; e += NT) {
-    const int i = e / D, j = e - i * D;
-    double sacc = 0.0;
-    for (int k = (i > j ? i : j); k < D; k++) sacc = __builtin_fma(G[k * LD + i] * G[k * LD + j], qq[k], sacc);  // bitwise symmetric in (i,j)
-    ds[e] = 0.5 * c * sacc;
+  for (int i0 = 0; i0 < Dp; i0 += 4) {
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    const double* xr = S.Gm + i0;
+    const double* yc = S.Lm + li;
+#pragma unroll 2
+    for (int k = i0; k < Dp; k++) {
+      const double yv = yc[k * LD];
+      const double* xk = xr + k * LD;
+      g0 = __builtin_fma(xk[0], yv, g0); g1 = __builtin_fma(xk[1], yv, g1);
+      g2 = __builtin_fma(xk[2], yv, g2); g3 = __builtin_fma(xk[3], yv, g3);
+    }
+    if (act) {
+      if (i0 < D) ds[i0 * D + l] = 0.5 * c * g0;
+      if (i0 + 1 < D) ds[(i0 + 1) * D + l] = 0.5 * c * g1;
+      if (i0 + 2 < D) ds[(i0 + 2) * D + l] = 0.5 * c * g2;
+      if (i0 + 3 < D) ds[(i0 + 3) * D + l] = 0.5 * c * g3;
+    }
   }
 
-  // --- <f> (E96_drift, lorenz_96.py:440-462) and optionally dense <df/dx> (E96_drift_dx, :35-83)
-  if (tid < D) {
-    const int i = tid, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
+  // ---- <f> (E96_drift, lorenz_96.py:440-462) and optionally dense <df/dx> (E96_drift_dx, :35-83)
+  if (act) {
+    const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
     const double cxx = St[ip1 * D + im1] - St[im2 * D + im1];
-    a.Ef[o * D + i] = cxx + (mv[ip1] - mv[im2]) * mv[im1] - mv[i] + theta;
+    a.Ef[o * D + i] = cxx + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
   }
   if (a.Edf) {
     double* ed = a.Edf + o * D * D;
-    for (int e = tid; e < D * D; e += NT) {
+    for (int e = l; e < D * D; e += 64) {
       const int k = e / D, j = e - k * D;
       const int kp1 = wrap(k + 1, D), km1 = wrap(k - 1, D), km2 = wrap(k - 2, D);
       // same assignment order as the reference: later assignments win when indices coincide
       double v = 0.0;
       if (j == k) v = -1.0;
-      if (j == kp1) v = mv[km1];
-      if (j == km2) v = -mv[km1];
-      if (j == km1) v = mv[kp1] - mv[km2];
+      if (j == kp1) v = S.mv[km1];
+      if (j == km2) v = -S.mv[km1];
+      if (j == km1) v = S.mv[kp1] - S.mv[km2];
       ed[e] = v;
     }
   }
@@ -365,12 +443,6 @@ __global__ void __launch_bounds__(NT) k_edf_dense(EnergyArgs a) {
   }
 }
 
-size_t l96_lds_bytes(int D) {
-  const int LD = D + 1, M = 2 * D + 1;
-  int parts = NT / M; parts = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
-  return sizeof(double) * (size_t)(2 * D * LD + M * D + 2 * D + M + 2 * D + 4 + M * parts);
-}
-
 }  // namespace
 }  // namespace vgpa
 
@@ -385,11 +457,12 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_energy_l63, grid, dim3(64), 0, st, a);
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
-    const size_t lds = l96_lds_bytes(a.D);
+    const size_t lds = l96_lds_doubles(a.D) * sizeof(double);
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)k_energy_l96, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(a.Np, a.batch);
-    hipLaunchKernelGGL(k_energy_l96, grid, dim3(NT), lds, st, a);
+    const long long nwaves = (long long)a.Np * a.batch;
+    if (nwaves > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_energy_l96, dim3((unsigned)nwaves), dim3(64), lds, st, a);
   } else {
     return hipErrorInvalidValue;
   }
