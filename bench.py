@@ -60,9 +60,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (vgpa_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from vgpa_amd import parallel as par
+    par.init_from_env("nccl", local_rank)            # RCCL; no-op at WORLD_SIZE == 1
 
     import vgpa_amd as va
     from vgpa_amd._lib import FLAG_FORCE_GENERIC
@@ -86,10 +85,12 @@ def main():
     ctx = va.Context("L96", args.method, d, n_pts, dt, sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"],
                      obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=B,
                      device=local_rank, flags=flags)
-    rng = np.random.default_rng(1000 + rank)
+    lo, hi = par.shard_range(B * world, rank, world)        # this rank's slice of the global problem list
+    assert hi - lo == B
     xb = np.empty((B, len_x))
-    for i in range(B):                                       # problem 0 of rank 0 is exactly x0 + 0.05 N(0,1), rng(0)
-        r = np.random.default_rng(0) if (i == 0 and rank == 0) else rng
+    for i in range(B):                                       # global problem 0 is exactly x0 + 0.05 N(0,1), rng(0)
+        gi = lo + i
+        r = np.random.default_rng(0) if gi == 0 else np.random.default_rng(1000 + gi)
         xb[i] = x0 + 0.05 * r.standard_normal(len_x)
     x_dev, g_dev = ctx.alloc(B * len_x), ctx.alloc(B * len_x)
     x_dev.upload(xb)
@@ -108,10 +109,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = par.max_over_ranks(elapsed, device="cuda")
 
     # ---- correctness guard inside the bench: problem 0 of rank 0 must reproduce the reference's anchor
     check = None

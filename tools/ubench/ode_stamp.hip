@@ -22,22 +22,26 @@ int main(int argc, char** argv) {
   hipMemcpy(dS0, S0.data(), DD * 8, hipMemcpyHostToDevice); hipMemcpy(dSg, Sg.data(), DD * 8, hipMemcpyHostToDevice); hipMemcpy(dm0, m0.data(), D * 8, hipMemcpyHostToDevice);
   a.A = dA; a.b = db; a.m0 = dm0; a.S0 = dS0; a.Sigma = dSg; a.m = dm; a.S = dS;
   mfma::launch_nb<3, true, 10>(a, 0); hipDeviceSynchronize();
+#ifdef VGPA_STAMPS
   long long zero[4][16] = {};
   hipMemcpyToSymbol(HIP_SYMBOL(mfma::g_stamp), zero, sizeof(zero));
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); mfma::launch_nb<3, true, 10>(a, 0); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("fwd RK4 D=40 Np=%d B=%d: %.3f ms  (%.0f cycles/step at 2.4 GHz)\n", Np, B, ms, ms * 1e-3 * 2.4e9 / (Np - 1));
+#ifdef VGPA_STAMPS
   long long st[4][16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(mfma::g_stamp), sizeof(st));
   long long ck[4]; (void)hipMemcpyFromSymbol(ck, HIP_SYMBOL(mfma::g_clk), sizeof(ck));
   printf("in-kernel clock: %.3f GHz (s_memtime %lld ticks over %lld x 10 ns)\n", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1,
          ck[2] - ck[0], ck[3] - ck[1]);
   const char* names[9] = {"elementwise(final)", "mfma product", "mat-vec", "W/pv stores", "barrier A", "W^T/pv loads", "elementwise(stage)", "X stores", "barrier B"};
-  printf("fwd RK4 D=40 Np=%d B=%d: %.3f ms  (%.0f cycles/step at 2.4 GHz)\n", Np, B, ms, ms * 1e-3 * 2.4e9 / (Np - 1));
   for (int w = 0; w < 4; w++) {
     long long tot = 0; for (int i = 0; i < 9; i++) tot += st[w][i];
     printf("wave %d: total stamped %lld cycles/step:", w, tot / (Np - 1));
     for (int i = 0; i < 9; i++) printf(" [%s %lld]", names[i], st[w][i] / (Np - 1));
     printf("\n");
   }
+#endif
   return 0;
 }

@@ -129,25 +129,29 @@ struct Geo {
   static constexpr int MAXU = deal_min_slots(NB, NQ, NLEFT, NU);   // unit slots per wave (>= ceil(NU/4))
   static constexpr int S1 = MAXU / 2;                     // slots [0,S1) use B fragment 0, slots [S1,MAXU) fragment 1
   static constexpr int P = 4 * NB;                        // padded dimension
-  static constexpr int PC = 16 * ((P + 15) / 16);
-  static constexpr int LDX = (PC % 32 == 16) ? PC : PC + 16;   // = 16 (mod 32): conflict-free 16-wide rows
-  // Leading dimension of the A operand buffers.  Odd and = 5 (mod 32): conflict-free for the 4-wide fragment
-  // reads, the column reads of the mat-vec and the transposing stores; 4*LDA*8 B = 2208 B is > 2040 B and not a
-  // multiple of 512 B, which keeps hipcc from fusing the reads of two k-steps into ds_read2(st64)_b64 (half the
-  // LDS rate of ds_read_b64, MI355X_MICROARCH.md s.LDS).
-  static constexpr int LDA = 69;
-  static constexpr int LDW = P + 1;                       // exchange buffer for W^T (odd)
+  // LDS operand layouts ("k-pair interleaved"): element (k, c) of an operand matrix sits at
+  //     ((k >> 3) * 4 + (k & 3)) * LD + 2 * c + ((k >> 2) & 1)
+  // i.e. the fragments of two consecutive k-steps (kk = k >> 2 even / odd) are adjacent, so ONE ds_read_b128 per lane
+  // fetches both (a lone wave per SIMD reaches the LDS rate with b128 reads but only ~1/5 of it with b64 reads,
+  // MI355X_MICROARCH.md s.LDS).  LDX = 0 (mod 32) doubles makes the 16-wide B rows conflict-free for the b128 lane
+  // groups; LDA = 8 or 24 (mod 32) doubles spreads the four 4-wide A rows of a fragment over the 64 banks.
   static constexpr int KKE = NB + (NB & 1);               // k-steps rounded up to even (extra rows are zero)
-  static constexpr int ROWS = 4 * KKE;                    // rows allocated per LDS matrix (zero padded)
+  static constexpr int ROWS = 2 * KKE;                    // (KKE / 2) k-pairs x 4 rows
+  static constexpr int LDX = 32 * ((2 * P + 31) / 32);
+  static constexpr int LDA = 16 * ((2 * P - 8 + 15) / 16) + 8;   // = 8 or 24 (mod 32), >= 2P
+  static constexpr int LDW = P + 1;                       // exchange buffer for W^T (odd, plain row-major)
   static constexpr int EPT = (P * P + NT - 1) / NT;       // A entries per thread for the HBM -> LDS staging
   static constexpr int TRASH = NT;                        // one scratch double per thread for lanes without an element
   static constexpr size_t LDS_DOUBLES = (size_t)ROWS * LDX + (size_t)P * LDW + 3 * (size_t)ROWS * LDA +
                                         (size_t)(2 + NW) * P + TRASH + 8;
 };
 
+// offset of element (k, c) in a k-pair interleaved operand matrix with leading dimension LD
+__host__ __device__ constexpr int pair_off(int k, int c, int LD) { return ((k >> 3) * 4 + (k & 3)) * LD + 2 * c + ((k >> 2) & 1); }
+
 template <int NB>
 struct Lds {
-  double* X;     // [ROWS][LDX]  stage state
+  double* X;     // [ROWS][LDX]  stage state (k-pair interleaved)
   double* W;     // [P][LDW]     exchange buffer for W^T
   double* A0;    // [ROWS][LDA]  operand of A at the step's start point
   double* AM;    // [ROWS][LDA]  operand of the mid-point
@@ -165,11 +169,11 @@ struct Lds {
 template <int NB>
 struct Tab {
   static constexpr int MAXU = Geo<NB>::MAXU;
-  int colA[MAXU];   // 4*I_b + (l&3)
+  int colA[MAXU];   // 2*(4*I_b + (l&3))
   int colB0, colB1; // B-fragment columns of the group feeding slots [0,S1) / slots [S1,MAXU)
   int offWw[MAXU];  // row*LDW + col
   int offWr[MAXU];  // col*LDW + row
-  int offX[MAXU];   // row*LDX + col
+  int offX[MAXU];   // pair_off(row, col, LDX)
   int gofs[MAXU];   // row*D + col   (global element offset inside a D x D matrix)
   unsigned valid;   // per-lane bit s: this lane owns a real matrix element in slot s
 };
@@ -182,8 +186,8 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
   const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, wave, nullptr);
   constexpr int rem = g::REM ? g::REM : 1;
   auto group_col = [&](int grp) { return (grp < g::NQ) ? (16 * grp + (lane & 15)) : (4 * (4 * g::NQ + b % rem) + c4); };
-  T.colB0 = group_col(deal.gA);
-  T.colB1 = group_col(deal.gB);
+  T.colB0 = 2 * group_col(deal.gA);      // (doubles; the pair layout stores two k-steps per column)
+  T.colB1 = 2 * group_col(deal.gB);
   T.valid = 0u;
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) {
@@ -210,10 +214,10 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
     // offsets are relative to the LDS base; lanes without an element are pointed at their private trash word
     constexpr int W_BASE = g::ROWS * g::LDX;
     constexpr int TRASH_BASE = g::ROWS * g::LDX + g::P * g::LDW + 3 * g::ROWS * g::LDA + (2 + NW) * g::P;
-    T.colA[s] = 4 * Ib + c4;
+    T.colA[s] = 2 * (4 * Ib + c4);
     T.offWw[s] = own ? (W_BASE + row * g::LDW + col) : (TRASH_BASE + (int)threadIdx.x);
     T.offWr[s] = own ? (W_BASE + col * g::LDW + row) : (TRASH_BASE + (int)threadIdx.x);
-    T.offX[s] = own ? (row * g::LDX + col) : (TRASH_BASE + (int)threadIdx.x);
+    T.offX[s] = own ? pair_off(row, col, g::LDX) : (TRASH_BASE + (int)threadIdx.x);
     T.gofs[s] = row * D + col;
     if (own) T.valid |= (1u << s);
   }
@@ -222,36 +226,41 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
 // ---- one D^3 product on the matrix cores: w[s] = sum_kk Aop-block x X-block ---------------------------------
 // LDAOP = leading dimension of the A-operand matrix (LDA, or LDX when the stage state itself is the operand).
 // Straight-line code: KKE k-steps, fragments of step kk+1 are loaded while the MFMAs of step kk issue.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 template <int NB, int LDAOP>
 __device__ __forceinline__ void mfma_product(const double* __restrict__ Aop, const double* __restrict__ X,
                                              const Tab<NB>& T, double (&w)[Geo<NB>::MAXU]) {
   using g = Geo<NB>;
-  constexpr int MAXU = g::MAXU;
+  constexpr int MAXU = g::MAXU, NP = g::KKE / 2;
   const int r4 = (threadIdx.x & 63) >> 4;
   const double* pa = Aop + r4 * LDAOP;
   const double* px = X + r4 * g::LDX;
-  double af[2][MAXU], bf[2][2];
+  d2_t af[2][MAXU], bf[2][2];
 #pragma unroll
-  for (int s = 0; s < MAXU; s++) { w[s] = 0.0; af[0][s] = pa[T.colA[s]]; }
-  bf[0][0] = px[T.colB0];
-  bf[0][1] = px[T.colB1];
+  for (int s = 0; s < MAXU; s++) { w[s] = 0.0; af[0][s] = *reinterpret_cast<const d2_t*>(pa + T.colA[s]); }
+  bf[0][0] = *reinterpret_cast<const d2_t*>(px + T.colB0);
+  bf[0][1] = *reinterpret_cast<const d2_t*>(px + T.colB1);
 #pragma unroll
-  for (int kk = 0; kk < g::KKE; kk++) {
-    const int cur = kk & 1, nxt = cur ^ 1;
-    if (kk + 1 < g::KKE) {
+  for (int kp = 0; kp < NP; kp++) {
+    const int cur = kp & 1, nxt = cur ^ 1;
+    if (kp + 1 < NP) {
 #pragma unroll
-      for (int s = 0; s < MAXU; s++) af[nxt][s] = pa[(kk + 1) * 4 * LDAOP + T.colA[s]];
-      bf[nxt][0] = px[(kk + 1) * 4 * g::LDX + T.colB0];
-      bf[nxt][1] = px[(kk + 1) * 4 * g::LDX + T.colB1];
+      for (int s = 0; s < MAXU; s++) af[nxt][s] = *reinterpret_cast<const d2_t*>(pa + (kp + 1) * 4 * LDAOP + T.colA[s]);
+      bf[nxt][0] = *reinterpret_cast<const d2_t*>(px + (kp + 1) * 4 * g::LDX + T.colB0);
+      bf[nxt][1] = *reinterpret_cast<const d2_t*>(px + (kp + 1) * 4 * g::LDX + T.colB1);
     }
 #pragma unroll
-    for (int s = 0; s < MAXU; s++) {
-      const double b = (s < g::S1) ? bf[cur][0] : bf[cur][1];      // compile-time choice
-#if defined(VGPA_STAMPS) && defined(VGPA_ABL_NOMFMA)
-      w[s] += af[cur][s] * 1e-300 + b * 1e-300;                     // timing-only ablation (wrong results)
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int s = 0; s < MAXU; s++) {
+        const double b = (s < g::S1) ? bf[cur][0][h] : bf[cur][1][h];   // compile-time choice
+#if defined(VGPA_ABL_NOMFMA)
+        w[s] += af[cur][s][h] * 1e-300 + b * 1e-300;                    // timing-only ablation (wrong results)
 #else
-      w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[cur][s], b, w[s], 0, 0, 0);
+        w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[cur][s][h], b, w[s], 0, 0, 0);
 #endif
+      }
     }
   }
 }
@@ -265,11 +274,12 @@ __device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = wave * NB;
   const int li = (lane < g::P) ? lane : 0;
-  const double* pa = FWD ? (Aop + k0 * g::LDA + li) : (Aop + li * g::LDA + k0);
-  const double* pv = xv + k0;
   double av[NB], xk[NB];
 #pragma unroll
-  for (int k = 0; k < NB; k++) { av[k] = FWD ? pa[k * g::LDA] : pa[k]; xk[k] = pv[k]; }
+  for (int k = 0; k < NB; k++) {
+    av[k] = FWD ? Aop[pair_off(k0 + k, li, g::LDA)] : Aop[pair_off(li, k0 + k, g::LDA)];
+    xk[k] = xv[k0 + k];
+  }
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < NB; k++) s = __builtin_fma(av[k], xk[k], s);
@@ -287,8 +297,18 @@ __device__ __forceinline__ void stage_products(const Lds<NB>& L, int D, const do
   VGPA_STAMP(0);                       // elementwise work since the last publish
   mfma_product<NB, LDAOP>(Aop, L.X, T, w);
   VGPA_STAMP(1);                       // MFMA product
+#if defined(VGPA_ABL_NOMATVEC)
+  const double part = 0.0;                                          // timing-only ablation (wrong results)
+#else
   const double part = matvec_partial<NB, FWD>(Avec, L.xv);
+#endif
   VGPA_STAMP(2);                       // mat-vec
+#if defined(VGPA_ABL_NOXCHG)
+#pragma unroll
+  for (int s = 0; s < g::MAXU; s++) wt[s] = w[s];                    // timing-only ablation (wrong results)
+  vsum = part;
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) L.X[T.offWw[s]] = w[s];          // (offsets are LDS-base relative; X is the base)
   L.pv[wave * g::P + ((lane < g::P) ? lane : 0)] = part;            // lanes >= P hold the same value as lane 0
@@ -312,7 +332,9 @@ __device__ __forceinline__ void publish(const Lds<NB>& L, int D, const Tab<NB>& 
   for (int s = 0; s < Geo<NB>::MAXU; s++) L.X[T.offX[s]] = xn[s];
   if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < D) L.xv[threadIdx.x & 63] = vn;
   VGPA_STAMP(7);                       // X stores
+#if !defined(VGPA_ABL_NOBARB)
   __syncthreads();
+#endif
   VGPA_STAMP(8);                       // barrier B
 }
 
@@ -344,7 +366,7 @@ __device__ __forceinline__ void build_aofs(int D, int (&aofs)[Geo<NB>::EPT]) {
   for (int q = 0; q < g::EPT; q++) {
     const int e = threadIdx.x + q * NT;
     const int r = e / D, c = e - r * D;
-    aofs[q] = (e < D * D) ? (FWD ? (c * g::LDA + r) : (r * g::LDA + c)) : -1;
+    aofs[q] = (e < D * D) ? (FWD ? pair_off(c, r, g::LDA) : pair_off(r, c, g::LDA)) : -1;
   }
 }
 
@@ -398,12 +420,25 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   __syncthreads();
 
   for (int k = 0; k < Np - 1; k++) {
+    // S_k, m_k of the previous iteration go to HBM here, right behind the operand loads they follow in the memory
+    // queue: by the time the next iteration waits for its operands (vmcnt) these stores have long retired.
+#if !defined(VGPA_ABL_NOSTORE)
+    if (k > 0) {
+      double* so = st + (size_t)k * DD;
+#pragma unroll
+      for (int s = 0; s < MAXU; s++)
+        if ((T.valid >> s) & 1u) so[T.gofs[s]] = sk[s];
+      if (vlane) mt[(size_t)k * D + lane] = mk;
+    }
+#endif
     // operands of this step: A1 <- A_{k+1}, AM <- mid-point; prefetch A_{k+2} for the next step
+#if !defined(VGPA_ABL_NOSTAGE)
     store_a<NB, true, false>(L.A1, D, aofs, aN, aN);
     if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, true, true>(L.AM, D, aofs, aC, aN);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (k + 2 < Np) load_a<NB>(A + (size_t)(k + 2) * DD, DD, aN);
+#endif
     const double b2 = (vlane && k + 2 < Np) ? bb[(size_t)(k + 2) * D + lane] : 0.0;
     double mnew = 0.0;
 
@@ -462,15 +497,17 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
       mnew = mk + dt * (k1 + 2.0 * (k2 + k3) + k4) / 6.0;
     }
     mk = mnew;
-    double* so = st + (size_t)(k + 1) * DD;
-#pragma unroll
-    for (int s = 0; s < MAXU; s++)
-      if ((T.valid >> s) & 1u) so[T.gofs[s]] = sk[s];
-    if (vlane) mt[(size_t)(k + 1) * D + lane] = mk;
     publish<NB>(L, D, T, sk, mk VGPA_STAMP_PASS);
     // rotate operand buffers: A_{k+1} becomes the start-point operand of the next step
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     b0 = b1; b1 = b2;
+  }
+  if (Np > 1) {
+    double* so = st + (size_t)(Np - 1) * DD;
+#pragma unroll
+    for (int s = 0; s < MAXU; s++)
+      if ((T.valid >> s) & 1u) so[T.gofs[s]] = sk[s];
+    if (vlane) mt[(size_t)(Np - 1) * D + lane] = mk;
   }
 #ifdef VGPA_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 0) { g_clk[2] = __builtin_amdgcn_s_memtime(); g_clk[3] = __builtin_amdgcn_s_memrealtime(); }
@@ -532,6 +569,14 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
   __syncthreads();
 
   for (int t = Np - 1; t > 0; t--) {
+    // Psi_t, lam_t of the previous iteration go to HBM here (see the forward kernel)
+    if (t < Np - 1) {
+      double* po = psi + (size_t)t * DD;
+#pragma unroll
+      for (int s = 0; s < MAXU; s++)
+        if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
+      if (vlane) lam[(size_t)t * D + lane] = lk;
+    }
     store_a<NB, false, false>(L.A1, D, aofs, aN, aN);
     if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, false, true>(L.AM, D, aofs, aN, aC);
 #pragma unroll
@@ -617,17 +662,21 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
       lnew = lk - dt * (k1 + 2.0 * (k2 + k3) + k4) / 6.0 + jm;
     }
     lk = lnew;
-    double* po = psi + (size_t)(t - 1) * DD;
 #pragma unroll
     for (int s = 0; s < MAXU; s++) {
-      if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
       gC[s] = gN[s];
       gN[s] = (((T.valid >> s) & 1u) && t >= 2) ? gs[(size_t)(t - 2) * DD + T.gofs[s]] : 0.0;
     }
-    if (vlane) lam[(size_t)(t - 1) * D + lane] = lk;
     publish<NB>(L, D, T, pk, lk VGPA_STAMP_PASS);
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
+  }
+  if (Np > 1) {
+    double* po = psi;
+#pragma unroll
+    for (int s = 0; s < MAXU; s++)
+      if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
+    if (vlane) lam[lane] = lk;
   }
 }
 
