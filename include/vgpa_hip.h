@@ -66,7 +66,8 @@ enum {
 };
 /* config flags */
 enum {
-  VGPA_FLAG_FORCE_GENERIC = 1 /* use the generic (no symmetry assumption) stepping kernels */
+  VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
+  VGPA_FLAG_PAIR_PROBLEMS = 2  /* experimental: two phase-staggered problems per workgroup in the MFMA steppers */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;

@@ -28,8 +28,14 @@
 namespace vgpa {
 namespace mfma {
 
-constexpr int NT = 256;
-constexpr int NW = 4;
+constexpr int NT = 256;   // threads working on one problem
+constexpr int NW = 4;     // waves working on one problem (one per SIMD)
+
+// A workgroup holds ONE problem (256 threads) or TWO (512 threads: waves 0-3 -> problem 2b, waves 4-7 -> problem
+// 2b+1, phase-staggered, see k_fwd_mfma).  Everything below addresses threads through these problem-local ids.
+__device__ __forceinline__ int ltid() { return threadIdx.x & (NT - 1); }
+__device__ __forceinline__ int lwave() { return (threadIdx.x >> 6) & (NW - 1); }
+__device__ __forceinline__ int lhalf() { return threadIdx.x >> 8; }
 
 // Diagnostic build only (tools/ubench/ode_stamp.hip): per-segment cycle sums of one wave.  Never defined in the
 // product build, so no stamp executes there.
@@ -181,7 +187,7 @@ struct Tab {
 template <int NB>
 __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
   using g = Geo<NB>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = lwave();
   const int b = (lane >> 2) & 3, r4 = lane >> 4, c4 = lane & 3;
   const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, wave, nullptr);
   constexpr int rem = g::REM ? g::REM : 1;
@@ -215,9 +221,9 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
     constexpr int W_BASE = g::ROWS * g::LDX;
     constexpr int TRASH_BASE = g::ROWS * g::LDX + g::P * g::LDW + 3 * g::ROWS * g::LDA + (2 + NW) * g::P;
     T.colA[s] = 2 * (4 * Ib + c4);
-    T.offWw[s] = own ? (W_BASE + row * g::LDW + col) : (TRASH_BASE + (int)threadIdx.x);
-    T.offWr[s] = own ? (W_BASE + col * g::LDW + row) : (TRASH_BASE + (int)threadIdx.x);
-    T.offX[s] = own ? pair_off(row, col, g::LDX) : (TRASH_BASE + (int)threadIdx.x);
+    T.offWw[s] = own ? (W_BASE + row * g::LDW + col) : (TRASH_BASE + ltid());
+    T.offWr[s] = own ? (W_BASE + col * g::LDW + row) : (TRASH_BASE + ltid());
+    T.offX[s] = own ? pair_off(row, col, g::LDX) : (TRASH_BASE + ltid());
     T.gofs[s] = row * D + col;
     if (own) T.valid |= (1u << s);
   }
@@ -271,7 +277,7 @@ template <int NB, bool FWD>
 __device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop, const double* __restrict__ xv) {
   using g = Geo<NB>;
   static_assert(NW * NB == g::P, "the four waves split the padded k range evenly");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = lwave();
   const int k0 = wave * NB;
   const int li = (lane < g::P) ? lane : 0;
   double av[NB], xk[NB];
@@ -293,7 +299,7 @@ __device__ __forceinline__ void stage_products(const Lds<NB>& L, int D, const do
                                                const double* Avec, double (&w)[Geo<NB>::MAXU],
                                                double (&wt)[Geo<NB>::MAXU], double& vsum VGPA_STAMP_ARG) {
   using g = Geo<NB>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = lwave();
   VGPA_STAMP(0);                       // elementwise work since the last publish
   mfma_product<NB, LDAOP>(Aop, L.X, T, w);
   VGPA_STAMP(1);                       // MFMA product
@@ -330,7 +336,7 @@ __device__ __forceinline__ void publish(const Lds<NB>& L, int D, const Tab<NB>& 
   VGPA_STAMP(6);                       // elementwise work of the stage
 #pragma unroll
   for (int s = 0; s < Geo<NB>::MAXU; s++) L.X[T.offX[s]] = xn[s];
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < D) L.xv[threadIdx.x & 63] = vn;
+  if (lwave() == 0 && (threadIdx.x & 63) < D) L.xv[threadIdx.x & 63] = vn;
   VGPA_STAMP(7);                       // X stores
 #if !defined(VGPA_ABL_NOBARB)
   __syncthreads();
@@ -343,7 +349,7 @@ template <int NB>
 __device__ __forceinline__ void load_a(const double* __restrict__ A, int DD, double (&a)[Geo<NB>::EPT]) {
 #pragma unroll
   for (int q = 0; q < Geo<NB>::EPT; q++) {
-    const int e = threadIdx.x + q * NT;
+    const int e = ltid() + q * NT;
     a[q] = (e < DD) ? A[e] : 0.0;
   }
 }
@@ -364,22 +370,28 @@ __device__ __forceinline__ void build_aofs(int D, int (&aofs)[Geo<NB>::EPT]) {
   using g = Geo<NB>;
 #pragma unroll
   for (int q = 0; q < g::EPT; q++) {
-    const int e = threadIdx.x + q * NT;
+    const int e = ltid() + q * NT;
     const int r = e / D, c = e - r * D;
     aofs[q] = (e < D * D) ? (FWD ? pair_off(c, r, g::LDA) : pair_off(r, c, g::LDA)) : -1;
   }
 }
 
 // =================================================================================================================
-template <int METHOD, int NB>
-__global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
+template <int METHOD, int NB, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
   const int D = a.D, DD = D * D, Np = a.Np;
-  const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PAIR: two problems per workgroup.  Half 1 runs ONE barrier behind half 0, so that while one problem is in the
+  // LDS-exchange / elementwise part of a stage (matrix pipe idle) the other one issues its MFMAs on the same SIMDs.
+  const int half = PAIR ? lhalf() : 0;
+  const int prob_raw = PAIR ? (2 * (int)blockIdx.x + half) : (int)blockIdx.x;
+  const int prob = prob_raw < a.batch ? prob_raw : a.batch - 1;   // odd batch: the spare half redoes the last problem
+  const int tid = ltid(), lane = tid & 63, wave = lwave();
+  double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
   Lds<NB> L;
-  L.carve(smem);
+  L.carve(lds_base);
   const double* A = a.A + (size_t)prob * Np * DD;
   const double* bb = a.b + (size_t)prob * Np * D;
   double* mt = a.m + (size_t)prob * Np * D;
@@ -395,7 +407,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   build_tab<NB>(D, T);
   int aofs[EPT];
   build_aofs<NB, true>(D, aofs);
-  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
+  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
   double sk[MAXU], sig[MAXU], w[MAXU], wt[MAXU], r[MAXU], acc1[MAXU], acc2[MAXU], xn[MAXU];
@@ -418,6 +430,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
   double b0 = vlane ? bb[lane] : 0.0;
   double b1 = (vlane && Np > 1) ? bb[D + lane] : 0.0;
   __syncthreads();
+  if (PAIR && half == 1) __syncthreads();          // stagger: half 1 trails by one barrier
 
   for (int k = 0; k < Np - 1; k++) {
     // S_k, m_k of the previous iteration go to HBM here, right behind the operand loads they follow in the memory
@@ -502,6 +515,7 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     b0 = b1; b1 = b2;
   }
+  if (PAIR && half == 0) __syncthreads();          // matches the extra barrier of half 1
   if (Np > 1) {
     double* so = st + (size_t)(Np - 1) * DD;
 #pragma unroll
@@ -515,15 +529,21 @@ __global__ void __launch_bounds__(NT) k_fwd_mfma(OdeArgs a) {
 }
 
 // =================================================================================================================
-template <int METHOD, int NB>
-__global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
+template <int METHOD, int NB, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
   const int D = a.D, DD = D * D, Np = a.Np;
-  const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PAIR: two problems per workgroup.  Half 1 runs ONE barrier behind half 0, so that while one problem is in the
+  // LDS-exchange / elementwise part of a stage (matrix pipe idle) the other one issues its MFMAs on the same SIMDs.
+  const int half = PAIR ? lhalf() : 0;
+  const int prob_raw = PAIR ? (2 * (int)blockIdx.x + half) : (int)blockIdx.x;
+  const int prob = prob_raw < a.batch ? prob_raw : a.batch - 1;   // odd batch: the spare half redoes the last problem
+  const int tid = ltid(), lane = tid & 63, wave = lwave();
+  double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
   Lds<NB> L;
-  L.carve(smem);
+  L.carve(lds_base);
   const double* A = a.A + (size_t)prob * Np * DD;
   const double* gm = a.dEm + (size_t)prob * Np * D;
   const double* gs = a.dEs + (size_t)prob * Np * DD;
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
   build_tab<NB>(D, T);
   int aofs[EPT];
   build_aofs<NB, false>(D, aofs);
-  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
+  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
   double pk[MAXU], gC[MAXU], gN[MAXU], jsc[MAXU], w[MAXU], wt[MAXU], r[MAXU], acc1[MAXU], acc2[MAXU], xn[MAXU];
@@ -567,6 +587,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
     else if (vlane && n_obs_cur >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_cur) * D + lane];
   }
   __syncthreads();
+  if (PAIR && half == 1) __syncthreads();          // stagger: half 1 trails by one barrier
 
   for (int t = Np - 1; t > 0; t--) {
     // Psi_t, lam_t of the previous iteration go to HBM here (see the forward kernel)
@@ -671,6 +692,7 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
   }
+  if (PAIR && half == 0) __syncthreads();          // matches the extra barrier of half 1
   if (Np > 1) {
     double* po = psi;
 #pragma unroll
@@ -680,15 +702,25 @@ __global__ void __launch_bounds__(NT) k_bwd_mfma(OdeArgs a) {
   }
 }
 
-template <int METHOD, bool FWD, int NB>
-hipError_t launch_nb(const OdeArgs& a, hipStream_t st) {
-  constexpr size_t lds = Geo<NB>::LDS_DOUBLES * sizeof(double);
+template <int METHOD, bool FWD, int NB, bool PAIR>
+hipError_t launch_nb_p(const OdeArgs& a, hipStream_t st) {
+  constexpr size_t lds = (PAIR ? 2 : 1) * Geo<NB>::LDS_DOUBLES * sizeof(double);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = FWD ? k_fwd_mfma<METHOD, NB> : k_bwd_mfma<METHOD, NB>;
+  auto kern = FWD ? k_fwd_mfma<METHOD, NB, PAIR> : k_bwd_mfma<METHOD, NB, PAIR>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(a.batch), dim3(NT), lds, st, a);
+  const int blocks = PAIR ? (a.batch + 1) / 2 : a.batch;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(PAIR ? 2 * NT : NT), lds, st, a);
   return hipGetLastError();
+}
+
+// Two problems per workgroup when the batch can fill the chip that way and both fit in LDS; else one.
+template <int METHOD, bool FWD, int NB>
+hipError_t launch_nb(const OdeArgs& a, hipStream_t st) {
+  if constexpr (2 * Geo<NB>::LDS_DOUBLES * sizeof(double) <= 160 * 1024) {
+    if (a.batch >= 2 && !a.no_pair) return launch_nb_p<METHOD, FWD, NB, true>(a, st);
+  }
+  return launch_nb_p<METHOD, FWD, NB, false>(a, st);
 }
 
 }  // namespace mfma

@@ -15,6 +15,7 @@ constexpr int kMaxTheta = 4;
 // Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
 struct OdeArgs {
   int D, Np, batch;
+  int no_pair;           // diagnostics: force one problem per workgroup in the MFMA stepping kernels
   double dt;
   // forward
   const double* A;       // [B][Np][D][D]
