@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(NT) k_grad(GradArgs a) {
   double* mv = P + (a.sigma_diag ? 0 : D * LD);
   double* rv = mv + D;            // -Ef - A m + b
   double* uv = rv + D;            // dEb + lam
-  const double* At = a.A + o * DD;
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
+  const double* bt = a.b + (size_t)prob * a.strideB + (size_t)t * D;
   const double* St = a.S + o * DD;
   const double* Pt = a.psi + o * DD;
   const double* Edf = a.Edf ? a.Edf + o * DD : nullptr;
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(NT) k_grad(GradArgs a) {
   if (tid < D) {
     double s = 0.0;
     for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
-    rv[tid] = -a.Ef[o * D + tid] - s + a.b[o * D + tid];
+    rv[tid] = -a.Ef[o * D + tid] - s + bt[tid];
   }
   __syncthreads();
   if (!a.sigma_diag) {
@@ -178,7 +179,8 @@ __global__ void __launch_bounds__(64) k_grad_small(GradArgs a) {
   if (t >= a.Np) return;
   constexpr int DD = D * D;
   const size_t o = (size_t)prob * a.Np + t;
-  const double* At = a.A + o * DD;
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
+  const double* bt = a.b + (size_t)prob * a.strideB + (size_t)t * D;
   const double* St = a.S + o * DD;
   const double* Pt = a.psi + o * DD;
   double mv[D], rv[D], uv[D], pa[DD], q[DD];
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(64) k_grad_small(GradArgs a) {
   for (int i = 0; i < D; i++) {
     double s = 0.0;
     for (int k = 0; k < D; k++) s = __builtin_fma(At[i * D + k], mv[k], s);
-    rv[i] = -a.Ef[o * D + i] - s + a.b[o * D + i];
+    rv[i] = -a.Ef[o * D + i] - s + bt[i];
   }
   for (int i = 0; i < D; i++)
     for (int j = 0; j < D; j++)

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(NT) k_energy_1d(EnergyArgs a) {
   if (t >= a.Np) return;
   const size_t o = (size_t)prob * a.Np + t;
   const double th = a.theta[0], sg = a.sigma1;
-  const double la = a.A[o], ob = a.b[o], m = a.m[o], s = a.S[o];
+  const double la = a.A[(size_t)prob * a.strideA + t], ob = a.b[(size_t)prob * a.strideB + t], m = a.m[o], s = a.S[o];
   if (a.model == VGPA_MODEL_OU) {
     const double ex2 = m * m + s;
     const double q1 = (th - la) * (th - la);
@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(64) k_energy_l63(EnergyArgs a) {
   const int prob = blockIdx.y;
   if (t >= a.Np) return;
   const size_t o = (size_t)prob * a.Np + t;
-  const double* At = a.A + o * 9;
-  const double* bt = a.b + o * 3;
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * 9;
+  const double* bt = a.b + (size_t)prob * a.strideB + (size_t)t * 3;
   const double* mt = a.m + o * 3;
   const double* St = a.S + o * 9;
   const double vS = a.theta[0], vR = a.theta[1], vB = a.theta[2];
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   L96Lds S;
   S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
   S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
-  const double* At = a.A + o * D * D;
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
   const double theta = a.theta[0];
   const double kappa = 1.05 * D, c = D + kappa;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     }
   }
   if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
-  if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[o * D + l]; S.sg[l] = a.isg[l]; }
+  if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[(size_t)prob * a.strideB + (size_t)t * D + l]; S.sg[l] = a.isg[l]; }
   wave_sync();
 
   // ---- 1. Cholesky, left-looking in panels of four columns (numpy.linalg.cholesky reads the lower triangle);

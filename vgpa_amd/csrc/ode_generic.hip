@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(NT) k_fwd_generic(OdeArgs a) {
   const int prob = blockIdx.x;
   Lds l;
   l.X = smem; l.Y = smem + DD; l.AB = smem + 2 * DD; l.xv = smem + 3 * DD; l.yv = l.xv + D;
-  const double* A = a.A + (size_t)prob * Np * DD;
-  const double* b = a.b + (size_t)prob * Np * D;
+  const double* A = a.A + (size_t)prob * a.strideA;
+  const double* b = a.b + (size_t)prob * a.strideB;
   double* mt = a.m + (size_t)prob * Np * D;
   double* st = a.S + (size_t)prob * Np * DD;
   const double dt = a.dt, h = 0.5 * a.dt;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(NT) k_bwd_generic(OdeArgs a) {
   const int prob = blockIdx.x;
   Lds l;
   l.X = smem; l.Y = smem + DD; l.AB = smem + 2 * DD; l.xv = smem + 3 * DD; l.yv = l.xv + D;
-  const double* A = a.A + (size_t)prob * Np * DD;
+  const double* A = a.A + (size_t)prob * a.strideA;
   const double* gm = a.dEm + (size_t)prob * Np * D;
   const double* gs = a.dEs + (size_t)prob * Np * DD;
   double* lam = a.lam + (size_t)prob * Np * D;

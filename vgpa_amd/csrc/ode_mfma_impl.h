@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
   double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
   Lds<NB> L;
   L.carve(lds_base);
-  const double* A = a.A + (size_t)prob * Np * DD;
-  const double* bb = a.b + (size_t)prob * Np * D;
+  const double* A = a.A + (size_t)prob * a.strideA;
+  const double* bb = a.b + (size_t)prob * a.strideB;
   double* mt = a.m + (size_t)prob * Np * D;
   double* st = a.S + (size_t)prob * Np * DD;
   const double dt = a.dt, h = 0.5 * a.dt;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
   double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
   Lds<NB> L;
   L.carve(lds_base);
-  const double* A = a.A + (size_t)prob * Np * DD;
+  const double* A = a.A + (size_t)prob * a.strideA;
   const double* gm = a.dEm + (size_t)prob * Np * D;
   const double* gs = a.dEs + (size_t)prob * Np * DD;
   double* lam = a.lam + (size_t)prob * Np * D;

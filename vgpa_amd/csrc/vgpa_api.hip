@@ -24,6 +24,7 @@ struct vgpa_ctx {
   double theta[kMaxTheta] = {0, 0, 0, 0};
   // device buffers
   std::vector<void*> allocs;
+  const double* xcur = nullptr;   // where the kernels read [A|b] from (d_x or the caller's device buffer)
   double *d_x = nullptr, *d_m = nullptr, *d_S = nullptr, *d_Ef = nullptr, *d_dEm = nullptr, *d_dEs = nullptr;
   double *d_lam = nullptr, *d_psi = nullptr, *d_g = nullptr, *d_et = nullptr, *d_eobs = nullptr, *d_esde = nullptr;
   double *d_f = nullptr, *d_jm = nullptr, *d_Edf = nullptr, *d_jm_dense = nullptr, *d_js_dense = nullptr;
@@ -101,20 +102,24 @@ bool stack_symmetric(const double* a, size_t count, int n) {
 
 }  // namespace
 
-// x (host or device, [B][len_x]) -> d_A/d_b problem-major arrays.  d_x holds [B][Np*DD] of A followed
-// by [B][Np*D] of b.
-static inline double* ctx_A(vgpa_ctx* c) { return c->d_x; }
-static inline double* ctx_b(vgpa_ctx* c) { return c->d_x + (size_t)c->B * c->Np * c->DD; }
+// The variational parameters are consumed in the caller's x layout: problem p at xcur + p*len_x, A first, then b.
+// xcur is either the context's own copy d_x (host entry points) or the caller's device buffer (zero copy).
+static inline const double* ctx_A(vgpa_ctx* c) { return c->xcur; }
+static inline const double* ctx_b(vgpa_ctx* c) { return c->xcur + (size_t)c->Np * c->DD; }
 
 static int ingest_x(vgpa_ctx* c, const double* x, bool on_device) {
+  if (on_device) { c->xcur = x; return VGPA_OK; }
+  HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (size_t)c->B * c->len_x * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->xcur = c->d_x;
+  return VGPA_OK;
+}
+
+// operator-level inputs arrive as separate [B][Np][D][D] / [B][Np][D] host arrays: pack them into the x layout
+static int ingest_ab(vgpa_ctx* c, const double* lin_a, const double* off_b) {
   const size_t na = (size_t)c->Np * c->DD, nb = (size_t)c->Np * c->D;
-  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (c->B == 1) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (na + nb) * sizeof(double), kind, c->stream));
-    return VGPA_OK;
-  }
-  HIP_TRY(c, hipMemcpy2DAsync(ctx_A(c), na * sizeof(double), x, c->len_x * sizeof(double), na * sizeof(double), c->B, kind, c->stream));
-  HIP_TRY(c, hipMemcpy2DAsync(ctx_b(c), nb * sizeof(double), x + na, c->len_x * sizeof(double), nb * sizeof(double), c->B, kind, c->stream));
+  c->xcur = c->d_x;
+  if (lin_a) HIP_TRY(c, hipMemcpy2DAsync(c->d_x, c->len_x * sizeof(double), lin_a, na * sizeof(double), na * sizeof(double), c->B, hipMemcpyHostToDevice, c->stream));
+  if (off_b) HIP_TRY(c, hipMemcpy2DAsync(c->d_x + na, c->len_x * sizeof(double), off_b, nb * sizeof(double), nb * sizeof(double), c->B, hipMemcpyHostToDevice, c->stream));
   return VGPA_OK;
 }
 
@@ -140,6 +145,7 @@ static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
   OdeArgs a{};
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
   a.no_pair = (c->cfg.flags & VGPA_FLAG_PAIR_PROBLEMS) ? 0 : 1;
   hipError_t e = use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
@@ -151,6 +157,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
 static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   OdeArgs a{};
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
   a.no_pair = (c->cfg.flags & VGPA_FLAG_PAIR_PROBLEMS) ? 0 : 1;
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
@@ -166,6 +173,7 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
   a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
   a.sigma1 = c->sigma1; a.isg = c->d_isg;
+  a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
   a.e_t = c->d_et; a.Ef = c->d_Ef; a.Edf = edf; a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.status = c->d_status;
   return a;
@@ -201,6 +209,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.sigma_diag = c->sigma_diag ? 1 : 0;
   a.dt = c->cfg.dt;
   for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
+  a.strideA = a.strideB = c->len_x;
   a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
   hipError_t e = launch_grad(a, c->stream);
@@ -419,8 +428,7 @@ int vgpa_solve_fwd(vgpa_ctx* c, const double* lin_a, const double* off_b, const 
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t BN = (size_t)c->B * c->Np;
   int rc;
-  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
-  if ((rc = upload(c, ctx_b(c), off_b, BN * c->D))) return rc;
+  if ((rc = ingest_ab(c, lin_a, off_b))) return rc;
   if ((rc = upload(c, c->d_op_m0, m0, (size_t)c->D))) return rc;
   if ((rc = upload(c, c->d_op_S0, s0, c->DD))) return rc;
   if ((rc = upload(c, c->d_op_Sigma, sigma, c->DD))) return rc;
@@ -442,7 +450,7 @@ int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, con
     if ((rc = dev_alloc(c, &c->d_jm_dense, BN * c->D))) return rc;
     if ((rc = dev_alloc(c, &c->d_js_dense, BN * c->DD))) return rc;
   }
-  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
+  if ((rc = ingest_ab(c, lin_a, nullptr))) return rc;
   if ((rc = upload(c, c->d_dEm, desde_dm, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_dEs, desde_ds, BN * c->DD))) return rc;
   if ((rc = upload(c, c->d_jm_dense, deobs_dm, BN * c->D))) return rc;
@@ -462,8 +470,7 @@ int vgpa_energy(vgpa_ctx* c, const double* lin_a, const double* off_b, const dou
   const size_t BN = (size_t)c->B * c->Np;
   int rc;
   if (edf && !c->d_Edf && (rc = dev_alloc(c, &c->d_Edf, BN * c->DD))) return rc;
-  if ((rc = upload(c, ctx_A(c), lin_a, BN * c->DD))) return rc;
-  if ((rc = upload(c, ctx_b(c), off_b, BN * c->D))) return rc;
+  if ((rc = ingest_ab(c, lin_a, off_b))) return rc;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));

@@ -16,6 +16,7 @@ constexpr int kMaxTheta = 4;
 struct OdeArgs {
   int D, Np, batch;
   int no_pair;           // diagnostics: force one problem per workgroup in the MFMA stepping kernels
+  size_t strideA, strideB;  // elements between consecutive problems in A / b (x layout: len_x for both)
   double dt;
   // forward
   const double* A;       // [B][Np][D][D]
@@ -44,8 +45,9 @@ struct EnergyArgs {
   double theta[kMaxTheta];
   double sigma1;            // 1-D models: sigma
   const double* isg;        // [D] diagonal of Sigma^-1
-  const double* A;          // [B][Np][D][D]
-  const double* b;          // [B][Np][D]
+  size_t strideA, strideB;  // elements between consecutive problems in A / b
+  const double* A;          // [B][Np][D][D] (problem stride strideA)
+  const double* b;          // [B][Np][D]    (problem stride strideB)
   const double* m;          // [B][Np][D]
   const double* S;          // [B][Np][D][D]
   double* e_t;              // [B][Np] integrand of E_sde
@@ -75,6 +77,7 @@ struct GradArgs {
   double dt;
   double theta[kMaxTheta];
   const double* isig;       // [D][D] Sigma^-1
+  size_t strideA, strideB;  // elements between consecutive problems in A / b
   const double* A; const double* b;
   const double* m; const double* S;
   const double* lam; const double* psi;
