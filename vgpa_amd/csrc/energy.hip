@@ -186,10 +186,95 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// value of lane j (wave-uniform j) through v_readlane_b32: much cheaper than a ds_bpermute round trip
+__device__ __forceinline__ double lane_value(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- wave-level fp64 MFMA product for the two GEMM-shaped phases --------------------------------------------------
+// W[i][j] = sum_k Aop[k][i] * Bm[k][j] over the padded P x P problem (P = 4*NB), one wave, v_mfma_f64_4x4x4_4b_f64.
+// Same unit scheme as the stepping kernels (ode_mfma_impl.h): a unit = one accumulator = four 4x4 output blocks;
+// full units (I, q) cover block-row I x 16 columns, left-over units pack the remaining column blocks of G rows.
+// Both callers have triangular structure that is exploited at compile time (whole 4x4x4 block products skipped):
+//   MODE 0:  Bm[k][j] = 0 for k < j            (G = A.L, L lower triangular)
+//   MODE 1:  additionally Aop[k][i] = 0 for k < i  (X^T diag(q) X with X = L^-1 lower triangular)
+template <int NB>
+struct WaveGemmGeo {
+  static constexpr int NQ = NB / 4, REM = NB % 4, G = REM ? 4 / REM : 0;
+  static constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
+  static constexpr int NU = NB * NQ + NLEFT;
+};
+
+template <int NB, int MODE>
+__device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const double* __restrict__ Bm, int LD,
+                                          double (&acc)[WaveGemmGeo<NB>::NU]) {
+  using g = WaveGemmGeo<NB>;
+  const int l = threadIdx.x & 63, r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+  constexpr int rem = g::REM ? g::REM : 1;
+#pragma unroll
+  for (int u = 0; u < g::NU; u++) acc[u] = 0.0;
+  const double* pa = Aop + r4 * LD + c4;
+  const double* pb = Bm + r4 * LD;
+  const int colq = l & 15;                                   // column inside a full 16-column group
+  const int coll = 4 * (4 * g::NQ + b % rem) + c4;           // column of the left-over group
+  const int ileft = b / rem;                                 // block-row offset inside a left-over unit
+#pragma unroll
+  for (int kk = 0; kk < NB; kk++) {
+    double bq[g::NQ > 0 ? g::NQ : 1];
+#pragma unroll
+    for (int q = 0; q < g::NQ; q++)
+      if (kk >= 4 * q) bq[q] = pb[kk * 4 * LD + 16 * q + colq];
+    double bl = 0.0;
+    if (g::NLEFT > 0 && kk >= 4 * g::NQ) bl = pb[kk * 4 * LD + coll];
+#pragma unroll
+    for (int I = 0; I < NB; I++) {
+      if (MODE == 1 && kk < I) continue;
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < g::NQ; q++) any = any || (kk >= 4 * q);
+      if (!any) continue;
+      const double af = pa[kk * 4 * LD + 4 * I];
+#pragma unroll
+      for (int q = 0; q < g::NQ; q++)
+        if (kk >= 4 * q) acc[q * NB + I] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * NB + I], 0, 0, 0);
+    }
+    if (g::NLEFT > 0 && kk >= 4 * g::NQ) {
+#pragma unroll
+      for (int v = 0; v < g::NLEFT; v++) {
+        if (MODE == 1 && kk < v * g::G) continue;
+        int ib = v * g::G + ileft;
+        ib = ib < NB ? ib : NB - 1;                          // spare block slots read valid memory; result unused
+        const double af = pa[kk * 4 * LD + 4 * ib];
+        acc[NB * g::NQ + v] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bl, acc[NB * g::NQ + v], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// (row, col) of the element this lane holds in accumulator u; ok = it is a real block slot
+template <int NB>
+__device__ __forceinline__ void wave_gemm_elem(int u, int& row, int& col, bool& ok) {
+  using g = WaveGemmGeo<NB>;
+  const int l = threadIdx.x & 63, r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+  constexpr int rem = g::REM ? g::REM : 1;
+  int Ib, Jb;
+  if (u < NB * g::NQ) {
+    const int q = u / NB;
+    Ib = u - q * NB; Jb = 4 * q + b; ok = true;
+  } else {
+    const int v = u - NB * g::NQ;
+    Ib = v * g::G + b / rem; Jb = 4 * g::NQ + b % rem;
+    ok = (b < g::G * g::REM) && (Ib < NB);
+  }
+  row = 4 * Ib + r4; col = 4 * Jb + c4;
 }
 
 struct L96Lds {
@@ -205,9 +290,11 @@ __host__ __device__ inline size_t l96_lds_doubles(int D) {
 // Register blocking: every inner k-iteration below feeds FOUR independent fma chains from FIVE LDS reads (one
 // lane-private operand + four wave-uniform ones), which both cuts LDS traffic (the binding resource of this
 // kernel) and gives the scheduler independent work to hide the LDS latency behind.
+template <int NB>
 __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int D = a.D, Dp = l96_dp(D), LD = l96_ld(D), M = 2 * D + 1;
+  const int D = a.D, M = 2 * D + 1;
+  constexpr int Dp = 4 * NB, LD = Dp + 1;
   const int l = threadIdx.x;
   const long long wid = blockIdx.x;
   const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
@@ -232,7 +319,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     while (cc >= D) { cc -= D; r++; }
     for (int e = l; e < D * D; e += 64) {
       S.Lm[r * LD + cc] = c * St[e];
-      S.Gm[r * LD + cc] = At[e];
+      S.Gm[cc * LD + r] = At[e];                 // A^T: operand layout [k][i] of the MFMA product
       cc += 64;
       while (cc >= D) { cc -= D; r++; }
     }
@@ -249,7 +336,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     double s0 = rowi[j0], s1 = rowi[j0 + 1], s2 = rowi[j0 + 2], s3 = rowi[j0 + 3];
     const double* p0 = S.Lm + j0 * LD;
     const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < j0; k++) {
       const double av = rowi[k];
       s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
@@ -261,10 +348,10 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       const int j = j0 + q;
       double s = sq[q];
 #pragma unroll
-      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], __shfl(lq[q2], j, 64), s);
-      const double piv = __shfl(s, j, 64);
+      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
+      const double piv = lane_value(s, j);
       if (!(piv > 0.0)) bad = true;
-      const double d = sqrt(piv), rdv = 1.0 / d;
+      const double rdv = rsqrt(piv), d = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
       lq[q] = (l > j) ? s * rdv : 0.0;
       if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
       if (l == j) S.rd[j] = rdv;
@@ -278,23 +365,19 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     return;
   }
 
-  // ---- 2. A.m ; G = A.L in place (row i is private to lane i; ascending r never reads what it overwrote)
+  // ---- 2. A.m (lane = row i, A^T rows are contiguous over i) ; G = A.L on the matrix cores, then Gm <- G ([i][r])
   {
-    double* gi = S.Gm + li * LD;
     double s = 0.0;
-    for (int k = 0; k < D; k++) s = __builtin_fma(gi[k], S.mv[k], s);
+    for (int k = 0; k < D; k++) s = __builtin_fma(S.Gm[k * LD + li], S.mv[k], s);
     if (act) S.am[l] = s;
-    for (int r0 = 0; r0 < Dp; r0 += 4) {
-      double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-      const double* lr = S.Lm + r0;
-#pragma unroll 2
-      for (int k = r0; k < Dp; k++) {
-        const double av = gi[k];
-        const double* lk = lr + k * LD;
-        g0 = __builtin_fma(av, lk[0], g0); g1 = __builtin_fma(av, lk[1], g1);
-        g2 = __builtin_fma(av, lk[2], g2); g3 = __builtin_fma(av, lk[3], g3);
-      }
-      if (pad) { gi[r0] = g0; gi[r0 + 1] = g1; gi[r0 + 2] = g2; gi[r0 + 3] = g3; }
+    double acc[WaveGemmGeo<NB>::NU];
+    wave_gemm<NB, 0>(S.Gm, S.Lm, LD, acc);
+    wave_sync();                                 // every lane is done reading A^T before G overwrites it
+#pragma unroll
+    for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
+      int row, col; bool ok;
+      wave_gemm_elem<NB>(u, row, col, ok);
+      if (ok) S.Gm[row * LD + col] = acc[u];
     }
   }
   wave_sync();
@@ -343,7 +426,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     double s0 = (i0 == l) ? 1.0 : 0.0, s1 = (i0 + 1 == l) ? 1.0 : 0.0, s2 = (i0 + 2 == l) ? 1.0 : 0.0,
            s3 = (i0 + 3 == l) ? 1.0 : 0.0;
     const double* xc = S.Gm + li;
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < i0; k++) {
       const double xv = xc[k * LD];
       s0 = __builtin_fma(-r0p[k], xv, s0); s1 = __builtin_fma(-r1p[k], xv, s1);
@@ -373,22 +456,14 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     if (pad) S.Lm[k * LD + l] = S.qq[k] * S.Gm[k * LD + l];
   wave_sync();
   double* ds = a.dEs + o * D * D;
-  for (int i0 = 0; i0 < Dp; i0 += 4) {
-    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-    const double* xr = S.Gm + i0;
-    const double* yc = S.Lm + li;
-#pragma unroll 2
-    for (int k = i0; k < Dp; k++) {
-      const double yv = yc[k * LD];
-      const double* xk = xr + k * LD;
-      g0 = __builtin_fma(xk[0], yv, g0); g1 = __builtin_fma(xk[1], yv, g1);
-      g2 = __builtin_fma(xk[2], yv, g2); g3 = __builtin_fma(xk[3], yv, g3);
-    }
-    if (act) {
-      if (i0 < D) ds[i0 * D + l] = 0.5 * c * g0;
-      if (i0 + 1 < D) ds[(i0 + 1) * D + l] = 0.5 * c * g1;
-      if (i0 + 2 < D) ds[(i0 + 2) * D + l] = 0.5 * c * g2;
-      if (i0 + 3 < D) ds[(i0 + 3) * D + l] = 0.5 * c * g3;
+  {
+    double acc[WaveGemmGeo<NB>::NU];
+    wave_gemm<NB, 1>(S.Gm, S.Lm, LD, acc);       // X^T (diag(q) X)
+#pragma unroll
+    for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
+      int row, col; bool ok;
+      wave_gemm_elem<NB>(u, row, col, ok);
+      if (ok && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[u];
     }
   }
 
@@ -458,11 +533,21 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
     const size_t lds = l96_lds_doubles(a.D) * sizeof(double);
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_energy_l96, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long long nwaves = (long long)a.Np * a.batch;
     if (nwaves > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_energy_l96, dim3((unsigned)nwaves), dim3(64), lds, st, a);
+#define VGPA_L96_CASE(NBV)                                                                                          \
+  case NBV:                                                                                                         \
+    if (lds > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_energy_l96<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k_energy_l96<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);                             \
+    break;
+    switch ((a.D + 3) / 4) {
+      VGPA_L96_CASE(1) VGPA_L96_CASE(2) VGPA_L96_CASE(3) VGPA_L96_CASE(4) VGPA_L96_CASE(5) VGPA_L96_CASE(6)
+      VGPA_L96_CASE(7) VGPA_L96_CASE(8) VGPA_L96_CASE(9) VGPA_L96_CASE(10) VGPA_L96_CASE(11) VGPA_L96_CASE(12)
+      VGPA_L96_CASE(13) VGPA_L96_CASE(14) VGPA_L96_CASE(15) VGPA_L96_CASE(16)
+      default: return hipErrorInvalidValue;
+    }
+#undef VGPA_L96_CASE
   } else {
     return hipErrorInvalidValue;
   }
