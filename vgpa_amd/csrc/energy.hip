@@ -11,6 +11,13 @@
 //         matrix (quirk Q1) is reproduced exactly.
 #include "vgpa_internal.h"
 
+#ifndef VGPA_L96_NOK
+#define VGPA_L96_NOK 0
+#endif
+#ifndef VGPA_L96_NOPANEL
+#define VGPA_L96_NOPANEL 0
+#endif
+
 namespace vgpa {
 namespace {
 
@@ -315,13 +322,30 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   if (pad) { S.mv[l] = 0.0; S.bv[l] = 0.0; S.sg[l] = 0.0; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
   wave_sync();
   {
-    int r = 0, cc = l;
-    while (cc >= D) { cc -= D; r++; }
-    for (int e = l; e < D * D; e += 64) {
-      S.Lm[r * LD + cc] = c * St[e];
-      S.Gm[cc * LD + r] = At[e];                 // A^T: operand layout [k][i] of the MFMA product
-      cc += 64;
-      while (cc >= D) { cc -= D; r++; }
+    // all HBM loads of a chunk are issued before the first one is consumed (a lone wave cannot hide a serial chain
+    // of ~2 us HBM round trips); e / D by multiplication with ceil(2^20 / D), exact for e < 4096, 4 <= D <= 64
+    constexpr int EPL = (Dp * Dp + 63) / 64;
+    const int DD = D * D;
+    const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;
+#pragma unroll
+    for (int q0 = 0; q0 < EPL; q0 += 9) {
+      double sv[9], av[9];
+#pragma unroll
+      for (int u = 0; u < 9; u++) {
+        const int e = l + 64 * (q0 + u);
+        const bool in = (q0 + u < EPL) && (e < DD);
+        sv[u] = in ? St[e] : 0.0;
+        av[u] = in ? At[e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 9; u++) {
+        const int e = l + 64 * (q0 + u);
+        if ((q0 + u < EPL) && (e < DD)) {
+          const int r = (int)(((unsigned)e * magic) >> 20), cc = e - r * D;
+          S.Lm[r * LD + cc] = c * sv[u];
+          S.Gm[cc * LD + r] = av[u];               // A^T: operand layout [k][i] of the MFMA product
+        }
+      }
     }
   }
   if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
@@ -337,14 +361,14 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     const double* p0 = S.Lm + j0 * LD;
     const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
 #pragma unroll 4
-    for (int k = 0; k < j0; k++) {
+    for (int k = 0; k < (VGPA_L96_NOK ? 0 : j0); k++) {
       const double av = rowi[k];
       s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
       s2 = __builtin_fma(-av, p2[k], s2); s3 = __builtin_fma(-av, p3[k], s3);
     }
     double lq[4], sq[4] = {s0, s1, s2, s3};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < (VGPA_L96_NOPANEL ? 0 : 4); q++) {
       const int j = j0 + q;
       double s = sq[q];
 #pragma unroll
@@ -365,6 +389,9 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     return;
   }
 
+#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 1
+  return;
+#endif
   // ---- 2. A.m (lane = row i, A^T rows are contiguous over i) ; G = A.L on the matrix cores, then Gm <- G ([i][r])
   {
     double s = 0.0;
@@ -382,6 +409,9 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   }
   wave_sync();
 
+#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 2
+  return;
+#endif
   // ---- 3. v_p, lane = sigma point.  chi(p, i) = m_i + sgn_p L[i][r_p]  (p = 0: the mean)
   for (int pass = 0; pass < 2; pass++) {
     const int p = pass * 64 + l;
@@ -418,6 +448,9 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   if (l == 0) a.e_t[o] = e_t;
   wave_sync();
 
+#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 3
+  return;
+#endif
   // ---- 4. X = L^-1 into Gm, lane = column c (private), four rows at a time; entries above the diagonal come
   //         out as exact zeros (every term of their sums is zero).
   for (int i0 = 0; i0 < Dp; i0 += 4) {
@@ -446,6 +479,9 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   }
   wave_sync();
 
+#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 4
+  return;
+#endif
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X.  Lm <- diag(q) X (L is no longer needed).
   {
     double s = 0.0;
