@@ -139,6 +139,42 @@ int vgpa_dev_free(vgpa_ctx* ctx, void* ptr);
 int vgpa_memcpy_h2d(vgpa_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int vgpa_memcpy_d2h(vgpa_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 
+/* large-D (D > 64) stage-level entry points on DEVICE pointers --------------------------------------------------
+ * One RK stage of the symmetric recursions = vgpa_ld_gemm (W[I_p,:] = A[I_p,:] X forward, (A^T)[I_p,:] Psi backward;
+ * fp64 MFMA) + vgpa_ld_stage (fused element-wise update of the row block I_p = [row0, row0+Mp) and of the vector
+ * recursion).  They stand behind the same reference code as vgpa_solve_fwd / vgpa_solve_bwd
+ * (src/numerics/{euler,heun,runge_kutta2,runge_kutta4}.py); the host driver vgpa_amd/large_d.py places the RCCL
+ * all-to-all / all-gather of the row-sharded recursion between the two calls.
+ * `stream` is a hipStream_t (NULL = default stream).  C is written in column-chunk packed layout
+ * C[(j / cw) * M * cw + i * cw + (j % cw)] (cw = N: plain row-major). */
+typedef struct {
+  int32_t D, row0, Mp, cw;      /* problem size, first row / number of rows of this rank, chunk width of W */
+  int32_t fwd;                  /* 1: moments (S, m); 0: Lagrange multipliers (Psi, lam) */
+  int32_t kstore;               /* 0 none, 1: K1 = R, 2: K23 = R, 3: K23 += R */
+  int32_t final_mode;           /* 0: out = base +/- cx R; 1: base +/- cf R; 2: +/- cf (K1+R); 3: +/- cf (K1+2 K23+R)/6 */
+  int32_t lda;                  /* leading dimension of A0 / A1 (vector recursion) */
+  double cx, cf;
+  const double* W;              /* [D/cw][Mp][cw] */
+  const double* Wcol;           /* [D][Mp] (== W with one rank) */
+  const double* E0;             /* [Mp][D] Sigma rows (fwd) or dEsde_dS[t] rows (bwd) */
+  const double* E1;             /* NULL, or second operand of the mid-point 0.5*(E1+E0) */
+  const double* J;              /* NULL, or [Mp][D] jump rows added by a final backward stage */
+  const double* base;           /* [Mp][D] */
+  double* K1; double* K23;      /* [Mp][D] */
+  double* out;                  /* [Mp][D] */
+  const double* A0;             /* full A of the stage (vector recursion reads rows row0..row0+Mp) */
+  const double* A1;             /* NULL, or second operand of the mid-point */
+  const double* x;              /* [D] stage vector */
+  const double* e0; const double* e1;   /* [Mp] b (fwd) / dEsde_dm (bwd) entries; e1 NULL or mid-point operand */
+  const double* jv;             /* NULL or [Mp] vector jump */
+  const double* vbase;          /* [Mp] */
+  double* k1v; double* k23v; double* vout;   /* [Mp] */
+} vgpa_ld_stage_args;
+
+int vgpa_ld_gemm(void* stream, int transa, int M, int N, int K, const double* A0, const double* A1_or_null, int lda,
+                 const double* B, int ldb, double* C, int cw);
+int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* args);
+
 /* timing of the stepping kernel on the context's stream (HIP events), for bench.py's roofline */
 int vgpa_profile_begin(vgpa_ctx* ctx);
 int vgpa_profile_end(vgpa_ctx* ctx, double* fwd_ms, double* energy_ms, double* bwd_ms,

@@ -1,0 +1,191 @@
+"""
+Large-D (D > 64) recursions.
+  * GPU (-m gpu): the HIP stage kernels through the C ABI vs the numpy oracle, all four steppers, D in {80, 96, 128, 200}.
+  * CPU: the row-sharding / collective logic of the host driver under gloo (world size 2), with a CPU stand-in for
+    the two stage kernels that restates their contract (tests only -- the package ships only the HIP backend).
+"""
+import os
+import sys
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+from oracle import vgpa_oracle as vo
+
+TOL = 1e-9
+
+
+def make_inputs(d, n, seed=3):
+    rng = np.random.default_rng(seed)
+    a = 2.0 * np.eye(d) + 0.3 * rng.standard_normal((n, d, d)) / np.sqrt(d)
+    b = rng.standard_normal((n, d))
+    m0 = rng.standard_normal(d)
+    q = rng.standard_normal((d, d)) / np.sqrt(d)
+    s0 = 0.2 * np.eye(d) + 0.05 * (q + q.T)
+    sigma = np.diag(1.0 + rng.random(d))
+    g = rng.standard_normal((n, d, d)) / np.sqrt(d)
+    gs = g + np.swapaxes(g, 1, 2)
+    gm = rng.standard_normal((n, d))
+    js, jm = np.zeros((n, d, d)), np.zeros((n, d))
+    for t in range(3, n, 7):
+        js[t] = 0.5 * np.eye(d)
+        jm[t] = rng.standard_normal(d)
+    return a, b, m0, s0, sigma, gm, gs, jm, js
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+@pytest.mark.parametrize("d,n", [(80, 12), (96, 25), (128, 16), (200, 9)])
+def test_large_d_matches_oracle(method, d, n):
+    import vgpa_amd as va
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
+    mt, st = va.FwdOde(0.01, method, False)(a, b, m0, s0, sigma)
+    mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
+    assert rel_err(mt, mt_o) < TOL and rel_err(st, st_o) < TOL
+    lam, psi = va.BwdOde(0.01, method, False)(a, gm, gs, jm, js)
+    lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
+    assert rel_err(lam, lam_o) < TOL and rel_err(psi, psi_o) < TOL
+
+
+@pytest.mark.gpu
+def test_large_d_agrees_with_small_d_kernels_at_the_boundary():
+    """D = 64 runs on the LDS-resident kernels, the per-stage GEMM path must give the same numbers."""
+    import vgpa_amd as va
+    from vgpa_amd.large_d import ShardedRecursion
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(64, 20)
+    mt, st = va.FwdOde(0.01, "rk4", False)(a, b, m0, s0, sigma)
+    rec = ShardedRecursion("rk4", 0.01, 64)
+    mt2, st2 = rec.solve_fwd(a, b, m0, s0, sigma)
+    assert rel_err(mt2.cpu().numpy(), mt) < 1e-12 and rel_err(st2.cpu().numpy(), st) < 1e-12
+    lam, psi = va.BwdOde(0.01, "rk4", False)(a, gm, gs, jm, js)
+    lam2, psi2 = rec.solve_bwd(a, gm, gs, jm, js)
+    assert rel_err(lam2.cpu().numpy(), lam) < 1e-12 and rel_err(psi2.cpu().numpy(), psi) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class CpuStageStandIn:
+    """Restates the contract of vgpa_ld_gemm / vgpa_ld_stage (vgpa_amd/csrc/large_d.hip) with numpy -- tests only."""
+
+    @staticmethod
+    def _v(t, off, count):
+        return t.numpy()[off:off + count]
+
+    def gemm(self, transa, M, N, K, A0, a0_off, A1, a1_off, lda, B, ldb, C, cw):
+        def op(t, off):
+            flat = t.numpy()
+            if transa:      # element (k, i) at off + k*lda + i
+                return np.stack([flat[off + k * lda: off + k * lda + M] for k in range(K)]).T
+            return np.stack([flat[off + i * lda: off + i * lda + K] for i in range(M)])
+        a = op(A0, a0_off)
+        if A1 is not None:
+            a = 0.5 * (a + op(A1, a1_off))
+        b = B.numpy()[:K * ldb].reshape(K, ldb)[:, :N]
+        c = a.dot(b)
+        out = C.numpy()
+        for q in range(N // cw):
+            out[q * M * cw:(q + 1) * M * cw] = c[:, q * cw:(q + 1) * cw].ravel()
+
+    def stage(self, **kw):
+        D, Mp, cw, row0 = kw["D"], kw["Mp"], kw["cw"], kw["row0"]
+        fwd, ks, fin, cx, cf = kw["fwd"], kw["kstore"], kw["final_mode"], kw["cx"], kw["cf"]
+
+        def mat(x, rows=Mp, cols=D):
+            if x is None:
+                return None
+            t, off = x if isinstance(x, tuple) else (x, 0)
+            return t.numpy()[off:off + rows * cols].reshape(rows, cols)
+
+        def vec(x, count=Mp):
+            if x is None:
+                return None
+            t, off = x if isinstance(x, tuple) else (x, 0)
+            return t.numpy()[off:off + count]
+        wp = kw["W"].numpy()[:(D // cw) * Mp * cw].reshape(D // cw, Mp, cw)
+        w = np.concatenate([wp[q] for q in range(D // cw)], axis=1)
+        wcol = kw["Wcol"].numpy()[:D * Mp].reshape(D, Mp) if kw["Wcol"] is not kw["W"] else w
+        e = mat(kw["E0"]) if kw["E1"] is None else 0.5 * (mat(kw["E1"]) + mat(kw["E0"]))
+        r = ((-w - wcol.T) + e) if fwd else ((-e + wcol.T) + w)
+        k1, k23 = mat(kw["K1"]), mat(kw["K23"])
+        sgn = 1.0 if fwd else -1.0
+        base = mat(kw["base"]).copy()
+        jump = mat(kw["J"]) if (fin and kw["J"] is not None) else 0.0
+        k1_old, k23_old = k1.copy(), k23.copy()
+        if ks == 1: k1[:] = r
+        elif ks == 2: k23[:] = r
+        elif ks == 3: k23[:] = k23 + r
+        if fin == 0: res = base + sgn * (cx * r)
+        else:
+            comb = r if fin == 1 else ((k1_old + r) if fin == 2 else (k1_old + 2.0 * k23_old + r) / 6.0)
+            res = base + sgn * (cf * comb) + jump
+        mat(kw["out"])[:] = res
+        # vector recursion
+        a_t, a_off = kw["A0"]
+        arows = a_t.numpy()[a_off + row0 * kw["lda"]: a_off + (row0 + Mp) * kw["lda"]].reshape(Mp, kw["lda"])[:, :D]
+        if kw["A1"] is not None:
+            b_t, b_off = kw["A1"]
+            arows = 0.5 * (arows + b_t.numpy()[b_off + row0 * kw["lda"]: b_off + (row0 + Mp) * kw["lda"]].reshape(Mp, kw["lda"])[:, :D])
+        y = arows.dot(kw["x"].numpy()[:D])
+        ev = vec(kw["e0"]) if kw["e1"] is None else 0.5 * (vec(kw["e1"]) + vec(kw["e0"]))
+        rv = (-y + ev) if fwd else (-ev + y)
+        k1v, k23v = vec(kw["k1v"]), vec(kw["k23v"])
+        k1o, k23o = k1v.copy(), k23v.copy()
+        if ks == 1: k1v[:] = rv
+        elif ks == 2: k23v[:] = rv
+        elif ks == 3: k23v[:] = k23v + rv
+        vb = vec(kw["vbase"]).copy()
+        jv = vec(kw["jv"]) if (fin and kw["jv"] is not None) else 0.0
+        if fin == 0: vres = vb + sgn * (cx * rv)
+        else:
+            comb = rv if fin == 1 else ((k1o + rv) if fin == 2 else (k1o + 2.0 * k23o + rv) / 6.0)
+            vres = vb + sgn * (cf * comb) + jv
+        vec(kw["vout"])[:] = vres
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, method):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from vgpa_amd import parallel as par
+    from vgpa_amd.large_d import ShardedRecursion
+    par.init_from_env("gloo")
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(12, 7)
+    rec = ShardedRecursion(method, 0.01, 12, backend=CpuStageStandIn())
+    assert rec.world == world and rec.Mp == 12 // world
+    mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
+    lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), mt=mt.numpy(), st=st.numpy(), lam=lam.numpy(), psi=psi.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["rk4", "heun", "rk2", "euler"])
+def test_row_sharded_recursion_two_ranks_gloo(tmp_path, method):
+    """world = 2: all_to_all of the packed W chunks + all_gather of the row blocks reproduce the unsharded oracle."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), method), nprocs=2, join=True)
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(12, 7)
+    mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
+    lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
+    for rank in range(2):
+        z = np.load(tmp_path / f"r{rank}.npz")
+        assert rel_err(z["mt"], mt_o) < 1e-12 and rel_err(z["st"], st_o) < 1e-12
+        assert rel_err(z["lam"], lam_o) < 1e-12 and rel_err(z["psi"], psi_o) < 1e-12
+
+
+def test_single_rank_driver_with_standin_matches_oracle():
+    from vgpa_amd.large_d import ShardedRecursion
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(10, 6)
+    for method in ("euler", "heun", "rk2", "rk4"):
+        rec = ShardedRecursion(method, 0.01, 10, backend=CpuStageStandIn())
+        mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
+        mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
+        assert rel_err(mt.numpy(), mt_o) < 1e-12 and rel_err(st.numpy(), st_o) < 1e-12
+        lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
+        lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
+        assert rel_err(lam.numpy(), lam_o) < 1e-12 and rel_err(psi.numpy(), psi_o) < 1e-12

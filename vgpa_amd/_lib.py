@@ -25,9 +25,19 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_obs_energy", "vgpa_free_energy", "vgpa_gradient", "vgpa_sweep", "vgpa_energy_parts",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
-           "vgpa_profile_begin", "vgpa_profile_end"]
+           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage"]
 
 P_DOUBLE = POINTER(c_double)
+
+
+class LdStageArgs(ctypes.Structure):
+    """vgpa_ld_stage_args (include/vgpa_hip.h)."""
+    _fields_ = [("D", c_int32), ("row0", c_int32), ("Mp", c_int32), ("cw", c_int32), ("fwd", c_int32),
+                ("kstore", c_int32), ("final_mode", c_int32), ("lda", c_int32), ("cx", c_double), ("cf", c_double),
+                ("W", c_void_p), ("Wcol", c_void_p), ("E0", c_void_p), ("E1", c_void_p), ("J", c_void_p),
+                ("base", c_void_p), ("K1", c_void_p), ("K23", c_void_p), ("out", c_void_p), ("A0", c_void_p),
+                ("A1", c_void_p), ("x", c_void_p), ("e0", c_void_p), ("e1", c_void_p), ("jv", c_void_p),
+                ("vbase", c_void_p), ("k1v", c_void_p), ("k23v", c_void_p), ("vout", c_void_p)]
 
 
 class VgpaConfig(ctypes.Structure):
@@ -80,6 +90,9 @@ def load():
     lib.vgpa_dev_free.argtypes = [c_void_p, c_void_p]
     lib.vgpa_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
     lib.vgpa_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64]
+    lib.vgpa_ld_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_int]
+    lib.vgpa_ld_stage.argtypes = [c_void_p, POINTER(LdStageArgs)]
     lib.vgpa_profile_begin.argtypes = [c_void_p]
     lib.vgpa_profile_end.argtypes = [c_void_p, P_DOUBLE, P_DOUBLE, P_DOUBLE, P_DOUBLE, POINTER(c_int64)]
     if lib.vgpa_abi_version() != ABI_VERSION:

@@ -1,0 +1,295 @@
+// Large-D time stepping (D > 64): every RK stage is one fp64-MFMA GEMM + one fused element-wise kernel.
+//
+// Same mathematics and stage structure as the LDS-resident kernels (ode_mfma_impl.h): with S / Psi symmetric
+//     forward : f_S   = -(W + W^T) + Sigma,   W  = A S            (src/numerics/ode_solver.py:60)
+//     backward: f_Psi = -G + W' + W'^T,       W' = A^T Psi        (ode_solver.py:94)
+// steppers of src/numerics/{euler,heun,runge_kutta2,runge_kutta4}.py incl. the RK2 quirk (runge_kutta2.py:96) and
+// f_lam = -g + A.lam (ode_solver.py:77).  The stage state lives in HBM / L2 (D = 1024: 8 MB, D = 4096: 134 MB).
+//
+// Row sharding.  A rank owns the row block I_p = [row0, row0 + Mp) of S / Psi and of A (forward) --
+// for the backward product A^T Psi it owns the COLUMN block of A.  Per stage it computes W[I_p, :] with the GEMM,
+// written directly in "column-chunk packed" layout [q][Mp][CW] so that an all-to-all of the chunks delivers
+// Wcol = W[:, I_p] (shape [D][Mp]) without any repacking, then the element-wise kernel forms
+//     R[I_p, :] = -(W[I_p, :] + Wcol^T) + Sigma[I_p, :]
+// and the next stage state's row block, which an all-gather completes.  With one rank CW = D and Wcol = W.
+// The collectives are issued by the host side (vgpa_amd/large_d.py, torch.distributed = RCCL) between the two
+// kernels of a stage; this file only exposes the two kernels through the C ABI (vgpa_ld_*).
+//
+// GEMM: 128 x 64 block tile, BK = 16, 256 threads = 2 x 2 waves of 64 x 32, v_mfma_f64_16x16x4_f64
+// (A lane map i = l & 15, k = l >> 4; B k = l >> 4, j = l & 15; C col = l & 15, row = (l >> 4) + 4 r -- probed,
+// profiles/r01_fp64_mfma_layout_probe.txt), LDS tiles stored k-major with leading dimensions chosen for
+// conflict-free b64 fragment reads, register-prefetched global loads, two LDS buffers, one barrier per k-step.
+#include "vgpa_internal.h"
+
+namespace vgpa {
+namespace ld {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 64, BK = 16, NT = 256;
+constexpr int LDAS = BM + 17;   // 145: conflict-free transposing stores (NN) and near conflict-free fragment reads
+constexpr int LDBS = BN + 16;   // 80 = 16 (mod 32): conflict-free fragment reads
+
+struct GemmArgs {
+  int M, N, K;              // C[M x N] = op(A)[M x K] . B[K x N]
+  const double* A0;         // TRANSA ? [K x M] : [M x K], leading dimension lda
+  const double* A1;         // second operand for the mid-point 0.5*(A0 + A1), or nullptr
+  int lda;
+  const double* B; int ldb;
+  double* C;                // packed by column chunks of width cw: C[(j / cw) * M * cw + i * cw + (j % cw)]
+  int cw;
+};
+
+template <bool TRANSA, bool MID>
+__global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[2][BK * LDAS];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  // global -> register staging maps
+  //  A tile: 128 x 16 = 2048 doubles, 8 per thread.  NN: k = tid & 15 fastest (rows of A are contiguous in k);
+  //          TN: i = tid & 127 fastest (rows of A^T storage are contiguous in i).
+  //  B tile: 16 x 64 = 1024 doubles, 4 per thread, j = tid & 63 fastest.
+  double ra[8], rb[4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      int i, k;
+      if (TRANSA) { i = tid & 127; k = (tid >> 7) + 2 * q; }
+      else { k = tid & 15; i = (tid >> 4) + 16 * q; }
+      const int gi = i0 + i, gk = k0 + k;
+      double v = 0.0;
+      if (gi < g.M && gk < g.K) {
+        const size_t idx = TRANSA ? ((size_t)gk * g.lda + gi) : ((size_t)gi * g.lda + gk);
+        v = MID ? 0.5 * (g.A0[idx] + g.A1[idx]) : g.A0[idx];
+      }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = tid & 63, k = (tid >> 6) + 4 * q;
+      const int gj = j0 + j, gk = k0 + k;
+      rb[q] = (gj < g.N && gk < g.K) ? g.B[(size_t)gk * g.ldb + gj] : 0.0;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      int i, k;
+      if (TRANSA) { i = tid & 127; k = (tid >> 7) + 2 * q; }
+      else { k = tid & 15; i = (tid >> 4) + 16 * q; }
+      As[buf][k * LDAS + i] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = tid & 63, k = (tid >> 6) + 4 * q;
+      Bs[buf][k * LDBS + j] = rb[q];
+    }
+  };
+
+  d4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    const double* as = As[cur] + fk * LDAS + 64 * wm + fi;
+    const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double af[4], bf[2];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) af[mt] = as[kk * 4 * LDAS + 16 * mt];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) bf[nt] = bs[kk * 4 * LDBS + 16 * nt];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+      if (gj >= g.N) continue;
+      const size_t chunk = (size_t)(gj / g.cw) * g.M * g.cw + (gj % g.cw);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + 64 * wm + 16 * mt + (lane >> 4) + 4 * r;
+        if (gi < g.M) g.C[chunk + (size_t)gi * g.cw] = acc[mt][nt][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused element-wise stage kernel on the row block [row0, row0 + Mp) of a D x D symmetric recursion.
+//   R[r][j] = fwd ? (-(W[r][j]) - Wcol[j][r]) + E[r][j]          (E = Sigma)
+//                 : (-E[r][j] + Wcol[j][r]) + W[r][j]            (E = G_stage = dEsde_dS or its mid-point)
+//   K-slot bookkeeping follows the reference's expression order:
+//     kstore 1: K1 = R     2: K23 = R     3: K23 += R
+//     final 0 : Xn = base +/- cx * R                                   (next stage state; + forward, - backward)
+//     final 1 : out = base +/- cf * R                        [+ J]     (Euler, RK2 last stage)
+//     final 2 : out = base +/- cf * (K1 + R)                 [+ J]     (Heun, cf = dt/2)
+//     final 3 : out = base +/- cf * (K1 + 2*K23 + R) / 6     [+ J]     (RK4, cf = dt)
+// The trailing blocks of the grid advance the vector recursion (m forward, lam backward) for this rank's rows:
+//     y_r = sum_k Aeff[r][k] x[k] ;  r_v = fwd ? -y + e : -e + y ;  same slot logic with vector buffers.
+struct StageArgs {
+  int D, row0, Mp, cw, fwd, kstore, final, mid_e, has_j;
+  double cx, cf;
+  const double* W;      // [q][Mp][cw] packed row block of the stage product
+  const double* Wcol;   // [D][Mp]     column block of the stage product (== W when one rank owns everything)
+  const double* E0; const double* E1;   // [Mp rows][D] (row block): Sigma, or G_t / G_{t-1} (mid: 0.5*(E0+E1))
+  const double* J;      // [Mp][D] jump added at the end of a backward step (or nullptr)
+  const double* base;   // [Mp][D] S_k / Psi_t row block
+  double* K1; double* K23;   // [Mp][D]
+  double* out;          // [Mp][D]: next stage state row block, or the new S / Psi row block
+  // vector part
+  const double* A0; const double* A1; int lda, mid_a;   // rows [row0, row0+Mp) of the stage's A (full D columns)
+  const double* x;      // [D] stage vector (full)
+  const double* e0; const double* e1; int mid_ev;        // [Mp] b or dEsde_dm entries of this rank's rows
+  const double* jv;     // [Mp] vector jump or nullptr
+  const double* vbase;  // [Mp]
+  double* k1v; double* k23v; double* vout;   // [Mp]
+};
+
+constexpr int TS = 32;
+
+__device__ __forceinline__ double stage_combine(double r, double base, double k1, double k23, int fin, double cx,
+                                                double cf, double sgn, double jump) {
+  if (fin == 0) return base + sgn * (cx * r);
+  double comb = r;
+  if (fin == 2) comb = k1 + r;
+  if (fin == 3) comb = (k1 + 2.0 * k23 + r) / 6.0;
+  return base + sgn * (cf * comb) + jump;
+}
+
+__global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
+  __shared__ double tile[TS][TS + 1];
+  const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
+  const int nmat = ntx * nty;
+  const double sgn = a.fwd ? 1.0 : -1.0;
+  if ((int)blockIdx.x < nmat) {
+    const int by = blockIdx.x / ntx, bx = blockIdx.x - by * ntx;   // tile of R: rows by (local), cols bx (global)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
+    // transposed operand: Wcol[j][r] for j in the column tile, r in the row tile -> read rows j, cols r (coalesced)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int jj = ty + 8 * q;
+      const int j = bx * TS + jj, r = by * TS + tx;
+      tile[jj][tx] = (j < a.D && r < a.Mp) ? a.Wcol[(size_t)j * a.Mp + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int rr = ty + 8 * q;
+      const int r = by * TS + rr, j = bx * TS + tx;
+      if (r < a.Mp && j < a.D) {
+        const size_t o = (size_t)r * a.D + j;
+        const double w = a.W[(size_t)(j / a.cw) * a.Mp * a.cw + (size_t)r * a.cw + (j % a.cw)];
+        const double wt = tile[tx][rr];
+        const double e = a.mid_e ? 0.5 * (a.E1[o] + a.E0[o]) : a.E0[o];
+        const double rv = a.fwd ? ((-w - wt) + e) : ((-e + wt) + w);
+        const double k1 = (a.final >= 2) ? a.K1[o] : 0.0;
+        const double k23 = (a.final == 3) ? a.K23[o] : 0.0;
+        if (a.kstore == 1) a.K1[o] = rv;
+        else if (a.kstore == 2) a.K23[o] = rv;
+        else if (a.kstore == 3) a.K23[o] = a.K23[o] + rv;
+        const double jump = (a.final && a.has_j) ? a.J[o] : 0.0;
+        a.out[o] = stage_combine(rv, a.base[o], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+      }
+    }
+    return;
+  }
+  // ---- vector recursion: one wave per row
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = ((int)blockIdx.x - nmat) * (NT / 64) + wave;
+  if (r >= a.Mp) return;
+  const size_t ro = (size_t)(a.row0 + r) * a.lda;
+  double s = 0.0;
+  for (int k = lane; k < a.D; k += 64) {
+    const double av = a.mid_a ? 0.5 * (a.A0[ro + k] + a.A1[ro + k]) : a.A0[ro + k];
+    s = __builtin_fma(av, a.x[k], s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const double e = a.mid_ev ? 0.5 * (a.e1[r] + a.e0[r]) : a.e0[r];
+    const double rv = a.fwd ? (-s + e) : (-e + s);
+    const double k1 = (a.final >= 2) ? a.k1v[r] : 0.0;
+    const double k23 = (a.final == 3) ? a.k23v[r] : 0.0;
+    if (a.kstore == 1) a.k1v[r] = rv;
+    else if (a.kstore == 2) a.k23v[r] = rv;
+    else if (a.kstore == 3) a.k23v[r] = a.k23v[r] + rv;
+    const double jump = (a.final && a.jv) ? a.jv[r] : 0.0;
+    a.vout[r] = stage_combine(rv, a.vbase[r], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+  }
+}
+
+hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+  const bool mid = g.A1 != nullptr;
+  if (transa) {
+    if (mid) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(NT), 0, st, g);
+  } else {
+    if (mid) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(NT), 0, st, g);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
+  const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
+  const int nvec = (a.Mp + (NT / 64) - 1) / (NT / 64);
+  hipLaunchKernelGGL(k_stage, dim3(ntx * nty + nvec), dim3(NT), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace ld
+}  // namespace vgpa
+
+// =================================================================================================================
+//  C ABI (declared in include/vgpa_hip.h): stage-level entry points on DEVICE pointers, used by the host driver
+//  vgpa_amd/large_d.py which interleaves them with the RCCL collectives of the row-sharded recursion.
+// =================================================================================================================
+using namespace vgpa;
+
+extern "C" {
+
+int vgpa_ld_gemm(void* stream, int transa, int M, int N, int K, const double* A0, const double* A1, int lda,
+                 const double* B, int ldb, double* C, int cw) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A0 || !B || !C || cw <= 0 || (N % cw) != 0) return VGPA_ERR_ARG;
+  ld::GemmArgs g{M, N, K, A0, A1, lda, B, ldb, C, cw};
+  return ld::launch_gemm(transa != 0, g, (hipStream_t)stream) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* p) {
+  if (!p || p->D <= 0 || p->Mp <= 0 || p->cw <= 0) return VGPA_ERR_ARG;
+  ld::StageArgs a{};
+  a.D = p->D; a.row0 = p->row0; a.Mp = p->Mp; a.cw = p->cw; a.fwd = p->fwd; a.kstore = p->kstore; a.final = p->final_mode;
+  a.mid_e = p->E1 != nullptr; a.has_j = p->J != nullptr; a.cx = p->cx; a.cf = p->cf;
+  a.W = p->W; a.Wcol = p->Wcol; a.E0 = p->E0; a.E1 = p->E1; a.J = p->J; a.base = p->base; a.K1 = p->K1; a.K23 = p->K23;
+  a.out = p->out; a.A0 = p->A0; a.A1 = p->A1; a.lda = p->lda; a.mid_a = p->A1 != nullptr; a.x = p->x;
+  a.e0 = p->e0; a.e1 = p->e1; a.mid_ev = p->e1 != nullptr; a.jv = p->jv; a.vbase = p->vbase;
+  a.k1v = p->k1v; a.k23v = p->k23v; a.vout = p->vout;
+  return ld::launch_stage(a, (hipStream_t)stream) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+}  // extern "C"

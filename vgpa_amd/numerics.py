@@ -13,6 +13,8 @@ import numpy as np
 
 from ._lib import Context
 
+SMALL_D_MAX = 64      # D <= 64: one-workgroup LDS-resident kernels; above: per-stage GEMM path
+
 
 class OdeSolver(object):
     """Parent of the four steppers (src/numerics/ode_solver.py:4-29)."""
@@ -28,6 +30,17 @@ class OdeSolver(object):
         self._ctx = {}
         self.device = 0
         self.flags = 0
+
+    def _large(self, dim_d):
+        """D > 64: per-stage fp64 GEMM path (vgpa_amd/large_d.py), one GPU or the default process group."""
+        from .large_d import ShardedRecursion
+        key = ("large", dim_d)
+        rec = self._ctx.get(key)
+        if rec is None:
+            self._ctx.clear()
+            rec = ShardedRecursion(self.method, self.dt, dim_d)
+            self._ctx[key] = rec
+        return rec
 
     def _context(self, dim_d, n_pts):
         key = (dim_d, n_pts, self.device, self.flags)
@@ -50,6 +63,9 @@ class OdeSolver(object):
                                    np.array([sigma], dtype=float))
             return mt.reshape(n), st.reshape(n)
         n, d = off_b.shape
+        if d > SMALL_D_MAX:
+            mt, st = self._large(d).solve_fwd(lin_a, off_b, m0, s0, sigma)
+            return mt.cpu().numpy(), st.cpu().numpy()
         ctx = self._context(d, n)
         return ctx.solve_fwd(lin_a, off_b, m0, s0, sigma)
 
@@ -64,6 +80,9 @@ class OdeSolver(object):
             lam, psi = ctx.solve_bwd(r3(lin_a), r2(dEsde_dm), r3(dEsde_ds), r2(dEobs_dm), r3(dEobs_ds))
             return lam.reshape(n), psi.reshape(n)
         n, d = dEsde_dm.shape
+        if d > SMALL_D_MAX:
+            lam, psi = self._large(d).solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
+            return lam.cpu().numpy(), psi.cpu().numpy()
         ctx = self._context(d, n)
         return ctx.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
 
