@@ -26,8 +26,7 @@ namespace ld {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 64, BK = 16, NT = 256;
-constexpr int LDAS = BM + 17;   // 145: conflict-free transposing stores (NN) and near conflict-free fragment reads
+constexpr int BN = 64, BK = 16, NT = 256;   // block tile BM x 64 (BM = 128, or 64 when 128 would not fill the chip)
 constexpr int LDBS = BN + 16;   // 80 = 16 (mod 32): conflict-free fragment reads
 
 struct GemmArgs {
@@ -40,8 +39,11 @@ struct GemmArgs {
   int cw;
 };
 
-template <bool TRANSA, bool MID>
+template <bool TRANSA, bool MID, int BM>
 __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
+  constexpr int LDAS = BM + 17;   // odd: conflict-free transposing stores (NN), near conflict-free fragment reads
+  constexpr int MT = BM / 32;     // 16-row MFMA tiles per wave along M (wave tile = (BM/2) x 32)
+  constexpr int AQ = BM * BK / NT;
   __shared__ __attribute__((aligned(16))) double As[2][BK * LDAS];
   __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,12 +55,12 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
   //  A tile: 128 x 16 = 2048 doubles, 8 per thread.  NN: k = tid & 15 fastest (rows of A are contiguous in k);
   //          TN: i = tid & 127 fastest (rows of A^T storage are contiguous in i).
   //  B tile: 16 x 64 = 1024 doubles, 4 per thread, j = tid & 63 fastest.
-  double ra[8], rb[4];
+  double ra[AQ], rb[4];
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < AQ; q++) {
       int i, k;
-      if (TRANSA) { i = tid & 127; k = (tid >> 7) + 2 * q; }
+      if (TRANSA) { i = tid & (BM - 1); k = (tid / BM) + (NT / BM) * q; }
       else { k = tid & 15; i = (tid >> 4) + 16 * q; }
       const int gi = i0 + i, gk = k0 + k;
       double v = 0.0;
@@ -77,9 +79,9 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < AQ; q++) {
       int i, k;
-      if (TRANSA) { i = tid & 127; k = (tid >> 7) + 2 * q; }
+      if (TRANSA) { i = tid & (BM - 1); k = (tid / BM) + (NT / BM) * q; }
       else { k = tid & 15; i = (tid >> 4) + 16 * q; }
       As[buf][k * LDAS + i] = ra[q];
     }
@@ -90,9 +92,9 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     }
   };
 
-  d4 acc[4][2];
+  d4 acc[MT][2];
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
@@ -103,17 +105,17 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-    const double* as = As[cur] + fk * LDAS + 64 * wm + fi;
+    const double* as = As[cur] + fk * LDAS + (BM / 2) * wm + fi;
     const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
-      double af[4], bf[2];
+      double af[MT], bf[2];
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) af[mt] = as[kk * 4 * LDAS + 16 * mt];
+      for (int mt = 0; mt < MT; mt++) af[mt] = as[kk * 4 * LDAS + 16 * mt];
 #pragma unroll
       for (int nt = 0; nt < 2; nt++) bf[nt] = bs[kk * 4 * LDBS + 16 * nt];
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
           acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
 
   // epilogue: C col = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
       const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
       const size_t chunk = (size_t)(gj / g.cw) * g.M * g.cw + (gj % g.cw);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int gi = i0 + 64 * wm + 16 * mt + (lane >> 4) + 4 * r;
+        const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
         if (gi < g.M) g.C[chunk + (size_t)gi * g.cw] = acc[mt][nt][r];
       }
     }
@@ -242,16 +244,24 @@ __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
   }
 }
 
-hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
+template <int BM>
+static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
   const bool mid = g.A1 != nullptr;
   if (transa) {
-    if (mid) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(NT), 0, st, g);
+    if (mid) hipLaunchKernelGGL((k_gemm<true, true, BM>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<true, false, BM>), grid, dim3(NT), 0, st, g);
   } else {
-    if (mid) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(NT), 0, st, g);
+    if (mid) hipLaunchKernelGGL((k_gemm<false, true, BM>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<false, false, BM>), grid, dim3(NT), 0, st, g);
   }
+}
+
+hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
+  // 128-row tiles reuse B twice as much; fall back to 64-row tiles when they would leave CUs without a workgroup
+  const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128);
+  if (wg128 >= 2 * 256) launch_gemm_bm<128>(transa, g, st);
+  else launch_gemm_bm<64>(transa, g, st);
   return hipGetLastError();
 }
 
@@ -261,6 +271,131 @@ hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_stage, dim3(ntx * nty + nvec), dim3(NT), 0, st, a);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Single-rank drivers (one GPU owns every row): the per-step / per-stage loop of the four steppers, all launches on
+// one stream.  `ws` is a workspace of at least ld_workspace_doubles(D) doubles.
+size_t ld_workspace_doubles(int D) { return (size_t)5 * D * D + 4 * (size_t)D; }
+
+namespace {
+struct Work {
+  double *W, *K1, *K23, *XA, *XB, *xvA, *xvB, *k1v, *k23v;
+};
+Work carve_work(double* ws, int D) {
+  const size_t DD = (size_t)D * D;
+  Work w;
+  w.W = ws; w.K1 = w.W + DD; w.K23 = w.K1 + DD; w.XA = w.K23 + DD; w.XB = w.XA + DD;
+  w.xvA = w.XB + DD; w.xvB = w.xvA + D; w.k1v = w.xvB + D; w.k23v = w.k1v + D;
+  return w;
+}
+
+struct StageSpec {
+  bool fwd;
+  const double *Am0, *Am1;   // A operand of the matrix product (Am1: mid-point partner or nullptr)
+  const double *Av0, *Av1;   // A of the vector recursion
+  const double* X; const double* xv;
+  const double *E0, *E1; const double *e0, *e1;
+  const double* J; const double* jv;
+  const double* base; const double* vbase;
+  double* out; double* vout;
+  int kstore, final_mode; double cx, cf;
+};
+
+hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st) {
+  GemmArgs g{D, D, D, s.Am0, s.Am1, D, s.X, D, w.W, D};
+  hipError_t e = launch_gemm(!s.fwd, g, st);
+  if (e != hipSuccess) return e;
+  StageArgs a{};
+  a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
+  a.W = w.W; a.Wcol = w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
+  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
+  a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr; a.jv = s.jv; a.vbase = s.vbase;
+  a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout;
+  return launch_stage(a, st);
+}
+}  // namespace
+
+#define LD_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, const double* b, const double* m0,
+                        const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st) {
+  const size_t DD = (size_t)D * D;
+  const Work w = carve_work(ws, D);
+  const double h = 0.5 * dt;
+  LD_TRY(hipMemcpyAsync(S, S0, DD * sizeof(double), hipMemcpyDeviceToDevice, st));
+  LD_TRY(hipMemcpyAsync(m, m0, D * sizeof(double), hipMemcpyDeviceToDevice, st));
+  for (int k = 0; k < Np - 1; k++) {
+    const double *Ak = A + k * DD, *Ak1 = Ak + DD, *bk = b + (size_t)k * D, *bk1 = bk + D;
+    const double *Sk = S + k * DD, *mk = m + (size_t)k * D;
+    double *Sn = S + (k + 1) * DD, *mn = m + (size_t)(k + 1) * D;
+    StageSpec s{};
+    s.fwd = true; s.E0 = Sigma; s.base = Sk; s.vbase = mk;
+    auto set = [&](const double* am0, const double* am1, const double* av0, const double* av1, const double* X,
+                   const double* xv, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
+                   double cx, double cf) {
+      s.Am0 = am0; s.Am1 = am1; s.Av0 = av0; s.Av1 = av1; s.X = X; s.xv = xv; s.e0 = e0; s.e1 = e1; s.out = out;
+      s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
+    };
+    if (method == VGPA_ODE_EULER) {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+    } else if (method == VGPA_ODE_HEUN) {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(run_stage(D, w, s, st));
+    } else if (method == VGPA_ODE_RK2) {
+      // covariance predictor: S_k stands in for A_k (reference quirk, runge_kutta2.py:96); mean predictor: A_k
+      set(Sk, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+    } else {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, Ak1, Ak, Ak1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+    }
+  }
+  return hipSuccess;
+}
+
+hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
+                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st) {
+  const size_t DD = (size_t)D * D;
+  const Work w = carve_work(ws, D);
+  const double h = 0.5 * dt;
+  LD_TRY(hipMemsetAsync(psi + (size_t)(Np - 1) * DD, 0, DD * sizeof(double), st));
+  LD_TRY(hipMemsetAsync(lam + (size_t)(Np - 1) * D, 0, D * sizeof(double), st));
+  for (int t = Np - 1; t > 0; t--) {
+    const double *At = A + t * DD, *Am = At - DD, *Gt = gs + t * DD, *Gm = Gt - DD;
+    const double *gt = gm + (size_t)t * D, *gmm = gt - D;
+    const double *Pt = psi + t * DD, *lt = lam + (size_t)t * D;
+    double *Pn = psi + (t - 1) * DD, *ln = lam + (size_t)(t - 1) * D;
+    const double *Jn = js + (t - 1) * DD, *jn = jm + (size_t)(t - 1) * D;
+    StageSpec s{};
+    s.fwd = false; s.base = Pt; s.vbase = lt;
+    auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
+                   const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
+                   double cx, double cf, bool jump) {
+      s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
+      s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
+      s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
+    };
+    if (method == VGPA_ODE_EULER) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    } else if (method == VGPA_ODE_HEUN) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(run_stage(D, w, s, st));
+    } else if (method == VGPA_ODE_RK2) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    } else {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+      set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    }
+  }
+  return hipSuccess;
+}
+#undef LD_TRY
 
 }  // namespace ld
 }  // namespace vgpa

@@ -31,6 +31,7 @@ struct vgpa_ctx {
   double *d_m0 = nullptr, *d_S0 = nullptr, *d_Sigma = nullptr, *d_isig = nullptr, *d_isg = nullptr;
   double *d_obs_y = nullptr, *d_Q = nullptr, *d_K = nullptr, *d_rinv = nullptr, *d_jsc = nullptr;
   double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
+  double* d_ld_ws = nullptr;      // workspace of the large-D drivers
   int64_t* d_obs_t = nullptr;
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
@@ -142,7 +143,21 @@ static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
   return sym && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && ode_mfma_supported(c->cfg.method, fwd, c->D);
 }
 
+static int ensure_ld_ws(vgpa_ctx* c) {
+  if (c->d_ld_ws) return VGPA_OK;
+  return dev_alloc(c, &c->d_ld_ws, ld::ld_workspace_doubles(c->D));
+}
+
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
+  if (c->D > kMaxSmallD) {
+    if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric s0 and sigma");
+    int rc = ensure_ld_ws(c);
+    if (rc) return rc;
+    hipError_t e = ld::ld_solve_fwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), ctx_b(c), m0, S0, Sigma, c->d_m, c->d_S,
+                                    c->d_ld_ws, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D forward sweep failed: %s", hipGetErrorString(e));
+    return VGPA_OK;
+  }
   OdeArgs a{};
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
@@ -155,6 +170,15 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
 }
 
 static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
+  if (c->D > kMaxSmallD) {
+    if (!sym || !dense_jumps) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric dEsde_ds / dEobs_ds (dense jumps)");
+    int rc = ensure_ld_ws(c);
+    if (rc) return rc;
+    hipError_t e = ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm_dense,
+                                    c->d_js_dense, c->d_lam, c->d_psi, c->d_ld_ws, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D backward sweep failed: %s", hipGetErrorString(e));
+    return VGPA_OK;
+  }
   OdeArgs a{};
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
@@ -284,7 +308,10 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   if (single && cfg->dim_d != 1) return fail(nullptr, VGPA_ERR_ARG, "1-D model with D=%d", cfg->dim_d);
   if (cfg->model == VGPA_MODEL_L63 && cfg->dim_d != 3) return fail(nullptr, VGPA_ERR_ARG, "Lorenz-63 needs D=3, got %d", cfg->dim_d);
   if (cfg->model == VGPA_MODEL_L96 && cfg->dim_d < 4) return fail(nullptr, VGPA_ERR_ARG, "Insufficient state vector dimensions: %d", cfg->dim_d);
-  if (cfg->dim_d > kMaxSmallD) return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d: the large-D (multi-workgroup GEMM) path is not built yet", cfg->dim_d, kMaxSmallD);
+  if (cfg->dim_d > kMaxSmallD && cfg->model != VGPA_MODEL_NONE)
+    return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d: only the ODE operators (vgpa_solve_fwd / vgpa_solve_bwd, model NONE) are built "
+                "for large D; the energy terms of the fused sweep are not yet", cfg->dim_d, kMaxSmallD);
+  if (cfg->dim_d > kMaxSmallD && cfg->batch != 1) return fail(nullptr, VGPA_ERR_UNSUPPORTED, "large-D contexts hold one problem");
   const int need_theta = (cfg->model == VGPA_MODEL_L63) ? 3 : (cfg->model == VGPA_MODEL_NONE ? 0 : 1);
   if (cfg->n_theta != need_theta || (need_theta > 0 && !cfg->theta)) return fail(nullptr, VGPA_ERR_ARG, "model needs %d drift parameter(s)", need_theta);
   if (!cfg->sigma) return fail(nullptr, VGPA_ERR_ARG, "sigma is required");
@@ -315,6 +342,8 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   if (single) {
     if (!(sigma[0] > 0.0)) { fail(nullptr, VGPA_ERR_ARG, "The diffusion noise value: %g, should be strictly positive.", sigma[0]); vgpa_destroy(c); return VGPA_ERR_ARG; }
     c->sigma1 = sigma[0]; isig[0] = 1.0 / sigma[0]; isg[0] = isig[0];
+  } else if (cfg->model == VGPA_MODEL_NONE) {
+    for (int i = 0; i < D; i++) { isig[(size_t)i * D + i] = 1.0; isg[i] = 1.0; }   // ODE-only: Sigma^-1 is not used
   } else {
     if (!host_spd_inverse(D, sigma.data(), isig.data(), nullptr)) { fail(nullptr, VGPA_ERR_NOT_PD, "Noise matrix is not positive definite."); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
     for (int i = 0; i < D; i++) isg[i] = isig[(size_t)i * D + i];

@@ -107,6 +107,15 @@ hipError_t launch_grad(const GradArgs& a, hipStream_t st);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
 hipError_t launch_edf(const EnergyArgs& a, hipStream_t st);   // dense <df/dx> on request
 
+// large-D (per-stage GEMM) single-rank drivers, large_d.hip
+namespace ld {
+size_t ld_workspace_doubles(int D);
+hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, const double* b, const double* m0,
+                        const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st);
+hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
+                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st);
+}  // namespace ld
+
 // tiny host-side dense helpers (row-major, fp64) ---------------------------------------------------
 bool host_cholesky_lower(int n, const double* a, double* l);          // uses the lower triangle of a
 void host_lower_inverse(int n, const double* l, double* linv);

@@ -31,6 +31,15 @@ class OdeSolver(object):
         self.device = 0
         self.flags = 0
 
+    @staticmethod
+    def _sharded():
+        """True when a torch.distributed process group with more than one rank is active (row-sharded large-D path)."""
+        import sys
+        if "torch" not in sys.modules:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
     def _large(self, dim_d):
         """D > 64: per-stage fp64 GEMM path (vgpa_amd/large_d.py), one GPU or the default process group."""
         from .large_d import ShardedRecursion
@@ -63,7 +72,7 @@ class OdeSolver(object):
                                    np.array([sigma], dtype=float))
             return mt.reshape(n), st.reshape(n)
         n, d = off_b.shape
-        if d > SMALL_D_MAX:
+        if d > SMALL_D_MAX and self._sharded():
             mt, st = self._large(d).solve_fwd(lin_a, off_b, m0, s0, sigma)
             return mt.cpu().numpy(), st.cpu().numpy()
         ctx = self._context(d, n)
@@ -80,7 +89,7 @@ class OdeSolver(object):
             lam, psi = ctx.solve_bwd(r3(lin_a), r2(dEsde_dm), r3(dEsde_ds), r2(dEobs_dm), r3(dEobs_ds))
             return lam.reshape(n), psi.reshape(n)
         n, d = dEsde_dm.shape
-        if d > SMALL_D_MAX:
+        if d > SMALL_D_MAX and self._sharded():
             lam, psi = self._large(d).solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
             return lam.cpu().numpy(), psi.cpu().numpy()
         ctx = self._context(d, n)
