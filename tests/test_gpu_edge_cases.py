@@ -1,0 +1,133 @@
+"""
+GPU suite (-m gpu): edge cases of the hot path through the C ABI, all against the numpy oracle (lean mode).
+  * every block geometry of the MFMA steppers and of the wave-level energy kernel: D = 10 ... 64
+  * dense (non-diagonal) system noise Sigma, dense observation noise R, non-identity observation operator H
+  * shortest grids (Np = 2, 3), a single observation, observations at the first / last index
+  * odd batches, the experimental paired-problem variant, very small dt
+"""
+import numpy as np
+import pytest
+
+import vgpa_amd as va
+from vgpa_amd._lib import FLAG_FORCE_GENERIC
+from conftest import rel_err
+from oracle import vgpa_oracle as vo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+FLAG_PAIR = 2
+
+
+def spd(rng, d, scale=1.0, jitter=0.3):
+    q = rng.standard_normal((d, d)) / np.sqrt(d)
+    return scale * (np.eye(d) + jitter * (q + q.T) / 2.0 + jitter * q.dot(q.T))
+
+
+def make_problem(model, d, n_pts, method="rk4", dt=0.01, seed=5, dense=False, obs_at=None, h_op=None):
+    rng = np.random.default_rng(seed)
+    single = model in ("OU", "DW")
+    if single:
+        theta, sigma = 1.0, 0.8
+        m0, s0, mu0, tau0 = 0.3, 0.2, 1.0, 0.5
+        r = 0.04
+    else:
+        theta = np.array([10.0, 28.0, 2.667]) if model == "L63" else 8.0
+        sigma = spd(rng, d, 4.0) if dense else np.diag(3.0 + rng.random(d))
+        m0 = (8.0 if model == "L96" else 1.0) + rng.standard_normal(d)
+        s0 = spd(rng, d, 0.2, 0.1) if dense else 0.2 * np.eye(d)
+        mu0, tau0 = np.ones(d), 0.5 * np.eye(d)
+        r = spd(rng, d, 1.0, 0.2) if dense else np.eye(d)
+    obs_t = np.array(obs_at if obs_at is not None else sorted(set(range(2, n_pts - 1, 5))), dtype=np.int64)
+    obs_y = rng.standard_normal(obs_t.size) if single else 8.0 + rng.standard_normal((obs_t.size, d))
+    p = vo.Problem(model=model, method=method, dt=dt, theta=theta, sigma=sigma, m0=m0, s0=s0, mu0=mu0, tau0=tau0,
+                   obs_t=obs_t, obs_y=obs_y, obs_noise=r, n_pts=n_pts, dim_d=1 if single else d, obs_h=h_op)
+    if single:
+        a = 1.6 + 0.05 * rng.standard_normal(n_pts)
+        b = rng.standard_normal(n_pts)
+        x = np.concatenate((a, b))
+    else:
+        a = (8.0 if model == "L96" else 20.0) * np.eye(d) + 0.05 * rng.standard_normal((n_pts, d, d))
+        b = 8.0 * m0 + rng.standard_normal((n_pts, d))
+        x = np.concatenate((a.ravel(), b.ravel()))
+    return p, x
+
+
+def gpu_context(p, batch=1, flags=0):
+    d = p.dim_d
+    sig = np.array([[p.sigma]]) if p.single_dim else p.sigma
+    return va.Context(p.model, p.method, d, p.n_pts, p.dt, sigma=sig, theta=np.atleast_1d(p.theta),
+                      m0=np.atleast_1d(p.m0), s0=np.asarray(p.s0, dtype=float).reshape(d, d), obs_t=p.obs_t,
+                      obs_y=p.obs_y, obs_noise=np.asarray(p.obs_noise, dtype=float).reshape(d, d),
+                      obs_h=None if p.obs_h is None else np.asarray(p.obs_h, dtype=float).reshape(d, d),
+                      e0=float(np.asarray(vo.kl0(p))), batch=batch, flags=flags)
+
+
+def check(p, x, flags=0, tol=TOL):
+    ctx = gpu_context(p, flags=flags)
+    f, g = ctx.sweep(x)
+    f_ref, g_ref, st = vo.sweep(p, x, faithful=False)
+    assert abs(f - f_ref) <= tol * abs(f_ref), (f, f_ref)
+    assert rel_err(g, g_ref) < tol
+    for key in ("mt", "st", "lamt", "psit"):
+        got = ctx.fetch(key)
+        want = st[key]
+        assert rel_err(np.asarray(got).reshape(np.shape(want)), want) < tol, key
+    ctx.close()
+
+
+@pytest.mark.parametrize("d", [10, 11, 13, 16, 20, 21, 24, 28, 32, 33, 36, 44, 45, 52, 64])
+@pytest.mark.parametrize("method", ["rk4", "heun"])
+def test_every_block_geometry(d, method):
+    n = 14 if d <= 44 else 8
+    p, x = make_problem("L96", d, n, method=method)
+    check(p, x)
+
+
+@pytest.mark.parametrize("model,d", [("L96", 12), ("L96", 40), ("L63", 3)])
+def test_dense_noise_matrices_and_observation_operator(model, d):
+    rng = np.random.default_rng(11)
+    h = np.eye(d) + 0.1 * rng.standard_normal((d, d))
+    p, x = make_problem(model, d, 25, dense=True, h_op=h)
+    check(p, x)                                   # dense Sigma, S0, R, H: symmetric inputs -> MFMA steppers
+    check(p, x, flags=FLAG_FORCE_GENERIC)
+
+
+@pytest.mark.parametrize("n_pts,obs", [(2, [0]), (3, [1]), (6, [0, 4]), (12, [10])])
+@pytest.mark.parametrize("model,d", [("OU", 1), ("L63", 3), ("L96", 12)])
+def test_shortest_grids_and_boundary_observations(model, d, n_pts, obs):
+    p, x = make_problem(model, d, n_pts, obs_at=obs)
+    check(p, x)
+
+
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_all_steppers_double_well_and_small_dt(method):
+    p, x = make_problem("DW", 1, 40, method=method, dt=1e-4)
+    check(p, x)
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_PAIR])
+def test_odd_batches(flags):
+    p, x = make_problem("L96", 12, 20)
+    ctx = gpu_context(p, batch=5, flags=flags)
+    rng = np.random.default_rng(1)
+    xb = np.stack([x + 0.01 * rng.standard_normal(x.size) for _ in range(5)])
+    fb, gb = ctx.sweep(xb)
+    for i in range(5):
+        f_ref, g_ref, _ = vo.sweep(p, xb[i], faithful=False)
+        assert abs(fb[i] - f_ref) <= TOL * abs(f_ref)
+        assert rel_err(gb[i], g_ref) < TOL
+
+
+def test_state_errors():
+    p, x = make_problem("L63", 3, 10)
+    ctx = gpu_context(p)
+    with pytest.raises(RuntimeError):
+        ctx.gradient(None)                         # gradient(x, eval_fun=False) before any free_energy
+    with pytest.raises(ValueError):
+        ctx.free_energy(x[:-1])
+    with pytest.raises(ValueError):
+        va.Context("L63", "rk4", 3, 10, 0.01, sigma=np.eye(3), theta=[1.0])     # L63 needs 3 drift parameters
+    with pytest.raises(ValueError):
+        va.Context("L96", "rk4", 12, 10, -0.01, sigma=np.eye(12), theta=[8.0])
+    with pytest.raises(NotImplementedError):
+        va.Context("L96", "rk4", 128, 10, 0.01, sigma=np.eye(128), theta=[8.0])  # fused sweep at D > 64: not yet

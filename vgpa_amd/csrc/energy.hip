@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64) k_energy_l63(EnergyArgs a) {
 //    1. Cholesky, left-looking by columns            lane = row i        (cross-lane: pivot row reads, wave_sync)
 //    2. A.m and G = A.L in place on A (ascending r)  lane = row i        (lane-private rows)
 //    3. v_p = sum_i isg_i (l96_flat(chi)_pi + (A chi_p)_i - b_i)^2
-//                                                    lane = SIGMA POINT p (two passes: p < 64, p >= 64); the sum
+//                                                    lane = SIGMA POINT p (ceil(M/64) passes); the sum
 //       over i runs sequentially inside the lane with a sliding window over chi(p, i-2..i+1): no reduction.
 //       The flat np.roll of the reference (quirk Q1) makes row p's neighbours at the row ends come from rows p-1, p+1.
 //    4. L^-1 by forward substitution                 lane = column c     (lane-private columns)
@@ -373,12 +373,22 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       double s = sq[q];
 #pragma unroll
       for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
+#if defined(VGPA_L96_FAKE_LANE)
+      const double piv = s + 1.0;
+#else
       const double piv = lane_value(s, j);
+#endif
       if (!(piv > 0.0)) bad = true;
+#if defined(VGPA_L96_FAKE_RSQ)
+      const double rdv = piv * 0.1, d = piv * rdv;
+#else
       const double rdv = rsqrt(piv), d = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
+#endif
       lq[q] = (l > j) ? s * rdv : 0.0;
+#if !defined(VGPA_L96_NO_LWRITE)
       if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
       if (l == j) S.rd[j] = rdv;
+#endif
     }
     wave_sync();
   }
@@ -413,7 +423,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   return;
 #endif
   // ---- 3. v_p, lane = sigma point.  chi(p, i) = m_i + sgn_p L[i][r_p]  (p = 0: the mean)
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass * 64 < M; pass++) {
     const int p = pass * 64 + l;
     const bool pact = p < M;
     const int pc = pact ? p : 0;
