@@ -130,4 +130,4 @@ def test_state_errors():
     with pytest.raises(ValueError):
         va.Context("L96", "rk4", 12, 10, -0.01, sigma=np.eye(12), theta=[8.0])
     with pytest.raises(NotImplementedError):
-        va.Context("L96", "rk4", 128, 10, 0.01, sigma=np.eye(128), theta=[8.0])  # fused sweep at D > 64: not yet
+        va.Context("L63", "rk4", 128, 10, 0.01, sigma=np.eye(128), theta=[1.0, 2.0, 3.0])   # D > 64: ODE / L96 only

@@ -189,3 +189,29 @@ def test_single_rank_driver_with_standin_matches_oracle():
         lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
         lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
         assert rel_err(lam.numpy(), lam_o) < 1e-12 and rel_err(psi.numpy(), psi_o) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n", [(72, 9), (96, 8), (128, 7), (160, 6)])
+def test_large_d_lorenz96_energy_terms(d, n):
+    """vgpa_energy at D > 64 (batched blocked Cholesky / inverse / GEMMs) vs the oracle's lean L96 energy."""
+    import vgpa_amd as va
+    from test_gpu_edge_cases import make_problem, gpu_context
+    p, x = make_problem("L96", d, n)
+    a, b = p.split(x)
+    mt, st = vo.solve_fwd(p.method, p.dt, False, a, b, p.m0, p.s0, p.sigma)
+    esde_o, (ef_o, edf_o), (dm_o, ds_o, *_) = vo.model_energy(p, a, b, mt, st, faithful=False)
+    ctx = va.Context("L96", "rk4", d, n, p.dt, sigma=p.sigma, theta=[8.0])
+    esde, ef, edf, dm, ds = ctx.energy(a, b, mt, st)
+    assert abs(esde - esde_o) <= TOL * abs(esde_o)
+    assert rel_err(ef, ef_o) < TOL and rel_err(edf, edf_o) < TOL
+    assert rel_err(dm, dm_o) < TOL and rel_err(ds, ds_o) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,method", [(72, 9, "rk4"), (128, 7, "rk4"), (96, 8, "heun")])
+def test_large_d_fused_sweep(d, n, method):
+    """The whole sweep (F and gradient) at D > 64 against the oracle."""
+    from test_gpu_edge_cases import make_problem, check
+    p, x = make_problem("L96", d, n, method=method)
+    check(p, x)

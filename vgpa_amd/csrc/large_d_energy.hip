@@ -1,0 +1,527 @@
+// Lorenz-96 energy terms for D > 64 (src/dynamics/lorenz_96.py:316-438 with utilities.py:239-310 and
+// variational.py:339-400), batched over grid points, built from a batched fp64-MFMA GEMM and a 64x64 diagonal-block
+// kernel.  Same identities as the LDS-resident kernel (energy.hip):
+//     L = chol(c S_t),  X = L^-1,  G = A L,  chi(p, i) = m_i +/- L[i][r_p]  (flat np.roll over the (M, D) matrix, Q1)
+//     v_p = sum_i isg_i (l96_flat(chi)[p,i] + (A m)_i +/- G[i][r_p] - b_i)^2
+//     E_t = 1/2 (w0 v_0 + w sum_r (v_+r + v_-r)),  dE/dm = c/2 X^T delta,  dE/dS = c/2 X^T diag(q) X
+// Blocked algorithms with block size 64 (T = ceil(D/64) block columns), all steps batched over `nb` grid points:
+//   Cholesky (right-looking):  diag block: L_JJ = chol(C_JJ), X_JJ = L_JJ^-1      (k_diag64, one wave per block)
+//                              panel     : L[R,J] = C[R,J] X_JJ^T                 (GEMM, in place)
+//                              trailing  : C[R,R] -= L[R,J] L[R,J]^T              (GEMM, lower tiles only)
+//   inverse  (by block rows):  T1 = L[I,0:I] X[0:I,0:I];  X[I,0:I] = -X_II T1     (2 GEMMs)
+#include "vgpa_internal.h"
+
+namespace vgpa {
+namespace lde {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int BN = 64, BK = 16, NT = 256, NBLK = 64;
+
+// ---- batched general GEMM:  C = alpha * op(A) op(B) + beta * C ----------------------------------------------------
+struct GemmB {
+  int M, N, K;
+  const double* A; long long lda, sA;     // op(A)[i][k] = TA ? A[k*lda + i] : A[i*lda + k]
+  const double* B; long long ldb, sB;     // op(B)[k][j] = TB ? B[j*ldb + k] : B[k*ldb + j]
+  double* C; long long ldc, sC;
+  double alpha, beta;
+  int lower_only;                         // skip tiles that lie strictly above the diagonal
+};
+
+template <bool TA, bool TB, int BM>
+__global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
+  constexpr int LDAS = BM + 17;
+  constexpr int LDBS = TB ? (BN + 17) : (BN + 16);
+  constexpr int MT = BM / 32;
+  constexpr int AQ = BM * BK / NT;
+  __shared__ __attribute__((aligned(16))) double As[2][BK * LDAS];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  if (g.lower_only && j0 >= i0 + BM) return;
+  const double* A = g.A + (long long)blockIdx.z * g.sA;
+  const double* B = g.B + (long long)blockIdx.z * g.sB;
+  double* C = g.C + (long long)blockIdx.z * g.sC;
+  const int fi = lane & 15, fk = lane >> 4;
+  double ra[AQ], rb[4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < AQ; q++) {
+      int i, k;
+      if (TA) { i = tid & (BM - 1); k = (tid / BM) + (NT / BM) * q; }
+      else { k = tid & 15; i = (tid >> 4) + 16 * q; }
+      const int gi = i0 + i, gk = k0 + k;
+      ra[q] = (gi < g.M && gk < g.K) ? (TA ? A[(long long)gk * g.lda + gi] : A[(long long)gi * g.lda + gk]) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int j, k;
+      if (TB) { k = tid & 15; j = (tid >> 4) + 16 * q; }
+      else { j = tid & 63; k = (tid >> 6) + 4 * q; }
+      const int gj = j0 + j, gk = k0 + k;
+      rb[q] = (gj < g.N && gk < g.K) ? (TB ? B[(long long)gj * g.ldb + gk] : B[(long long)gk * g.ldb + gj]) : 0.0;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < AQ; q++) {
+      int i, k;
+      if (TA) { i = tid & (BM - 1); k = (tid / BM) + (NT / BM) * q; }
+      else { k = tid & 15; i = (tid >> 4) + 16 * q; }
+      As[buf][k * LDAS + i] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int j, k;
+      if (TB) { k = tid & 15; j = (tid >> 4) + 16 * q; }
+      else { j = tid & 63; k = (tid >> 6) + 4 * q; }
+      Bs[buf][k * LDBS + j] = rb[q];
+    }
+  };
+  d4 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+  const int nk = (g.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    const double* as = As[cur] + fk * LDAS + (BM / 2) * wm + fi;
+    const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double af[MT], bf[2];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) af[mt] = as[kk * 4 * LDAS + 16 * mt];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) bf[nt] = bs[kk * 4 * LDBS + 16 * nt];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+      if (gj >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
+        if (gi < g.M) {
+          double* cp = C + (long long)gi * g.ldc + gj;
+          const double v = g.alpha * acc[mt][nt][r];
+          *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
+        }
+      }
+    }
+}
+
+hipError_t gemm_b(bool ta, bool tb, const GemmB& g, int nb, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || nb <= 0) return hipSuccess;
+  dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb);
+  if (ta && tb) hipLaunchKernelGGL((k_gemm_b<true, true, 64>), grid, dim3(NT), 0, st, g);
+  else if (ta) hipLaunchKernelGGL((k_gemm_b<true, false, 64>), grid, dim3(NT), 0, st, g);
+  else if (tb) hipLaunchKernelGGL((k_gemm_b<false, true, 64>), grid, dim3(NT), 0, st, g);
+  else hipLaunchKernelGGL((k_gemm_b<false, false, 64>), grid, dim3(NT), 0, st, g);
+  return hipGetLastError();
+}
+
+// ---- 64 x 64 diagonal block: L_JJ = chol(C_JJ) (in place, strict upper zeroed) and X_JJ = L_JJ^-1 ------------------
+// One wave per (grid point, block).  Rows / columns beyond D are treated as an identity block.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double lane_value(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) k_diag64(int D, int J, double* Cb, double* Xb, long long strideC, long long strideX,
+                                               int32_t* status, int status_stride_log) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int LD = NBLK + 1;
+  double* Lm = smem;             // [64][65]
+  double* Xm = Lm + NBLK * LD;   // [64][65]
+  double* rd = Xm + NBLK * LD;   // [64]
+  const int l = threadIdx.x, b = blockIdx.x;
+  double* C = Cb + (long long)b * strideC;
+  double* X = Xb + (long long)b * strideX;
+  const int r0 = J * NBLK;
+  const int nv = (D - r0 < NBLK) ? (D - r0) : NBLK;      // valid rows / columns of this block
+  for (int e = l; e < NBLK * NBLK; e += 64) {
+    const int r = e >> 6, c = e & 63;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nv && c < nv) v = C[(long long)(r0 + r) * D + r0 + c];
+    Lm[r * LD + c] = v;
+  }
+  wave_sync();
+  bool bad = false;
+  for (int j0 = 0; j0 < NBLK && !bad; j0 += 4) {
+    const double* rowi = Lm + l * LD;
+    double s0 = rowi[j0], s1 = rowi[j0 + 1], s2 = rowi[j0 + 2], s3 = rowi[j0 + 3];
+    const double* p0 = Lm + j0 * LD;
+    const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
+#pragma unroll 4
+    for (int k = 0; k < j0; k++) {
+      const double av = rowi[k];
+      s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
+      s2 = __builtin_fma(-av, p2[k], s2); s3 = __builtin_fma(-av, p3[k], s3);
+    }
+    double lq[4], sq[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = j0 + q;
+      double s = sq[q];
+#pragma unroll
+      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
+      const double piv = lane_value(s, j);
+      if (!(piv > 0.0)) bad = true;
+      const double rdv = rsqrt(piv), d = piv * rdv;
+      lq[q] = (l > j) ? s * rdv : 0.0;
+      Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
+      if (l == j) rd[j] = rdv;
+    }
+    wave_sync();
+  }
+  if (bad) {
+    if (l == 0) atomicOr(status + (b >> status_stride_log), 1);
+    return;
+  }
+  // X = L^-1, lane = column
+  for (int e = l; e < NBLK * LD; e += 64) Xm[e] = 0.0;
+  wave_sync();
+  for (int i0 = 0; i0 < NBLK; i0 += 4) {
+    const double* r0p = Lm + i0 * LD;
+    const double* r1p = r0p + LD; const double* r2p = r1p + LD; const double* r3p = r2p + LD;
+    double s0 = (i0 == l) ? 1.0 : 0.0, s1 = (i0 + 1 == l) ? 1.0 : 0.0, s2 = (i0 + 2 == l) ? 1.0 : 0.0,
+           s3 = (i0 + 3 == l) ? 1.0 : 0.0;
+    const double* xc = Xm + l;
+#pragma unroll 4
+    for (int k = 0; k < i0; k++) {
+      const double xv = xc[k * LD];
+      s0 = __builtin_fma(-r0p[k], xv, s0); s1 = __builtin_fma(-r1p[k], xv, s1);
+      s2 = __builtin_fma(-r2p[k], xv, s2); s3 = __builtin_fma(-r3p[k], xv, s3);
+    }
+    const double x0 = s0 * rd[i0];
+    s1 = __builtin_fma(-r1p[i0], x0, s1);
+    const double x1 = s1 * rd[i0 + 1];
+    s2 = __builtin_fma(-r2p[i0], x0, s2); s2 = __builtin_fma(-r2p[i0 + 1], x1, s2);
+    const double x2 = s2 * rd[i0 + 2];
+    s3 = __builtin_fma(-r3p[i0], x0, s3); s3 = __builtin_fma(-r3p[i0 + 1], x1, s3); s3 = __builtin_fma(-r3p[i0 + 2], x2, s3);
+    const double x3 = s3 * rd[i0 + 3];
+    double* xw = Xm + i0 * LD + l;
+    xw[0] = x0; xw[LD] = x1; xw[2 * LD] = x2; xw[3 * LD] = x3;
+  }
+  wave_sync();
+  for (int e = l; e < NBLK * NBLK; e += 64) {
+    const int r = e >> 6, c = e & 63;
+    if (r < nv && c < nv) {
+      C[(long long)(r0 + r) * D + r0 + c] = Lm[r * LD + c];
+      X[(long long)(r0 + r) * D + r0 + c] = Xm[r * LD + c];
+    }
+  }
+}
+
+// ---- small batched kernels ---------------------------------------------------------------------------------------
+// C = c * S_t ; X = 0
+__global__ void __launch_bounds__(NT) k_prep(int D, double cfac, const double* S, double* C, double* X, long long sW) {
+  const long long DD = (long long)D * D;
+  const double* s = S + (long long)blockIdx.y * DD;
+  double* c = C + (long long)blockIdx.y * sW;
+  double* x = X + (long long)blockIdx.y * sW;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    c[e] = cfac * s[e];
+    x[e] = 0.0;
+  }
+}
+
+// zero the strict upper triangle of L (block rows above the diagonal still hold c*S / stale updates)
+__global__ void __launch_bounds__(NT) k_zero_upper(int D, double* C, long long sW) {
+  double* c = C + (long long)blockIdx.y * sW;
+  const long long DD = (long long)D * D;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int r = (int)(e / D), cc = (int)(e - (long long)r * D);
+    if (cc > r) c[e] = 0.0;
+  }
+}
+
+// y = op(A) x, one wave per output row; TA: y_i = sum_k A[k][i] x_k (rows k >= kmin_is_i ? i : 0)
+__global__ void __launch_bounds__(NT) k_matvec(int D, int ta, const double* A, long long sA, const double* x, long long sx,
+                                               double* y, long long sy, double scale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (NT / 64) + wave;
+  if (i >= D) return;
+  const double* a = A + (long long)blockIdx.y * sA;
+  const double* xv = x + (long long)blockIdx.y * sx;
+  double s = 0.0;
+  if (ta) for (int k = lane; k < D; k += 64) s = __builtin_fma(a[(long long)k * D + i], xv[k], s);
+  else for (int k = lane; k < D; k += 64) s = __builtin_fma(a[(long long)i * D + k], xv[k], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) y[(long long)blockIdx.y * sy + i] = scale * s;
+}
+
+__device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// v_p for every sigma point p (thread = sigma point, sequential sliding window over i)
+__global__ void __launch_bounds__(NT) k_resid(int D, double theta, const double* L, const double* G, long long sW,
+                                              const double* m, const double* b, long long sb, const double* am,
+                                              const double* isg, double* v, long long sv) {
+  const int M = 2 * D + 1;
+  const int p = blockIdx.x * NT + threadIdx.x;
+  if (p >= M) return;
+  const int t = blockIdx.y;
+  const double* Lm = L + (long long)t * sW;
+  const double* Gm = G + (long long)t * sW;
+  const double* mv = m + (long long)t * D;
+  const double* bv = b + (long long)t * sb;
+  const double* av = am + (long long)t * D;
+  auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
+  auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
+  auto chi = [&](int q, int i) { return mv[i] + sgn_of(q) * Lm[(long long)i * D + col_of(q)]; };
+  const int rp = col_of(p);
+  const double sp = sgn_of(p);
+  const int pm = wrapi(p - 1, M), pp = wrapi(p + 1, M);
+  double xm2 = chi(pm, D - 2), xm1 = chi(pm, D - 1), x0 = chi(p, 0), x1 = chi(p, 1);
+  double acc = 0.0;
+  for (int i = 0; i < D; i++) {
+    const double lin = av[i] + sp * Gm[(long long)i * D + rp];
+    const double res = ((x1 - xm2) * xm1 - x0 + theta) + lin - bv[i];
+    acc = __builtin_fma(isg[i], res * res, acc);
+    xm2 = xm1; xm1 = x0; x0 = x1;
+    const int in = i + 2;
+    x1 = (in < D) ? chi(p, in) : chi(pp, in - D);
+  }
+  v[(long long)t * sv + p] = acc;
+}
+
+// e_t, delta, q from v; also <f> (E96_drift)
+__global__ void __launch_bounds__(NT) k_finish(int D, double theta, const double* v, long long sv, const double* S,
+                                               const double* m, double* e_t, double* dl, double* qq, double* Ef) {
+  __shared__ double red[NT];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const double kappa = 1.05 * D, c = D + kappa, w0 = kappa / c, w1 = 1.0 / (2.0 * c);
+  const double* vv = v + (long long)t * sv;
+  double part = 0.0;
+  for (int r = tid; r < D; r += NT) part += vv[1 + r] + vv[1 + D + r];
+  red[tid] = part;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  const double et = 0.5 * (w0 * vv[0] + w1 * red[0]);
+  if (tid == 0) e_t[t] = et;
+  const double* St = S + (long long)t * D * D;
+  const double* mv = m + (long long)t * D;
+  for (int r = tid; r < D; r += NT) {
+    dl[(long long)t * D + r] = w1 * (vv[1 + r] - vv[1 + D + r]);
+    qq[(long long)t * D + r] = 0.5 * c * (w1 * (vv[1 + r] + vv[1 + D + r])) - et;
+    const int ip1 = wrapi(r + 1, D), im1 = wrapi(r - 1, D), im2 = wrapi(r - 2, D);
+    const double cxx = St[(long long)ip1 * D + im1] - St[(long long)im2 * D + im1];
+    Ef[(long long)t * D + r] = cxx + (mv[ip1] - mv[im2]) * mv[im1] - mv[r] + theta;
+  }
+}
+
+// Y[k][j] = q_k X[k][j]
+__global__ void __launch_bounds__(NT) k_scale_rows(int D, const double* X, const double* q, double* Y, long long sW) {
+  const double* x = X + (long long)blockIdx.y * sW;
+  double* y = Y + (long long)blockIdx.y * sW;
+  const double* qv = q + (long long)blockIdx.y * D;
+  const long long DD = (long long)D * D;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) y[e] = qv[e / D] * x[e];
+}
+
+// dense <df/dx> (E96_drift_dx)
+__global__ void __launch_bounds__(NT) k_edf(int D, const double* m, double* Edf) {
+  const double* mv = m + (long long)blockIdx.y * D;
+  double* ed = Edf + (long long)blockIdx.y * D * D;
+  const long long DD = (long long)D * D;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int k = (int)(e / D), j = (int)(e - (long long)k * D);
+    const int kp1 = wrapi(k + 1, D), km1 = wrapi(k - 1, D), km2 = wrapi(k - 2, D);
+    double val = 0.0;
+    if (j == k) val = -1.0;
+    if (j == kp1) val = mv[km1];
+    if (j == km2) val = -mv[km1];
+    if (j == km1) val = mv[kp1] - mv[km2];
+    ed[e] = val;
+  }
+}
+
+// Q = diag(isg) (Edf + A) - 2 Psi, Edf recomputed from m (E96_drift_dx)
+__global__ void __launch_bounds__(NT) k_grad_q(int D, const double* isg, const double* A, const double* m, const double* psi,
+                                               double* Q) {
+  const long long DD = (long long)D * D;
+  const double* a = A + (long long)blockIdx.y * DD;
+  const double* ps = psi + (long long)blockIdx.y * DD;
+  const double* mv = m + (long long)blockIdx.y * D;
+  double* q = Q + (long long)blockIdx.y * DD;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int k = (int)(e / D), j = (int)(e - (long long)k * D);
+    const int kp1 = wrapi(k + 1, D), km1 = wrapi(k - 1, D), km2 = wrapi(k - 2, D);
+    double ed = 0.0;
+    if (j == k) ed = -1.0;
+    if (j == kp1) ed = mv[km1];
+    if (j == km2) ed = -mv[km1];
+    if (j == km1) ed = mv[kp1] - mv[km2];
+    q[e] = isg[k] * (ed + a[e]) - 2.0 * ps[e];
+  }
+}
+
+// gA = dt (QS - u m^T) in place on QS ; gB = dt u ; u_i = isg_i (-Ef_i - (A m)_i + b_i) + lam_i
+__global__ void __launch_bounds__(NT) k_grad_fin(int D, double dt, const double* isg, const double* am, const double* b,
+                                                 const double* m, const double* lam, const double* Ef, double* gA, double* gB) {
+  const long long DD = (long long)D * D;
+  const long long vo = (long long)blockIdx.y * D;
+  double* g = gA + (long long)blockIdx.y * DD;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int i = (int)(e / D), j = (int)(e - (long long)i * D);
+    const double u = isg[i] * (-Ef[vo + i] - am[vo + i] + b[vo + i]) + lam[vo + i];
+    g[e] = dt * (g[e] - u * m[vo + j]);
+    if (j == 0) gB[vo + i] = dt * u;
+  }
+}
+
+}  // namespace lde
+
+namespace ld {
+
+size_t lde_workspace_doubles(int D, int nb) {
+  const size_t DD = (size_t)D * D;
+  return (size_t)nb * (3 * DD + (size_t)lde::NBLK * D + 4 * (size_t)D + (2 * (size_t)D + 1));
+}
+
+int lde_batch(int D) {
+  const double per_t = 3.1 * D * D * 8.0;
+  int nb = (int)(1.0e9 / per_t);
+  return nb < 1 ? 1 : (nb > 64 ? 64 : nb);
+}
+
+#define LDE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+// Energy terms of Np grid points of ONE problem.  Edf may be nullptr.
+hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
+                      const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
+                      double* ws, int nbmax, hipStream_t st) {
+  using namespace lde;
+  const long long DD = (long long)D * D;
+  const int T = (D + NBLK - 1) / NBLK, M = 2 * D + 1;
+  const double kappa = 1.05 * D, c = D + kappa;
+  const size_t lds_diag = sizeof(double) * (2 * NBLK * (NBLK + 1) + NBLK);
+  (void)hipFuncSetAttribute((const void*)k_diag64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+  for (int t0 = 0; t0 < Np; t0 += nbmax) {
+    const int nb = (Np - t0 < nbmax) ? (Np - t0) : nbmax;
+    double* C = ws;                                   // [nb][D][D]  c*S -> L -> diag(q) X
+    double* X = C + (size_t)nb * DD;                  // [nb][D][D]  L^-1
+    double* G = X + (size_t)nb * DD;                  // [nb][D][D]  A L
+    double* T1 = G + (size_t)nb * DD;                 // [nb][64][D]
+    double* am = T1 + (size_t)nb * NBLK * D;          // [nb][D]
+    double* dl = am + (size_t)nb * D;
+    double* qq = dl + (size_t)nb * D;
+    double* sp = qq + (size_t)nb * D;                 // spare [nb][D]
+    double* vv = sp + (size_t)nb * D;                 // [nb][M]
+    const double* At = A + (size_t)t0 * DD;
+    const double* St = S + (size_t)t0 * DD;
+    const double* mt = m + (size_t)t0 * D;
+    const double* bt = b + (size_t)t0 * D;
+    const int eg = (int)((DD + NT * 8 - 1) / (NT * 8));
+    hipLaunchKernelGGL(k_prep, dim3(eg, nb), dim3(NT), 0, st, D, c, St, C, X, DD);
+    // ---- blocked Cholesky
+    for (int J = 0; J < T; J++) {
+      hipLaunchKernelGGL(k_diag64, dim3(nb), dim3(64), lds_diag, st, D, J, C, X, DD, DD, status, 30);
+      const int r1 = (J + 1) * NBLK;
+      if (r1 >= D) break;
+      const int Mr = D - r1;
+      const int kw = (D - J * NBLK < NBLK) ? (D - J * NBLK) : NBLK;
+      GemmB p{};   // L[R,J] = C[R,J] X_JJ^T   (in place)
+      p.M = Mr; p.N = kw; p.K = kw; p.A = C + (size_t)r1 * D + J * NBLK; p.lda = D; p.sA = DD;
+      p.B = X + (size_t)(J * NBLK) * D + J * NBLK; p.ldb = D; p.sB = DD;
+      p.C = C + (size_t)r1 * D + J * NBLK; p.ldc = D; p.sC = DD; p.alpha = 1.0; p.beta = 0.0;
+      // in place: every workgroup owns a 64-row block of the panel, reads all of it before its epilogue writes it
+      LDE_TRY(gemm_b(false, true, p, nb, st));
+      GemmB u{};   // C[R,R] -= L[R,J] L[R,J]^T  (lower tiles)
+      u.M = Mr; u.N = Mr; u.K = kw; u.A = C + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
+      u.B = u.A; u.ldb = D; u.sB = DD; u.C = C + (size_t)r1 * D + r1; u.ldc = D; u.sC = DD; u.alpha = -1.0; u.beta = 1.0;
+      u.lower_only = 1;
+      LDE_TRY(gemm_b(false, true, u, nb, st));
+    }
+    hipLaunchKernelGGL(k_zero_upper, dim3(eg, nb), dim3(NT), 0, st, D, C, DD);
+    // ---- X = L^-1 by block rows
+    for (int I = 1; I < T; I++) {
+      const int r0 = I * NBLK;
+      const int Mi = (D - r0 < NBLK) ? (D - r0) : NBLK;
+      GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
+      a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = C + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = X; a1.ldb = D; a1.sB = DD;
+      a1.C = T1; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
+      LDE_TRY(gemm_b(false, false, a1, nb, st));
+      GemmB a2{};  // X[I, 0:r0] = -X_II T1
+      a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = X + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = T1; a2.ldb = D;
+      a2.sB = (long long)NBLK * D; a2.C = X + (size_t)r0 * D; a2.ldc = D; a2.sC = DD; a2.alpha = -1.0; a2.beta = 0.0;
+      LDE_TRY(gemm_b(false, false, a2, nb, st));
+    }
+    // ---- G = A L ; A m
+    GemmB gg{};
+    gg.M = D; gg.N = D; gg.K = D; gg.A = At; gg.lda = D; gg.sA = DD; gg.B = C; gg.ldb = D; gg.sB = DD; gg.C = G; gg.ldc = D;
+    gg.sC = DD; gg.alpha = 1.0; gg.beta = 0.0;
+    LDE_TRY(gemm_b(false, false, gg, nb, st));
+    hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, At, DD, mt, (long long)D, am, (long long)D, 1.0);
+    // ---- residuals, scalars
+    hipLaunchKernelGGL(k_resid, dim3((M + NT - 1) / NT, nb), dim3(NT), 0, st, D, theta, C, G, DD, mt, bt, (long long)D, am,
+                       isg, vv, (long long)M);
+    hipLaunchKernelGGL(k_finish, dim3(nb), dim3(NT), 0, st, D, theta, vv, (long long)M, St, mt, e_t + t0, dl, qq,
+                       Ef + (size_t)t0 * D);
+    // ---- dE/dm = c/2 X^T delta ; dE/dS = c/2 X^T diag(q) X
+    hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 1, X, DD, dl, (long long)D,
+                       dEm + (size_t)t0 * D, (long long)D, 0.5 * c);
+    hipLaunchKernelGGL(k_scale_rows, dim3(eg, nb), dim3(NT), 0, st, D, X, qq, C, DD);
+    GemmB sy{};
+    sy.M = D; sy.N = D; sy.K = D; sy.A = X; sy.lda = D; sy.sA = DD; sy.B = C; sy.ldb = D; sy.sB = DD;
+    sy.C = dEs + (size_t)t0 * DD; sy.ldc = D; sy.sC = DD; sy.alpha = 0.5 * c; sy.beta = 0.0;
+    LDE_TRY(gemm_b(true, false, sy, nb, st));
+    if (Edf) hipLaunchKernelGGL(k_edf, dim3(eg, nb), dim3(NT), 0, st, D, mt, Edf + (size_t)t0 * DD);
+    LDE_TRY(hipGetLastError());
+  }
+  return hipSuccess;
+}
+
+// Gradient w.r.t. (A_t, b_t) for D > 64 (src/var_bayes/variational.py:263-288), diagonal Sigma^-1:
+//   Q = Sigma^-1 (Edf + A) - 2 Psi ;  gLa = dt (Q S - u m^T) ;  u = Sigma^-1 (-Ef - A m + b) + lam ;  gLb = dt u
+hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A, const double* b, const double* m,
+                    const double* S, const double* lam, const double* psi, const double* Ef, double* gA, double* gB,
+                    double* ws, int nbmax, hipStream_t st) {
+  using namespace lde;
+  const long long DD = (long long)D * D;
+  for (int t0 = 0; t0 < Np; t0 += nbmax) {
+    const int nb = (Np - t0 < nbmax) ? (Np - t0) : nbmax;
+    double* Q = ws;                                    // [nb][D][D]
+    double* am = Q + (size_t)nb * DD;                  // [nb][D]
+    const int eg = (int)((DD + NT * 8 - 1) / (NT * 8));
+    hipLaunchKernelGGL(k_grad_q, dim3(eg, nb), dim3(NT), 0, st, D, isg, A + (size_t)t0 * DD, m + (size_t)t0 * D,
+                       psi + (size_t)t0 * DD, Q);
+    hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, A + (size_t)t0 * DD, DD, m + (size_t)t0 * D,
+                       (long long)D, am, (long long)D, 1.0);
+    GemmB g{};
+    g.M = D; g.N = D; g.K = D; g.A = Q; g.lda = D; g.sA = DD; g.B = S + (size_t)t0 * DD; g.ldb = D; g.sB = DD;
+    g.C = gA + (size_t)t0 * DD; g.ldc = D; g.sC = DD; g.alpha = 1.0; g.beta = 0.0;
+    LDE_TRY(gemm_b(false, false, g, nb, st));
+    hipLaunchKernelGGL(k_grad_fin, dim3(eg, nb), dim3(NT), 0, st, D, dt, isg, am, b + (size_t)t0 * D, m + (size_t)t0 * D,
+                       lam + (size_t)t0 * D, Ef + (size_t)t0 * D, gA + (size_t)t0 * DD, gB + (size_t)t0 * D);
+    LDE_TRY(hipGetLastError());
+  }
+  return hipSuccess;
+}
+#undef LDE_TRY
+
+}  // namespace ld
+}  // namespace vgpa

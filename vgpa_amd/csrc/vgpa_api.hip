@@ -32,6 +32,8 @@ struct vgpa_ctx {
   double *d_obs_y = nullptr, *d_Q = nullptr, *d_K = nullptr, *d_rinv = nullptr, *d_jsc = nullptr;
   double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
   double* d_ld_ws = nullptr;      // workspace of the large-D drivers
+  double* d_lde_ws = nullptr;     // workspace of the large-D energy / gradient kernels
+  int lde_nb = 1;
   int64_t* d_obs_t = nullptr;
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
@@ -203,7 +205,23 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
   return a;
 }
 
+static int ensure_lde_ws(vgpa_ctx* c) {
+  if (c->d_lde_ws) return VGPA_OK;
+  c->lde_nb = ld::lde_batch(c->D);
+  if (c->lde_nb > c->Np) c->lde_nb = c->Np;
+  return dev_alloc(c, &c->d_lde_ws, ld::lde_workspace_doubles(c->D, c->lde_nb));
+}
+
 static int run_energy(vgpa_ctx* c, double* edf) {
+  if (c->D > kMaxSmallD) {
+    if (c->cfg.model != VGPA_MODEL_L96) return fail(c, VGPA_ERR_UNSUPPORTED, "large-D energy terms exist for Lorenz-96 only");
+    int rc = ensure_lde_ws(c);
+    if (rc) return rc;
+    hipError_t e = ld::lde_energy(c->D, c->Np, c->theta[0], c->d_isg, ctx_A(c), ctx_b(c), c->d_m, c->d_S, c->d_et, c->d_Ef, edf,
+                                  c->d_dEm, c->d_dEs, c->d_status, c->d_lde_ws, c->lde_nb, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
+    return VGPA_OK;
+  }
   EnergyArgs a = energy_args(c, edf);
   hipError_t e = launch_energy(a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "energy launch failed: %s", hipGetErrorString(e));
@@ -229,6 +247,15 @@ static int run_reduce(vgpa_ctx* c) {
 }
 
 static int run_grad(vgpa_ctx* c, double* g_dev) {
+  if (c->D > kMaxSmallD) {
+    if (!c->sigma_diag) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D gradient needs a diagonal system noise matrix");
+    int rc = ensure_lde_ws(c);
+    if (rc) return rc;
+    hipError_t e = ld::lde_grad(c->D, c->Np, c->cfg.dt, c->d_isg, ctx_A(c), ctx_b(c), c->d_m, c->d_S, c->d_lam, c->d_psi, c->d_Ef,
+                                g_dev, g_dev + (size_t)c->Np * c->DD, c->d_lde_ws, c->lde_nb, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
+    return VGPA_OK;
+  }
   GradArgs a{};
   a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.sigma_diag = c->sigma_diag ? 1 : 0;
   a.dt = c->cfg.dt;
@@ -254,7 +281,18 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
   if ((rc = run_energy(c, nullptr))) return rc;
   prof_mark(c, 2);
-  if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
+  if (c->D > kMaxSmallD) {      // the large-D backward driver consumes dense jump arrays
+    const size_t BN = (size_t)c->B * c->Np;
+    if (!c->d_jm_dense) {
+      if ((rc = dev_alloc(c, &c->d_jm_dense, BN * c->D))) return rc;
+      if ((rc = dev_alloc(c, &c->d_js_dense, BN * c->DD))) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_jm_dense, 0, sizeof(double) * BN * c->D, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_js_dense, 0, sizeof(double) * BN * c->DD, c->stream));
+    e = launch_obs_dense(obs_args(c), c->d_jsc, c->d_jm_dense, c->d_js_dense, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs dense launch failed: %s", hipGetErrorString(e));
+  }
+  if ((rc = run_bwd(c, c->D > kMaxSmallD, c->sym_inputs))) return rc;
   prof_mark(c, 3);
   if ((rc = run_reduce(c))) return rc;
   c->have_state = true;
@@ -308,9 +346,9 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   if (single && cfg->dim_d != 1) return fail(nullptr, VGPA_ERR_ARG, "1-D model with D=%d", cfg->dim_d);
   if (cfg->model == VGPA_MODEL_L63 && cfg->dim_d != 3) return fail(nullptr, VGPA_ERR_ARG, "Lorenz-63 needs D=3, got %d", cfg->dim_d);
   if (cfg->model == VGPA_MODEL_L96 && cfg->dim_d < 4) return fail(nullptr, VGPA_ERR_ARG, "Insufficient state vector dimensions: %d", cfg->dim_d);
-  if (cfg->dim_d > kMaxSmallD && cfg->model != VGPA_MODEL_NONE)
-    return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d: only the ODE operators (vgpa_solve_fwd / vgpa_solve_bwd, model NONE) are built "
-                "for large D; the energy terms of the fused sweep are not yet", cfg->dim_d, kMaxSmallD);
+  if (cfg->dim_d > kMaxSmallD && cfg->model != VGPA_MODEL_NONE && cfg->model != VGPA_MODEL_L96)
+    return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d is built for the ODE operators (model NONE) and for Lorenz-96 only",
+                cfg->dim_d, kMaxSmallD);
   if (cfg->dim_d > kMaxSmallD && cfg->batch != 1) return fail(nullptr, VGPA_ERR_UNSUPPORTED, "large-D contexts hold one problem");
   const int need_theta = (cfg->model == VGPA_MODEL_L63) ? 3 : (cfg->model == VGPA_MODEL_NONE ? 0 : 1);
   if (cfg->n_theta != need_theta || (need_theta > 0 && !cfg->theta)) return fail(nullptr, VGPA_ERR_ARG, "model needs %d drift parameter(s)", need_theta);
@@ -345,14 +383,22 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   } else if (cfg->model == VGPA_MODEL_NONE) {
     for (int i = 0; i < D; i++) { isig[(size_t)i * D + i] = 1.0; isg[i] = 1.0; }   // ODE-only: Sigma^-1 is not used
   } else {
-    if (!host_spd_inverse(D, sigma.data(), isig.data(), nullptr)) { fail(nullptr, VGPA_ERR_NOT_PD, "Noise matrix is not positive definite."); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
-    for (int i = 0; i < D; i++) isg[i] = isig[(size_t)i * D + i];
     c->sigma_diag = true;
     for (int i = 0; i < D && c->sigma_diag; i++)
       for (int j = 0; j < D; j++)
         if (i != j && sigma[(size_t)i * D + j] != 0.0) { c->sigma_diag = false; break; }
-    if (c->sigma_diag)   // exact reciprocals on the diagonal, exact zeros elsewhere
-      for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) if (i != j) isig[(size_t)i * D + j] = 0.0;
+    if (c->sigma_diag) {   // chol_inv of a diagonal matrix: C = diag(1/sqrt(s)), C^T C = diag(C_ii * C_ii)
+      for (int i = 0; i < D; i++) {
+        const double sii = sigma[(size_t)i * D + i];
+        if (!(sii > 0.0)) { fail(nullptr, VGPA_ERR_NOT_PD, "Noise matrix is not positive definite."); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+        const double ci = 1.0 / std::sqrt(sii);
+        isig[(size_t)i * D + i] = ci * ci;
+        isg[i] = ci * ci;
+      }
+    } else {
+      if (!host_spd_inverse(D, sigma.data(), isig.data(), nullptr)) { fail(nullptr, VGPA_ERR_NOT_PD, "Noise matrix is not positive definite."); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+      for (int i = 0; i < D; i++) isg[i] = isig[(size_t)i * D + i];
+    }
   }
   c->sym_inputs = is_symmetric(sigma.data(), D) && (!cfg->s0 || is_symmetric(cfg->s0, D));
 
@@ -413,9 +459,25 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
       Q[0] = 1.0 / r; K[0] = h; rinv[0] = 1.0 / r; jsc[0] = 0.5 / r;
       c->obs_const = 0.5 * c->M * (std::log(2.0 * M_PI) + std::log(r));
     } else {
-      std::vector<double> Rinv(DD), H(DD, 0.0), T(DD);
+      std::vector<double> Rinv(DD, 0.0), H(DD, 0.0), T(DD);
       double logdet = 0.0;
-      if (!host_spd_inverse(D, cfg->obs_noise, Rinv.data(), &logdet)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise matrix is not positive definite"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+      bool r_diag = !cfg->obs_h;               // fast path: diagonal R and H = I (no O(D^3) host work at large D)
+      for (int i = 0; i < D && r_diag; i++)
+        for (int j = 0; j < D; j++)
+          if (i != j && cfg->obs_noise[(size_t)i * D + j] != 0.0) { r_diag = false; break; }
+      if (r_diag) {
+        for (int i = 0; i < D; i++) {
+          const double rii = cfg->obs_noise[(size_t)i * D + i];
+          if (!(rii > 0.0)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise matrix is not positive definite"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+          const double ci = 1.0 / std::sqrt(rii);
+          const double ri = ci * ci;
+          Q[(size_t)i * D + i] = ri; K[(size_t)i * D + i] = ri; jsc[(size_t)i * D + i] = 0.5 * ri; rinv[i] = ri;
+          logdet += std::log(std::sqrt(rii));
+        }
+        logdet *= 2.0;
+        c->obs_const = c->M * (D * std::log(2.0 * M_PI) + logdet);
+      } else if (!host_spd_inverse(D, cfg->obs_noise, Rinv.data(), &logdet)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise matrix is not positive definite"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
+      if (!r_diag) {
       if (cfg->obs_h) H.assign(cfg->obs_h, cfg->obs_h + DD); else for (int i = 0; i < D; i++) H[(size_t)i * D + i] = 1.0;
       host_matmul(D, H.data(), Rinv.data(), T.data(), false, false);      // H R^-1
       host_matmul(D, T.data(), H.data(), Q.data(), false, true);          // H R^-1 H^T
@@ -425,6 +487,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
       for (auto& v : jsc) v *= 0.5;
       for (int i = 0; i < D; i++) rinv[i] = Rinv[(size_t)i * D + i];
       c->obs_const = c->M * (D * std::log(2.0 * M_PI) + logdet);
+      }
       c->sym_inputs = c->sym_inputs && is_symmetric(jsc.data(), D);
     }
     TRY(upload(c, c->d_obs_t, cfg->obs_t, (size_t)c->M));

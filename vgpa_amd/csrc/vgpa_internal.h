@@ -114,6 +114,14 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
                         const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st);
 hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
                         const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st);
+size_t lde_workspace_doubles(int D, int nb);
+int lde_batch(int D);
+hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
+                      const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
+                      double* ws, int nbmax, hipStream_t st);
+hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A, const double* b, const double* m,
+                    const double* S, const double* lam, const double* psi, const double* Ef, double* gA, double* gB,
+                    double* ws, int nbmax, hipStream_t st);
 }  // namespace ld
 
 // tiny host-side dense helpers (row-major, fp64) ---------------------------------------------------
