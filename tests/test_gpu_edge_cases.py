@@ -129,5 +129,8 @@ def test_state_errors():
         va.Context("L63", "rk4", 3, 10, 0.01, sigma=np.eye(3), theta=[1.0])     # L63 needs 3 drift parameters
     with pytest.raises(ValueError):
         va.Context("L96", "rk4", 12, 10, -0.01, sigma=np.eye(12), theta=[8.0])
+    p72, x72 = make_problem("L96", 72, 5, dense=True)
+    c72 = gpu_context(p72)
+    c72.free_energy(x72)
     with pytest.raises(NotImplementedError):
-        va.Context("L63", "rk4", 128, 10, 0.01, sigma=np.eye(128), theta=[1.0, 2.0, 3.0])   # D > 64: ODE / L96 only
+        c72.gradient(None)                         # D > 64: the gradient needs a diagonal system noise matrix (for now)
