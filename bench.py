@@ -59,9 +59,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (vgpa_amd has no CPU fallback)")
+    # Rehearsal switch (not used by the driver): VGPA_BENCH_REHEARSE=1 runs all ranks on GPU 0 with the gloo backend so
+    # that the N > 1 control flow can be exercised on a one-GPU box.
+    rehearse = os.environ.get("VGPA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     from vgpa_amd import parallel as par
-    par.init_from_env("nccl", local_rank)            # RCCL; no-op at WORLD_SIZE == 1
+    par.init_from_env("gloo" if rehearse else "nccl", None if rehearse else local_rank)   # RCCL; no-op at WORLD_SIZE == 1
 
     import vgpa_amd as va
     from vgpa_amd._lib import FLAG_FORCE_GENERIC
@@ -109,7 +114,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
 
-    elapsed = par.max_over_ranks(elapsed, device="cuda")
+    elapsed = par.max_over_ranks(elapsed, device="cpu" if rehearse else "cuda")
 
     # ---- correctness guard inside the bench: problem 0 of rank 0 must reproduce the reference's anchor
     check = None
