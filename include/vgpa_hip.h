@@ -133,6 +133,21 @@ int vgpa_free_energy_dev(vgpa_ctx* ctx, const double* x_dev, double* f_host);
 int vgpa_sweep_enqueue(vgpa_ctx* ctx, const double* x_dev, double* g_dev);
 int vgpa_fetch_f(vgpa_ctx* ctx, double* f_host);    /* syncs, checks the device status word */
 
+/* gradient from the cached state into a DEVICE buffer (df(x) of SCG, src/numerics/optim_scg.py:100,235) */
+int vgpa_gradient_dev(vgpa_ctx* ctx, double* g_dev);
+
+/* device-resident vector algebra for the SCG driver (src/numerics/optim_scg.py:75-285):
+ * x, d and the gradients stay in HBM, only scalars return.  Every vector is the context's batch of `batch` segments of
+ * `seglen` doubles (seglen = len(x) of one problem for SCG); results / coefficients are host arrays of `batch` doubles,
+ * one per problem, so that `batch` independent optimisations advance in lock step.  Deterministic reductions. */
+int vgpa_vec_dot(vgpa_ctx* ctx, const double* a_dev, const double* b_dev, uint64_t seglen, double* out_host);
+int vgpa_vec_absmax(vgpa_ctx* ctx, const double* a_dev, uint64_t seglen, double* out_host);
+int vgpa_vec_asum(vgpa_ctx* ctx, const double* a_dev, uint64_t seglen, double* out_host);
+/* out = alpha[p]*x + beta[p]*y per problem p; y/beta may be NULL (out = alpha*x); out may alias x or y; a zero
+ * coefficient drops its operand entirely (0*inf = 0), which is how finished problems are frozen */
+int vgpa_vec_axpby(vgpa_ctx* ctx, uint64_t seglen, const double* alpha_host, const double* x_dev,
+                   const double* beta_host_or_null, const double* y_dev_or_null, double* out_dev);
+
 /* raw device memory helpers so that hosts without a HIP binding can own device buffers */
 int vgpa_dev_alloc(vgpa_ctx* ctx, uint64_t bytes, void** out);
 int vgpa_dev_free(vgpa_ctx* ctx, void* ptr);

@@ -1,0 +1,87 @@
+"""the SCG iteration with device-resident vectors must follow the host SCG trace."""
+import numpy as np
+import pytest
+
+import vgpa_amd as va
+from helpers import build_problem
+
+pytestmark = pytest.mark.gpu
+OPTS = {"max_it": 12, "x_tol": 1e-6, "f_tol": 1e-8}
+
+
+def _segments(ctx, host):
+    from vgpa_amd._lib import DeviceBuffer
+    buf = DeviceBuffer(ctx, host.size)
+    buf.upload(host)
+    return buf
+
+
+def test_vector_algebra_matches_numpy():
+    p = build_problem("OU", "Euler", 1.0, 0.01, None)
+    v = va.VarGP(p["model"], p["m0"], p["s0"], p["fwd"], p["bwd"], p["lik"], p["kl0"], p["obs_y"], p["obs_t"], batch=3)
+    ctx = v._context()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 255, 256, 257, 100003):
+        a, b = rng.standard_normal((3, n)), rng.standard_normal((3, n))
+        da, db, dc = _segments(ctx, a), _segments(ctx, b), _segments(ctx, np.zeros((3, n)))
+        assert np.allclose(ctx.vdot(da, db), (a * b).sum(1), rtol=1e-12, atol=1e-12 * n)
+        assert np.array_equal(ctx.vabsmax(da), np.abs(a).max(1))
+        assert np.allclose(ctx.vasum(da), np.abs(a).sum(1), rtol=1e-13)
+        al, be = np.array([0.5, 0.0, -2.0]), np.array([1.0, 1.0, 0.0])
+        ctx.vaxpby(al, da, be, db, dc)
+        want = al[:, None] * a + be[:, None] * b
+        got = dc.download().reshape(3, n)
+        assert np.array_equal(got[1], b[1]) and np.array_equal(got[2], -2.0 * a[2])
+        assert np.allclose(got, want, rtol=1e-15, atol=0)
+        ctx.vaxpby(-1.0, da, None, None, da)            # in place, scalar coefficient, no second operand
+        assert np.array_equal(da.download().reshape(3, n), -a)
+        for buf in (da, db, dc):
+            buf.free()
+    with pytest.raises(ValueError):
+        ctx.vdot(_segments(ctx, np.zeros(4)), _segments(ctx, np.zeros(4)))
+
+
+@pytest.mark.parametrize("name,method,tf,d", [("OU", "Euler", 2.0, None), ("DW", "Heun", 1.0, None),
+                                              ("L63", "RK4", 0.5, None), ("L96", "RK2", 0.3, 12)])
+def test_device_scg_follows_the_host_trace(name, method, tf, d):
+    p = build_problem(name, method, tf, 0.01, d)
+    v = p["vgp"]
+    x0 = v.initialization()
+    host = va.SCG(v.free_energy, v.gradient, dict(OPTS))
+    x_h, f_h = host(x0.copy())
+    dev = v.device_scg(dict(OPTS))
+    x_d, f_d = dev(x0.copy())
+    n_it = int(dev.statistics["MaxIt"][0])
+    assert n_it == host.statistics["MaxIt"]
+    assert np.allclose(dev.statistics["fx"][:n_it, 0], host.statistics["fx"][:n_it], rtol=1e-9, atol=0)
+    assert np.allclose(dev.statistics["beta"][:n_it, 0], host.statistics["beta"][:n_it], rtol=1e-9)
+    assert np.allclose(dev.statistics["dfx"][:n_it, 0], host.statistics["dfx"][:n_it], rtol=1e-7)
+    assert abs(f_d - f_h) <= 1e-9 * abs(f_h)
+    assert np.abs(x_d - x_h).max() <= 1e-7 * np.abs(x_h).max()
+    assert f_d <= v.free_energy(x0)
+    # one forward-backward evaluation less per accepted step than the reference's call pattern
+    assert dev.statistics["f_eval"] <= host.statistics["f_eval"] - np.count_nonzero(np.diff(host.statistics["fx"][:n_it]))
+    # the state left behind belongs to an evaluated point: arg_out can be fetched
+    assert np.isfinite(v.arg_out["mt"]).all()
+
+
+def test_batched_device_scg_equals_independent_runs():
+    """B problems in lock step (different starting points, different convergence histories) == B single runs."""
+    p = build_problem("L63", "RK4", 0.4, 0.01, None)
+    args = (p["model"], p["m0"], p["s0"], p["fwd"], p["bwd"], p["lik"], p["kl0"], p["obs_y"], p["obs_t"])
+    v1 = va.VarGP(*args)
+    x0 = v1.initialization()
+    rng = np.random.default_rng(9)
+    starts = np.stack([x0, x0 + 0.02 * rng.standard_normal(x0.size), x0 + 0.2 * rng.standard_normal(x0.size)])
+    opts = {"max_it": 10, "x_tol": 1e-3, "f_tol": 1e-2}        # loose: the problems stop at different iterations
+    singles = []
+    for s in starts:
+        run = v1.device_scg(dict(opts))
+        singles.append((run(s.copy()), int(run.statistics["MaxIt"][0])))
+    vb = va.VarGP(*args, batch=3)
+    run = vb.device_scg(dict(opts))
+    xb, fb = run(starts.copy())
+    for k, ((xs, fs), its) in enumerate(singles):
+        assert int(run.statistics["MaxIt"][k]) == its
+        assert abs(fb[k] - fs) <= 1e-9 * abs(fs)
+        assert np.abs(xb[k] - xs).max() <= 1e-7 * np.abs(xs).max()

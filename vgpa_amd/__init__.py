@@ -10,9 +10,9 @@ from .dynamics import (StochasticProcess, OrnsteinUhlenbeck, DoubleWell,   # noq
                        Lorenz63, Lorenz96, dynamical_systems)
 from .likelihood import Likelihood, GaussianLikelihood, PriorKL0           # noqa: F401
 from .variational import VarGP                                             # noqa: F401
-from .scg import SCG                                                       # noqa: F401
+from .scg import SCG, DeviceSCG                                            # noqa: F401
 
 __all__ = ["Context", "device_count", "load", "OdeSolver", "Euler", "Heun", "RungeKutta2", "RungeKutta4",
            "num_integration", "FwdOde", "BwdOde", "StochasticProcess", "OrnsteinUhlenbeck", "DoubleWell",
            "Lorenz63", "Lorenz96", "dynamical_systems", "Likelihood", "GaussianLikelihood", "PriorKL0",
-           "VarGP", "SCG"]
+           "VarGP", "SCG", "DeviceSCG"]

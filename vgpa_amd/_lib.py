@@ -25,7 +25,8 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_obs_energy", "vgpa_free_energy", "vgpa_gradient", "vgpa_sweep", "vgpa_energy_parts",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
-           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage"]
+           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev",
+           "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby"]
 
 P_DOUBLE = POINTER(c_double)
 
@@ -93,6 +94,11 @@ def load():
     lib.vgpa_ld_gemm.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_void_p, c_int]
     lib.vgpa_ld_stage.argtypes = [c_void_p, POINTER(LdStageArgs)]
+    lib.vgpa_gradient_dev.argtypes = [c_void_p, c_void_p]
+    lib.vgpa_vec_dot.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]
+    lib.vgpa_vec_absmax.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
+    lib.vgpa_vec_asum.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
+    lib.vgpa_vec_axpby.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vgpa_profile_begin.argtypes = [c_void_p]
     lib.vgpa_profile_end.argtypes = [c_void_p, P_DOUBLE, P_DOUBLE, P_DOUBLE, P_DOUBLE, POINTER(c_int64)]
     if lib.vgpa_abi_version() != ABI_VERSION:
@@ -335,6 +341,37 @@ class Context:
         f = np.empty(self.B)
         self._check(self._lib.vgpa_fetch_f(self._h, _ptr(f)))
         return float(f[0]) if self.B == 1 else f
+
+    def gradient_dev(self, g_buf):
+        self._check(self._lib.vgpa_gradient_dev(self._h, g_buf.ptr))
+
+    # ------------------------------------------------------------------ device vector algebra (SCG)
+    # Every vector is a DeviceBuffer of B segments; scalars are (B,) arrays, one per problem of the batch.
+    def _seglen(self, buf):
+        if buf.count % self.B:
+            raise ValueError(f" vector of {buf.count} doubles does not split into {self.B} problems")
+        return buf.count // self.B
+
+    def _vreduce(self, fn, a, *b):
+        out = np.empty(self.B)
+        self._check(fn(self._h, a.ptr, *[v.ptr for v in b], self._seglen(a), _ptr(out)))
+        return out
+
+    def vdot(self, a, b):
+        return self._vreduce(self._lib.vgpa_vec_dot, a, b)
+
+    def vabsmax(self, a):
+        return self._vreduce(self._lib.vgpa_vec_absmax, a)
+
+    def vasum(self, a):
+        return self._vreduce(self._lib.vgpa_vec_asum, a)
+
+    def vaxpby(self, alpha, x, beta, y, out):
+        """out = alpha*x + beta*y per problem (alpha, beta: scalars or (B,)); y=None drops the second term."""
+        al = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float64), (self.B,)))
+        be = None if y is None else np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (self.B,)))
+        self._check(self._lib.vgpa_vec_axpby(self._h, self._seglen(x), _ptr(al), x.ptr,
+                                             None if y is None else _ptr(be), None if y is None else y.ptr, out.ptr))
 
     def synchronize(self):
         self._check(self._lib.vgpa_synchronize(self._h))

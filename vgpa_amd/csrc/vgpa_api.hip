@@ -33,6 +33,8 @@ struct vgpa_ctx {
   double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
   double* d_ld_ws = nullptr;      // workspace of the large-D drivers
   double* d_lde_ws = nullptr;     // workspace of the large-D energy / gradient kernels
+  double* d_vec_scratch = nullptr; // [2B coefficients | B results | B*bps partials] of the vector algebra
+  size_t vec_scratch_n = 0;
   int lde_nb = 1;
   int64_t* d_obs_t = nullptr;
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
@@ -717,6 +719,52 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
   }
   if (rc) return rc;
   return vgpa_synchronize(c);
+}
+
+int vgpa_gradient_dev(vgpa_ctx* c, double* g_dev) {
+  if (!c || !g_dev) return fail(c, VGPA_ERR_ARG, "null argument");
+  if (!c->have_state) return fail(c, VGPA_ERR_STATE, "gradient(x, eval_fun=False) needs the state cached by a previous free_energy");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = finish_gradient(c, g_dev))) return rc;
+  return check_status(c);
+}
+
+static int vec_scratch(vgpa_ctx* c, uint64_t seglen) {
+  const size_t need = (size_t)c->B * (3 + (size_t)vec_blocks_per_seg((long long)seglen, c->B));
+  if (c->vec_scratch_n >= need) return VGPA_OK;
+  c->vec_scratch_n = (size_t)c->B * (3 + 256);
+  return dev_alloc(c, &c->d_vec_scratch, c->vec_scratch_n);
+}
+static int vec_reduce_host(vgpa_ctx* c, int mode, const double* a, const double* b, uint64_t seglen, double* out) {
+  if (!c || !a || !out || seglen == 0) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = vec_scratch(c, seglen))) return rc;
+  double* red = c->d_vec_scratch + 2 * (size_t)c->B;    // [0,2B) holds the axpby coefficients
+  hipError_t e = vec_reduce(mode, a, b, c->B, (long long)seglen, red, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "vector reduction failed: %s", hipGetErrorString(e));
+  HIP_TRY(c, hipMemcpyAsync(out, red, sizeof(double) * c->B, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VGPA_OK;
+}
+int vgpa_vec_dot(vgpa_ctx* c, const double* a, const double* b, uint64_t seglen, double* out) {
+  if (!b) return fail(c, VGPA_ERR_ARG, "null argument");
+  return vec_reduce_host(c, 0, a, b, seglen, out);
+}
+int vgpa_vec_absmax(vgpa_ctx* c, const double* a, uint64_t seglen, double* out) { return vec_reduce_host(c, 1, a, nullptr, seglen, out); }
+int vgpa_vec_asum(vgpa_ctx* c, const double* a, uint64_t seglen, double* out) { return vec_reduce_host(c, 2, a, nullptr, seglen, out); }
+int vgpa_vec_axpby(vgpa_ctx* c, uint64_t seglen, const double* alpha, const double* x, const double* beta, const double* y, double* out) {
+  if (!c || !alpha || !x || !out || seglen == 0 || ((y != nullptr) != (beta != nullptr))) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = vec_scratch(c, seglen))) return rc;
+  // the coefficient upload is stream-ordered behind the previous axpby, so the slots can be reused
+  HIP_TRY(c, hipMemcpyAsync(c->d_vec_scratch, alpha, sizeof(double) * c->B, hipMemcpyHostToDevice, c->stream));
+  if (beta) HIP_TRY(c, hipMemcpyAsync(c->d_vec_scratch + c->B, beta, sizeof(double) * c->B, hipMemcpyHostToDevice, c->stream));
+  hipError_t e = vec_axpby(c->B, (long long)seglen, c->d_vec_scratch, x, c->d_vec_scratch + c->B, y, out, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "axpby failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
 }
 
 // ---- raw device memory ------------------------------------------------------------------------------

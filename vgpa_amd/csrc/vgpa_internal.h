@@ -124,6 +124,12 @@ hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A
                     double* ws, int nbmax, hipStream_t st);
 }  // namespace ld
 
+// device vector algebra for the SCG driver (vecops.hip), segmented over the batch
+int vec_blocks_per_seg(long long seglen, int nseg);
+hipError_t vec_reduce(int mode, const double* a, const double* b, int nseg, long long seglen, double* scratch, hipStream_t st);
+hipError_t vec_axpby(int nseg, long long seglen, const double* alpha_dev, const double* x, const double* beta_dev,
+                     const double* y, double* out, hipStream_t st);
+
 // tiny host-side dense helpers (row-major, fp64) ---------------------------------------------------
 bool host_cholesky_lower(int n, const double* a, double* l);          // uses the lower triangle of a
 void host_lower_inverse(int n, const double* l, double* linv);

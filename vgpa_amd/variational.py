@@ -17,7 +17,7 @@ from ._lib import Context
 
 class VarGP(object):
 
-    def __init__(self, model, m0, s0, fwd_ode, bwd_ode, likelihood, kl0, obs_y, obs_t, device=0, flags=0) -> None:
+    def __init__(self, model, m0, s0, fwd_ode, bwd_ode, likelihood, kl0, obs_y, obs_t, device=0, flags=0, batch=1) -> None:
         self.model = model
         self.fwd_ode, self.bwd_ode = fwd_ode, bwd_ode
         self.kl0, self.likelihood = kl0, likelihood
@@ -29,7 +29,7 @@ class VarGP(object):
             self.dim_n, self.dim_d = self.model.sample_path.shape
         self.dim_tot = self.dim_n * self.dim_d * self.dim_d
         self.output = {"m0": m0, "s0": s0}
-        self.device, self.flags = device, flags
+        self.device, self.flags, self.batch = device, flags, int(batch)
         self._ctx = None
         self._stale = set()
         method_f = str(getattr(fwd_ode, "method", "")).lower()
@@ -56,7 +56,7 @@ class VarGP(object):
                                 obs_y=np.asarray(lik.values, dtype=float),
                                 obs_noise=np.asarray(lik.noise, dtype=float).reshape(d, d),
                                 obs_h=np.asarray(lik.operator, dtype=float).reshape(d, d),
-                                e0=e0, device=self.device, flags=self.flags)
+                                e0=e0, device=self.device, flags=self.flags, batch=self.batch)
         return self._ctx
 
     def initialization(self):
@@ -101,6 +101,12 @@ class VarGP(object):
         f, g = self._context().sweep(np.asarray(x, dtype=float))
         self._stale = {"mt", "st", "Efx", "Edf", "lamt", "psit"}
         return f, g
+
+    def device_scg(self, *options):
+        """SCG with x, d and the gradients resident in HBM (scg.DeviceSCG); `batch` problems advance in lock step."""
+        from .scg import DeviceSCG
+        self._stale = {"mt", "st", "Efx", "Edf", "lamt", "psit"}
+        return DeviceSCG(self._context(), *options)
 
     @property
     def arg_out(self):
