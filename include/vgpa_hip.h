@@ -67,7 +67,7 @@ enum {
 /* config flags */
 enum {
   VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
-  VGPA_FLAG_PAIR_PROBLEMS = 2  /* experimental: two phase-staggered problems per workgroup in the MFMA steppers */
+  VGPA_FLAG_FOUR_WAVES = 2     /* diagnostics: MFMA steppers with four waves per problem where eight are the default */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;

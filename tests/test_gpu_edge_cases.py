@@ -3,7 +3,7 @@ GPU suite (-m gpu): edge cases of the hot path through the C ABI, all against th
   * every block geometry of the MFMA steppers and of the wave-level energy kernel: D = 10 ... 64
   * dense (non-diagonal) system noise Sigma, dense observation noise R, non-identity observation operator H
   * shortest grids (Np = 2, 3), a single observation, observations at the first / last index
-  * odd batches, the experimental paired-problem variant, very small dt
+  * odd batches, the four-waves-per-problem variant of the MFMA steppers, very small dt
 """
 import numpy as np
 import pytest
@@ -15,7 +15,7 @@ from oracle import vgpa_oracle as vo
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
-FLAG_PAIR = 2
+FLAG_FOUR_WAVES = 2
 
 
 def spd(rng, d, scale=1.0, jitter=0.3):
@@ -105,7 +105,7 @@ def test_all_steppers_double_well_and_small_dt(method):
     check(p, x)
 
 
-@pytest.mark.parametrize("flags", [0, FLAG_PAIR])
+@pytest.mark.parametrize("flags", [0, FLAG_FOUR_WAVES])
 def test_odd_batches(flags):
     p, x = make_problem("L96", 12, 20)
     ctx = gpu_context(p, batch=5, flags=flags)

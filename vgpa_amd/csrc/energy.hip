@@ -578,7 +578,10 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_energy_l63, grid, dim3(64), 0, st, a);
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
-    const size_t lds = l96_lds_doubles(a.D) * sizeof(double);
+    size_t lds = l96_lds_doubles(a.D) * sizeof(double);
+#ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
+    lds += VGPA_L96_LDSPAD;
+#endif
     const long long nwaves = (long long)a.Np * a.batch;
     if (nwaves > 0x7fffffffLL) return hipErrorInvalidValue;
 #define VGPA_L96_CASE(NBV)                                                                                          \

@@ -28,19 +28,17 @@
 namespace vgpa {
 namespace mfma {
 
-constexpr int NT = 256;   // threads working on one problem
-constexpr int NW = 4;     // waves working on one problem (one per SIMD)
-
-// A workgroup holds ONE problem (256 threads) or TWO (512 threads: waves 0-3 -> problem 2b, waves 4-7 -> problem
-// 2b+1, phase-staggered, see k_fwd_mfma).  Everything below addresses threads through these problem-local ids.
-__device__ __forceinline__ int ltid() { return threadIdx.x & (NT - 1); }
-__device__ __forceinline__ int lwave() { return (threadIdx.x >> 6) & (NW - 1); }
-__device__ __forceinline__ int lhalf() { return threadIdx.x >> 8; }
+// A problem is integrated by ONE workgroup of NW waves: NW = 4 puts one wave on each SIMD of the CU; NW = 8 puts two,
+// so that while one wave of a SIMD sits in the LDS exchange / element-wise part of a stage the other one can issue
+// MFMAs (a lone wave per SIMD has nothing to hide its LDS and barrier latencies behind), and each lane owns half as
+// many matrix elements, which keeps the kernel inside the 256-register budget of two waves per SIMD.
+__device__ __forceinline__ int ltid() { return threadIdx.x; }
+__device__ __forceinline__ int lwave() { return threadIdx.x >> 6; }
 
 // Diagnostic build only (tools/ubench/ode_stamp.hip): per-segment cycle sums of one wave.  Never defined in the
 // product build, so no stamp executes there.
 #ifdef VGPA_STAMPS
-__device__ long long g_stamp[4][16];
+__device__ long long g_stamp[8][16];
 __device__ long long g_clk[4];   // s_memtime / s_memrealtime at kernel start and end (block 0, thread 0)
 #define VGPA_STAMP(i)                                                                         \
   do {                                                                                        \
@@ -71,26 +69,31 @@ struct WaveDeal { int uA, nA, gA, uB, nB, gB; };   // first unit / count / group
 
 __host__ __device__ constexpr int deal_group_size(int nb, int nq, int nleft, int g) { return g < nq ? nb : (g == nq ? nleft : 0); }
 
-// Returns the deal of wave `want` (0..3); *done = all units dealt after four waves.
-__host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int maxu, int want, bool* done) {
+// Returns the deal of wave `want` (0..nw-1); *done = all units were dealt.  Every wave aims at an even share of what is
+// left (ceil(remaining units / remaining waves), at most maxu), so the matrix-core work of the SIMDs is balanced.
+__host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int maxu, int nw, int want, bool* done) {
   const int ngroups = nq + (nleft ? 1 : 0);
   const int s1 = maxu / 2, s2 = maxu - s1;
   int g = 0, off = 0;
+  int left = nb * nq + nleft;
   WaveDeal res{0, 0, 0, 0, 0, 0};
-  for (int w = 0; w < 4; w++) {
+  for (int w = 0; w < nw; w++) {
     WaveDeal d{0, 0, 0, 0, 0, 0};
+    int quota = (left + (nw - w) - 1) / (nw - w);
+    quota = quota < maxu ? quota : maxu;
     while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
-    if (g < ngroups) {
+    if (g < ngroups && quota > 0) {
       const int rem = deal_group_size(nb, nq, nleft, g) - off;
-      const int a = rem < maxu ? rem : maxu;
+      const int a = rem < quota ? rem : quota;
       if (a <= s1 || a <= s2) {
         const bool first_in_a = a <= s1;
         const int u_first = g * nb + off, g_first = g;
         off += a;
         while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
         int b = 0, u_second = 0, g_second = g_first;
-        if (g < ngroups) {
-          const int cap = first_in_a ? s2 : s1;
+        if (g < ngroups && a < quota) {
+          int cap = first_in_a ? s2 : s1;
+          cap = cap < quota - a ? cap : quota - a;
           const int rem2 = deal_group_size(nb, nq, nleft, g) - off;
           b = rem2 < cap ? rem2 : cap;
           u_second = g * nb + off; g_second = g;
@@ -104,35 +107,37 @@ __host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int
         off += a;
       }
     }
+    left -= d.nA + d.nB;
     if (w == want) res = d;
   }
-  while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
-  if (done) *done = (g >= ngroups);
+  if (done) *done = (left == 0);
   return res;
 }
 
-__host__ __device__ constexpr bool deal_fits(int nb, int nq, int nleft, int maxu) {
+__host__ __device__ constexpr bool deal_fits(int nb, int nq, int nleft, int maxu, int nw) {
   bool ok = false;
-  (void)deal_units(nb, nq, nleft, maxu, 0, &ok);
+  (void)deal_units(nb, nq, nleft, maxu, nw, 0, &ok);
   return ok;
 }
 
-__host__ __device__ constexpr int deal_min_slots(int nb, int nq, int nleft, int nu) {
-  int m = (nu + 3) / 4;
-  while (!deal_fits(nb, nq, nleft, m)) m++;
+__host__ __device__ constexpr int deal_min_slots(int nb, int nq, int nleft, int nu, int nw) {
+  int m = (nu + nw - 1) / nw;
+  while (!deal_fits(nb, nq, nleft, m, nw)) m++;
   return m;
 }
 
 // Compile-time geometry of the padded problem: NB = ceil(D/4) 4x4 blocks per dimension.
-template <int NB_>
+template <int NB_, int NW_>
 struct Geo {
   static constexpr int NB = NB_;
+  static constexpr int NW = NW_;                           // waves per problem
+  static constexpr int NT = 64 * NW_;                      // threads per problem
   static constexpr int NQ = NB / 4;                       // full 16-column groups
   static constexpr int REM = NB % 4;                      // left-over column blocks per block-row
   static constexpr int G = REM ? 4 / REM : 0;             // block-rows packed into one left-over unit
   static constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
   static constexpr int NU = NB * NQ + NLEFT;              // units (MFMA accumulators) per product
-  static constexpr int MAXU = deal_min_slots(NB, NQ, NLEFT, NU);   // unit slots per wave (>= ceil(NU/4))
+  static constexpr int MAXU = deal_min_slots(NB, NQ, NLEFT, NU, NW);   // unit slots per wave (>= ceil(NU/NW))
   static constexpr int S1 = MAXU / 2;                     // slots [0,S1) use B fragment 0, slots [S1,MAXU) fragment 1
   static constexpr int P = 4 * NB;                        // padded dimension
   // LDS operand layouts ("k-pair interleaved"): element (k, c) of an operand matrix sits at
@@ -155,7 +160,7 @@ struct Geo {
 // offset of element (k, c) in a k-pair interleaved operand matrix with leading dimension LD
 __host__ __device__ constexpr int pair_off(int k, int c, int LD) { return ((k >> 3) * 4 + (k & 3)) * LD + 2 * c + ((k >> 2) & 1); }
 
-template <int NB>
+template <int NB, int NW>
 struct Lds {
   double* X;     // [ROWS][LDX]  stage state (k-pair interleaved)
   double* W;     // [P][LDW]     exchange buffer for W^T
@@ -166,15 +171,15 @@ struct Lds {
   double* pv;    // [NW][P]      partial mat-vec sums
   double* trash; // [NT]         write/read target of lanes that own no matrix element in a slot
   __device__ __forceinline__ void carve(double* smem) {
-    using g = Geo<NB>;
+    using g = Geo<NB, NW>;
     X = smem; W = X + g::ROWS * g::LDX; A0 = W + g::P * g::LDW; AM = A0 + g::ROWS * g::LDA;
     A1 = AM + g::ROWS * g::LDA; xv = A1 + g::ROWS * g::LDA; pv = xv + 2 * g::P; trash = pv + NW * g::P;
   }
 };
 
-template <int NB>
+template <int NB, int NW>
 struct Tab {
-  static constexpr int MAXU = Geo<NB>::MAXU;
+  static constexpr int MAXU = Geo<NB, NW>::MAXU;
   int colA[MAXU];   // 2*(4*I_b + (l&3))
   int colB0, colB1; // B-fragment columns of the group feeding slots [0,S1) / slots [S1,MAXU)
   int offWw[MAXU];  // row*LDW + col
@@ -184,12 +189,12 @@ struct Tab {
   unsigned valid;   // per-lane bit s: this lane owns a real matrix element in slot s
 };
 
-template <int NB>
-__device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
-  using g = Geo<NB>;
+template <int NB, int NW>
+__device__ __forceinline__ void build_tab(int D, Tab<NB, NW>& T) {
+  using g = Geo<NB, NW>;
   const int lane = threadIdx.x & 63, wave = lwave();
   const int b = (lane >> 2) & 3, r4 = lane >> 4, c4 = lane & 3;
-  const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, wave, nullptr);
+  const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, NW, wave, nullptr);
   constexpr int rem = g::REM ? g::REM : 1;
   auto group_col = [&](int grp) { return (grp < g::NQ) ? (16 * grp + (lane & 15)) : (4 * (4 * g::NQ + b % rem) + c4); };
   T.colB0 = 2 * group_col(deal.gA);      // (doubles; the pair layout stores two k-steps per column)
@@ -234,10 +239,10 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB>& T) {
 // Straight-line code: KKE k-steps, fragments of step kk+1 are loaded while the MFMAs of step kk issue.
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-template <int NB, int LDAOP>
+template <int NB, int NW, int LDAOP>
 __device__ __forceinline__ void mfma_product(const double* __restrict__ Aop, const double* __restrict__ X,
-                                             const Tab<NB>& T, double (&w)[Geo<NB>::MAXU]) {
-  using g = Geo<NB>;
+                                             const Tab<NB, NW>& T, double (&w)[Geo<NB, NW>::MAXU]) {
+  using g = Geo<NB, NW>;
   constexpr int MAXU = g::MAXU, NP = g::KKE / 2;
   const int r4 = (threadIdx.x & 63) >> 4;
   const double* pa = Aop + r4 * LDAOP;
@@ -271,42 +276,44 @@ __device__ __forceinline__ void mfma_product(const double* __restrict__ Aop, con
   }
 }
 
-// partial mat-vec of this wave (k-range = its quarter of the padded dimension, P = 4*NB = NW*NB; padding rows and
-// padding entries of xv are zero): forward sum_k Aop[k][i] v[k], backward sum_k Aop[i][k] v[k].  Branch-free.
-template <int NB, bool FWD>
+// partial mat-vec of this wave: the NW waves split the padded k range [0, 4*KKE) into NW equal pieces (padding rows
+// of the operand and padding entries of xv are zero): forward sum_k Aop[k][i] v[k], backward sum_k Aop[i][k] v[k].
+// Branch-free.
+template <int NB, int NW, bool FWD>
 __device__ __forceinline__ double matvec_partial(const double* __restrict__ Aop, const double* __restrict__ xv) {
-  using g = Geo<NB>;
-  static_assert(NW * NB == g::P, "the four waves split the padded k range evenly");
+  using g = Geo<NB, NW>;
+  constexpr int KQ = (4 * g::KKE) / NW;
+  static_assert(KQ * NW == 4 * g::KKE, "the waves split the padded k range evenly");
   const int lane = threadIdx.x & 63, wave = lwave();
-  const int k0 = wave * NB;
+  const int k0 = wave * KQ;
   const int li = (lane < g::P) ? lane : 0;
-  double av[NB], xk[NB];
+  double av[KQ], xk[KQ];
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
+  for (int k = 0; k < KQ; k++) {
     av[k] = FWD ? Aop[pair_off(k0 + k, li, g::LDA)] : Aop[pair_off(li, k0 + k, g::LDA)];
     xk[k] = xv[k0 + k];
   }
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < NB; k++) s = __builtin_fma(av[k], xk[k], s);
+  for (int k = 0; k < KQ; k++) s = __builtin_fma(av[k], xk[k], s);
   return s;
 }
 
 // Products of one stage + the LDS exchange.  On return: w = own W element, wt = W^T element, vsum = (Aop-matvec)
 // for lanes < D of wave 0.  Contains ONE barrier.
-template <int NB, bool FWD, int LDAOP>
-__device__ __forceinline__ void stage_products(const Lds<NB>& L, int D, const double* Aop, const Tab<NB>& T,
-                                               const double* Avec, double (&w)[Geo<NB>::MAXU],
-                                               double (&wt)[Geo<NB>::MAXU], double& vsum VGPA_STAMP_ARG) {
-  using g = Geo<NB>;
+template <int NB, int NW, bool FWD, int LDAOP>
+__device__ __forceinline__ void stage_products(const Lds<NB, NW>& L, int D, const double* Aop, const Tab<NB, NW>& T,
+                                               const double* Avec, double (&w)[Geo<NB, NW>::MAXU],
+                                               double (&wt)[Geo<NB, NW>::MAXU], double& vsum VGPA_STAMP_ARG) {
+  using g = Geo<NB, NW>;
   const int lane = threadIdx.x & 63, wave = lwave();
   VGPA_STAMP(0);                       // elementwise work since the last publish
-  mfma_product<NB, LDAOP>(Aop, L.X, T, w);
+  mfma_product<NB, NW, LDAOP>(Aop, L.X, T, w);
   VGPA_STAMP(1);                       // MFMA product
 #if defined(VGPA_ABL_NOMATVEC)
   const double part = 0.0;                                          // timing-only ablation (wrong results)
 #else
-  const double part = matvec_partial<NB, FWD>(Avec, L.xv);
+  const double part = matvec_partial<NB, NW, FWD>(Avec, L.xv);
 #endif
   VGPA_STAMP(2);                       // mat-vec
 #if defined(VGPA_ABL_NOXCHG)
@@ -324,18 +331,21 @@ __device__ __forceinline__ void stage_products(const Lds<NB>& L, int D, const do
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) wt[s] = L.X[T.offWr[s]];
   vsum = 0.0;
-  if (wave == 0 && lane < D)
-    vsum = ((L.pv[lane] + L.pv[g::P + lane]) + L.pv[2 * g::P + lane]) + L.pv[3 * g::P + lane];
+  if (wave == 0 && lane < D) {
+    vsum = L.pv[lane];
+#pragma unroll
+    for (int q = 1; q < NW; q++) vsum += L.pv[q * g::P + lane];
+  }
   VGPA_STAMP(5);                       // W^T / pv loads
 }
 
 // publish the next stage state (matrix elements owned by this lane + vector entries of wave 0).  ONE barrier.
-template <int NB>
-__device__ __forceinline__ void publish(const Lds<NB>& L, int D, const Tab<NB>& T,
-                                        const double (&xn)[Geo<NB>::MAXU], double vn VGPA_STAMP_ARG) {
+template <int NB, int NW>
+__device__ __forceinline__ void publish(const Lds<NB, NW>& L, int D, const Tab<NB, NW>& T,
+                                        const double (&xn)[Geo<NB, NW>::MAXU], double vn VGPA_STAMP_ARG) {
   VGPA_STAMP(6);                       // elementwise work of the stage
 #pragma unroll
-  for (int s = 0; s < Geo<NB>::MAXU; s++) L.X[T.offX[s]] = xn[s];
+  for (int s = 0; s < Geo<NB, NW>::MAXU; s++) L.X[T.offX[s]] = xn[s];
   if (lwave() == 0 && (threadIdx.x & 63) < D) L.xv[threadIdx.x & 63] = vn;
   VGPA_STAMP(7);                       // X stores
 #if !defined(VGPA_ABL_NOBARB)
@@ -345,52 +355,49 @@ __device__ __forceinline__ void publish(const Lds<NB>& L, int D, const Tab<NB>& 
 }
 
 // A(t) from HBM into registers, coalesced (thread e <-> A[e / D][e % D])
-template <int NB>
-__device__ __forceinline__ void load_a(const double* __restrict__ A, int DD, double (&a)[Geo<NB>::EPT]) {
+template <int NB, int NW>
+__device__ __forceinline__ void load_a(const double* __restrict__ A, int DD, double (&a)[Geo<NB, NW>::EPT]) {
 #pragma unroll
-  for (int q = 0; q < Geo<NB>::EPT; q++) {
-    const int e = ltid() + q * NT;
+  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
+    const int e = ltid() + q * Geo<NB, NW>::NT;
     a[q] = (e < DD) ? A[e] : 0.0;
   }
 }
 
 // registers -> LDS operand buffer: forward stores A^T (Aop[c][r] = A[r][c]), backward stores A.
-template <int NB, bool FWD, bool MID>
-__device__ __forceinline__ void store_a(double* __restrict__ buf, int D, const int (&aofs)[Geo<NB>::EPT],
-                                        const double (&a0)[Geo<NB>::EPT], const double (&a1)[Geo<NB>::EPT]) {
+template <int NB, int NW, bool FWD, bool MID>
+__device__ __forceinline__ void store_a(double* __restrict__ buf, int D, const int (&aofs)[Geo<NB, NW>::EPT],
+                                        const double (&a0)[Geo<NB, NW>::EPT], const double (&a1)[Geo<NB, NW>::EPT]) {
 #pragma unroll
-  for (int q = 0; q < Geo<NB>::EPT; q++) {
+  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
     if (aofs[q] >= 0) buf[aofs[q]] = MID ? 0.5 * (a0[q] + a1[q]) : a0[q];
   }
   (void)D;
 }
 
-template <int NB, bool FWD>
-__device__ __forceinline__ void build_aofs(int D, int (&aofs)[Geo<NB>::EPT]) {
-  using g = Geo<NB>;
+template <int NB, int NW, bool FWD>
+__device__ __forceinline__ void build_aofs(int D, int (&aofs)[Geo<NB, NW>::EPT]) {
+  using g = Geo<NB, NW>;
 #pragma unroll
   for (int q = 0; q < g::EPT; q++) {
-    const int e = ltid() + q * NT;
+    const int e = ltid() + q * Geo<NB, NW>::NT;
     const int r = e / D, c = e - r * D;
     aofs[q] = (e < D * D) ? (FWD ? pair_off(c, r, g::LDA) : pair_off(r, c, g::LDA)) : -1;
   }
 }
 
 // =================================================================================================================
-template <int METHOD, int NB, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
+template <int METHOD, int NB, int NW>
+__global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using g = Geo<NB>;
+  using g = Geo<NB, NW>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
   const int D = a.D, DD = D * D, Np = a.Np;
-  // PAIR: two problems per workgroup.  Half 1 runs ONE barrier behind half 0, so that while one problem is in the
-  // LDS-exchange / elementwise part of a stage (matrix pipe idle) the other one issues its MFMAs on the same SIMDs.
-  const int half = PAIR ? lhalf() : 0;
-  const int prob_raw = PAIR ? (2 * (int)blockIdx.x + half) : (int)blockIdx.x;
-  const int prob = prob_raw < a.batch ? prob_raw : a.batch - 1;   // odd batch: the spare half redoes the last problem
+  constexpr int NT = g::NT;
+  const int prob = (int)blockIdx.x;
   const int tid = ltid(), lane = tid & 63, wave = lwave();
-  double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
-  Lds<NB> L;
+  double* lds_base = smem;
+  Lds<NB, NW> L;
   L.carve(lds_base);
   const double* A = a.A + (size_t)prob * a.strideA;
   const double* bb = a.b + (size_t)prob * a.strideB;
@@ -403,10 +410,10 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
 #ifdef VGPA_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 0) { g_clk[0] = __builtin_amdgcn_s_memtime(); g_clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-  Tab<NB> T;
-  build_tab<NB>(D, T);
+  Tab<NB, NW> T;
+  build_tab<NB, NW>(D, T);
   int aofs[EPT];
-  build_aofs<NB, true>(D, aofs);
+  build_aofs<NB, NW, true>(D, aofs);
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
@@ -423,14 +430,13 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
     L.X[T.offX[s]] = sk[s];
   }
   if (vlane) { mk = a.m0[lane]; mt[lane] = mk; L.xv[lane] = mk; }
-  load_a<NB>(A, DD, aC);
-  store_a<NB, true, false>(L.A0, D, aofs, aC, aC);
-  if (Np > 1) load_a<NB>(A + DD, DD, aN);
+  load_a<NB, NW>(A, DD, aC);
+  store_a<NB, NW, true, false>(L.A0, D, aofs, aC, aC);
+  if (Np > 1) load_a<NB, NW>(A + DD, DD, aN);
   // offset vectors: b0 = b_k, b1 = b_{k+1}; b_{k+2} is fetched one step ahead (HBM latency off the critical path)
   double b0 = vlane ? bb[lane] : 0.0;
   double b1 = (vlane && Np > 1) ? bb[D + lane] : 0.0;
   __syncthreads();
-  if (PAIR && half == 1) __syncthreads();          // stagger: half 1 trails by one barrier
 
   for (int k = 0; k < Np - 1; k++) {
     // S_k, m_k of the previous iteration go to HBM here, right behind the operand loads they follow in the memory
@@ -446,61 +452,61 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
 #endif
     // operands of this step: A1 <- A_{k+1}, AM <- mid-point; prefetch A_{k+2} for the next step
 #if !defined(VGPA_ABL_NOSTAGE)
-    store_a<NB, true, false>(L.A1, D, aofs, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, true, true>(L.AM, D, aofs, aC, aN);
+    store_a<NB, NW, true, false>(L.A1, D, aofs, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true, true>(L.AM, D, aofs, aC, aN);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
-    if (k + 2 < Np) load_a<NB>(A + (size_t)(k + 2) * DD, DD, aN);
+    if (k + 2 < Np) load_a<NB, NW>(A + (size_t)(k + 2) * DD, DD, aN);
 #endif
     const double b2 = (vlane && k + 2 < Np) ? bb[(size_t)(k + 2) * D + lane] : 0.0;
     double mnew = 0.0;
 
     if (METHOD == VGPA_ODE_EULER) {
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + ((-w[s] - wt[s]) + sig[s]) * dt;
       mnew = mk + (-vs + b0) * dt;
     } else if (METHOD == VGPA_ODE_HEUN) {
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pm = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + acc1[s] * dt; }
-      publish<NB>(L, D, T, xn, mk + pm * dt VGPA_STAMP_PASS);
-      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, mk + pm * dt VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double cm = -vs + b1;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + h * (acc1[s] + ((-w[s] - wt[s]) + sig[s]));
       mnew = mk + h * (pm + cm);
     } else if (METHOD == VGPA_ODE_RK2) {
       // covariance predictor: S_k stands in for A_k (Q2): operand = X itself (S symmetric); mean predictor: A_k
-      stage_products<NB, true, g::LDX>(L, D, L.X, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDX>(L, D, L.X, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pm = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) xn[s] = sk[s] + h * ((-w[s] - wt[s]) + sig[s]);
-      publish<NB>(L, D, T, xn, mk + h * pm VGPA_STAMP_PASS);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, mk + h * pm VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double cm = -vs + 0.5 * (b0 + b1);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) sk[s] = sk[s] + dt * ((-w[s] - wt[s]) + sig[s]);
       mnew = mk + dt * cm;
     } else {  // RK4
       const double bmid = 0.5 * (b0 + b1);
-      stage_products<NB, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double k1 = -vs + b0;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + h * acc1[s]; }
-      publish<NB>(L, D, T, xn, mk + h * k1 VGPA_STAMP_PASS);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, mk + h * k1 VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k2 = -vs + bmid;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc2[s] = (-w[s] - wt[s]) + sig[s]; xn[s] = sk[s] + h * acc2[s]; }
-      publish<NB>(L, D, T, xn, mk + h * k2 VGPA_STAMP_PASS);
-      stage_products<NB, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, mk + h * k2 VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k3 = -vs + bmid;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { r[s] = (-w[s] - wt[s]) + sig[s]; acc2[s] = acc2[s] + r[s]; xn[s] = sk[s] + dt * r[s]; }
-      publish<NB>(L, D, T, xn, mk + dt * k3 VGPA_STAMP_PASS);
-      stage_products<NB, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, mk + dt * k3 VGPA_STAMP_PASS);
+      stage_products<NB, NW, true, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double k4 = -vs + b1;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -510,12 +516,11 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
       mnew = mk + dt * (k1 + 2.0 * (k2 + k3) + k4) / 6.0;
     }
     mk = mnew;
-    publish<NB>(L, D, T, sk, mk VGPA_STAMP_PASS);
+    publish<NB, NW>(L, D, T, sk, mk VGPA_STAMP_PASS);
     // rotate operand buffers: A_{k+1} becomes the start-point operand of the next step
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     b0 = b1; b1 = b2;
   }
-  if (PAIR && half == 0) __syncthreads();          // matches the extra barrier of half 1
   if (Np > 1) {
     double* so = st + (size_t)(Np - 1) * DD;
 #pragma unroll
@@ -529,20 +534,17 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_fwd_mfma(OdeArgs a) {
 }
 
 // =================================================================================================================
-template <int METHOD, int NB, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
+template <int METHOD, int NB, int NW>
+__global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using g = Geo<NB>;
+  using g = Geo<NB, NW>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
   const int D = a.D, DD = D * D, Np = a.Np;
-  // PAIR: two problems per workgroup.  Half 1 runs ONE barrier behind half 0, so that while one problem is in the
-  // LDS-exchange / elementwise part of a stage (matrix pipe idle) the other one issues its MFMAs on the same SIMDs.
-  const int half = PAIR ? lhalf() : 0;
-  const int prob_raw = PAIR ? (2 * (int)blockIdx.x + half) : (int)blockIdx.x;
-  const int prob = prob_raw < a.batch ? prob_raw : a.batch - 1;   // odd batch: the spare half redoes the last problem
+  constexpr int NT = g::NT;
+  const int prob = (int)blockIdx.x;
   const int tid = ltid(), lane = tid & 63, wave = lwave();
-  double* lds_base = smem + (size_t)half * g::LDS_DOUBLES;
-  Lds<NB> L;
+  double* lds_base = smem;
+  Lds<NB, NW> L;
   L.carve(lds_base);
   const double* A = a.A + (size_t)prob * a.strideA;
   const double* gm = a.dEm + (size_t)prob * Np * D;
@@ -553,10 +555,10 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
   const bool vlane = (wave == 0) && (lane < D);
 
   VGPA_STAMP_DECL;
-  Tab<NB> T;
-  build_tab<NB>(D, T);
+  Tab<NB, NW> T;
+  build_tab<NB, NW>(D, T);
   int aofs[EPT];
-  build_aofs<NB, false>(D, aofs);
+  build_aofs<NB, NW, false>(D, aofs);
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
@@ -574,9 +576,9 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
     if (ok) psi[(size_t)(Np - 1) * DD + T.gofs[s]] = 0.0;
   }
   if (vlane) lam[(size_t)(Np - 1) * D + lane] = 0.0;
-  load_a<NB>(A + (size_t)(Np - 1) * DD, DD, aC);
-  store_a<NB, false, false>(L.A0, D, aofs, aC, aC);
-  if (Np > 1) load_a<NB>(A + (size_t)(Np - 2) * DD, DD, aN);
+  load_a<NB, NW>(A + (size_t)(Np - 1) * DD, DD, aC);
+  store_a<NB, NW, false, false>(L.A0, D, aofs, aC, aC);
+  if (Np > 1) load_a<NB, NW>(A + (size_t)(Np - 2) * DD, DD, aN);
   // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
   double g0 = vlane ? gm[(size_t)(Np - 1) * D + lane] : 0.0;
   double g1 = (vlane && Np > 1) ? gm[(size_t)(Np - 2) * D + lane] : 0.0;
@@ -587,7 +589,6 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
     else if (vlane && n_obs_cur >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_cur) * D + lane];
   }
   __syncthreads();
-  if (PAIR && half == 1) __syncthreads();          // stagger: half 1 trails by one barrier
 
   for (int t = Np - 1; t > 0; t--) {
     // Psi_t, lam_t of the previous iteration go to HBM here (see the forward kernel)
@@ -598,11 +599,11 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
         if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
       if (vlane) lam[(size_t)t * D + lane] = lk;
     }
-    store_a<NB, false, false>(L.A1, D, aofs, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, false, true>(L.AM, D, aofs, aN, aC);
+    store_a<NB, NW, false, false>(L.A1, D, aofs, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, false, true>(L.AM, D, aofs, aN, aC);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
-    if (t >= 2) load_a<NB>(A + (size_t)(t - 2) * DD, DD, aN);
+    if (t >= 2) load_a<NB, NW>(A + (size_t)(t - 2) * DD, DD, aN);
     const double g2 = (vlane && t >= 2) ? gm[(size_t)(t - 2) * D + lane] : 0.0;   // for the next step
     const int n_obs_next = (!a.js_dense && a.obs_idx && t >= 2) ? a.obs_idx[t - 2] : -1;
     double jm_next = 0.0;
@@ -623,48 +624,48 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
     double lnew = 0.0;
 
     if (METHOD == VGPA_ODE_EULER) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - ((-gC[s] + wt[s]) + w[s]) * dt + js[s];
       lnew = lk - (-g0 + vs) * dt + jm;
     } else if (METHOD == VGPA_ODE_HEUN) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pl = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-gC[s] + wt[s]) + w[s]; xn[s] = pk[s] - acc1[s] * dt; }
-      publish<NB>(L, D, T, xn, lk - pl * dt VGPA_STAMP_PASS);
-      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, lk - pl * dt VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double cl = -g1 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - h * (acc1[s] + ((-gN[s] + wt[s]) + w[s])) + js[s];
       lnew = lk - h * (pl + cl) + jm;
     } else if (METHOD == VGPA_ODE_RK2) {
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double pl = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) xn[s] = pk[s] - h * ((-gC[s] + wt[s]) + w[s]);
-      publish<NB>(L, D, T, xn, lk - h * pl VGPA_STAMP_PASS);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, lk - h * pl VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double cl = -(0.5 * (g1 + g0)) + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) pk[s] = pk[s] - dt * ((-(0.5 * (gN[s] + gC[s])) + wt[s]) + w[s]) + js[s];
       lnew = lk - dt * cl + jm;
     } else {  // RK4
       const double gmid = 0.5 * (g1 + g0);
-      stage_products<NB, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A0, T, L.A0, w, wt, vs VGPA_STAMP_PASS);
       const double k1 = -g0 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) { acc1[s] = (-gC[s] + wt[s]) + w[s]; xn[s] = pk[s] - h * acc1[s]; }
-      publish<NB>(L, D, T, xn, lk - h * k1 VGPA_STAMP_PASS);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, lk - h * k1 VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k2 = -gmid + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
         acc2[s] = (-(0.5 * (gN[s] + gC[s])) + wt[s]) + w[s];
         xn[s] = pk[s] - h * acc2[s];
       }
-      publish<NB>(L, D, T, xn, lk - h * k2 VGPA_STAMP_PASS);
-      stage_products<NB, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, lk - h * k2 VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.AM, T, L.AM, w, wt, vs VGPA_STAMP_PASS);
       const double k3 = -gmid + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -672,8 +673,8 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
         acc2[s] = acc2[s] + r[s];
         xn[s] = pk[s] - dt * r[s];
       }
-      publish<NB>(L, D, T, xn, lk - dt * k3 VGPA_STAMP_PASS);
-      stage_products<NB, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
+      publish<NB, NW>(L, D, T, xn, lk - dt * k3 VGPA_STAMP_PASS);
+      stage_products<NB, NW, false, g::LDA>(L, D, L.A1, T, L.A1, w, wt, vs VGPA_STAMP_PASS);
       const double k4 = -g1 + vs;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) {
@@ -688,11 +689,10 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
       gC[s] = gN[s];
       gN[s] = (((T.valid >> s) & 1u) && t >= 2) ? gs[(size_t)(t - 2) * DD + T.gofs[s]] : 0.0;
     }
-    publish<NB>(L, D, T, pk, lk VGPA_STAMP_PASS);
+    publish<NB, NW>(L, D, T, pk, lk VGPA_STAMP_PASS);
     double* tmp = L.A0; L.A0 = L.A1; L.A1 = tmp;
     g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
   }
-  if (PAIR && half == 0) __syncthreads();          // matches the extra barrier of half 1
   if (Np > 1) {
     double* po = psi;
 #pragma unroll
@@ -702,25 +702,24 @@ __global__ void __launch_bounds__(PAIR ? 2 * NT : NT) k_bwd_mfma(OdeArgs a) {
   }
 }
 
-template <int METHOD, bool FWD, int NB, bool PAIR>
-hipError_t launch_nb_p(const OdeArgs& a, hipStream_t st) {
-  constexpr size_t lds = (PAIR ? 2 : 1) * Geo<NB>::LDS_DOUBLES * sizeof(double);
+template <int METHOD, bool FWD, int NB, int NW>
+hipError_t launch_nb_w(const OdeArgs& a, hipStream_t st) {
+  constexpr size_t lds = Geo<NB, NW>::LDS_DOUBLES * sizeof(double);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = FWD ? k_fwd_mfma<METHOD, NB, PAIR> : k_bwd_mfma<METHOD, NB, PAIR>;
+  auto kern = FWD ? k_fwd_mfma<METHOD, NB, NW> : k_bwd_mfma<METHOD, NB, NW>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int blocks = PAIR ? (a.batch + 1) / 2 : a.batch;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(PAIR ? 2 * NT : NT), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.batch), dim3(64 * NW), lds, st, a);
   return hipGetLastError();
 }
 
-// Two problems per workgroup when the batch can fill the chip that way and both fit in LDS; else one.
+// Eight waves per problem once every wave still gets at least two MFMA units per k-step; four otherwise (or on request).
 template <int METHOD, bool FWD, int NB>
 hipError_t launch_nb(const OdeArgs& a, hipStream_t st) {
-  if constexpr (2 * Geo<NB>::LDS_DOUBLES * sizeof(double) <= 160 * 1024) {
-    if (a.batch >= 2 && !a.no_pair) return launch_nb_p<METHOD, FWD, NB, true>(a, st);
+  if constexpr (Geo<NB, 8>::NU >= 16) {
+    if (!a.four_waves) return launch_nb_w<METHOD, FWD, NB, 8>(a, st);
   }
-  return launch_nb_p<METHOD, FWD, NB, false>(a, st);
+  return launch_nb_w<METHOD, FWD, NB, 4>(a, st);
 }
 
 }  // namespace mfma

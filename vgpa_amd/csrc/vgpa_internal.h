@@ -15,7 +15,7 @@ constexpr int kMaxTheta = 4;
 // Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
 struct OdeArgs {
   int D, Np, batch;
-  int no_pair;           // diagnostics: force one problem per workgroup in the MFMA stepping kernels
+  int four_waves;        // diagnostics: four waves per problem in the MFMA stepping kernels even where eight are used
   size_t strideA, strideB;  // elements between consecutive problems in A / b (x layout: len_x for both)
   double dt;
   // forward
