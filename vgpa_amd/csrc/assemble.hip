@@ -172,6 +172,137 @@ __global__ void __launch_bounds__(NT) k_grad(GradArgs a) {
   }
 }
 
+// ---- the same assembly with the D^3 product Q.S on the fp64 matrix cores (diagonal Sigma^-1, 5 <= D <= 64) ------------
+// One workgroup of four waves per (grid point, problem).  LDS: QT[k][i] = Q[i][k] (the A-operand of
+// v_mfma_f64_4x4x4_4b_f64, which contracts over rows) and Ss[k][j], both with an odd leading dimension.  Wave w owns the
+// block-rows I = w, w+4, ... of the 4x4-blocked result; a "unit" (one accumulator) is block-row I x sixteen columns,
+// and the left-over column blocks of REM-wide rows are packed G block-rows per unit (same scheme as the stepping
+// kernels, ode_mfma_impl.h).  Operand fetches are ~1/7 of the LDS traffic of the scalar inner product, which is what
+// bounded the VALU version; the kernel is left with its HBM streams (A, S, Psi in, gLa out).
+template <int NB>
+__global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int P = 4 * NB, LD = P + 1;
+  constexpr int NQ = NB / 4, REM = NB % 4, G = REM ? 4 / REM : 0;
+  constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
+  constexpr int RW = (NB + 3) / 4;            // block-rows per wave
+  constexpr int LW = (NLEFT + 3) / 4;         // left-over units per wave
+  constexpr int rem = REM ? REM : 1;
+  const int D = a.D, DD = D * D;
+  const int t = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const size_t o = (size_t)prob * a.Np + t;
+  double* QT = smem;              // [P][LD]
+  double* Ss = QT + P * LD;       // [P][LD]
+  double* mv = Ss + P * LD;       // [P]
+  double* rv = mv + P;            // -Ef - A m + b
+  double* uv = rv + P;            // dEb + lam
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
+  const double* bt = a.b + (size_t)prob * a.strideB + (size_t)t * D;
+  const double* St = a.S + o * DD;
+  const double* Pt = a.psi + o * DD;
+  const double* Edf = a.Edf ? a.Edf + o * DD : nullptr;
+  const size_t len_x = (size_t)a.Np * DD + (size_t)a.Np * D;
+  double* gA = a.g + (size_t)prob * len_x + (size_t)t * DD;
+  double* gB = a.g + (size_t)prob * len_x + (size_t)a.Np * DD + (size_t)t * D;
+
+  // all HBM loads of this thread are issued before the first one is consumed
+  constexpr int EPT = (P * P + NT - 1) / NT;
+  double sv[EPT], pv[EPT], av[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; q++) {
+    const int e = tid + q * NT;
+    const bool in = e < DD;
+    sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0; av[q] = in ? At[e] : 0.0;
+  }
+  if (tid < P) { mv[tid] = (tid < D) ? a.m[o * D + tid] : 0.0; uv[tid] = 0.0; }
+  if (D < P) {                                   // zero padding of the operands (rows / columns D..P-1)
+    for (int e = tid; e < P * LD; e += NT) { QT[e] = 0.0; Ss[e] = 0.0; }
+  }
+  __syncthreads();
+  const double s00 = St[0];
+  const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;   // e / D for e < 4096, 5 <= D <= 64
+#pragma unroll
+  for (int q = 0; q < EPT; q++) {
+    const int e = tid + q * NT;
+    if (e < DD) {
+      const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
+      const double ed = Edf ? Edf[e] : edf_entry(a.model, a.theta, D, i, j, mv, s00);
+      Ss[i * LD + j] = sv[q];
+      QT[j * LD + i] = a.isig[i * D + i] * (ed + av[q]) - 2.0 * pv[q];
+    }
+  }
+  if (tid < D) {
+    double s = 0.0;
+    for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
+    const double r = -a.Ef[o * D + tid] - s + bt[tid];
+    const double u = a.isig[tid * D + tid] * r + a.lam[o * D + tid];
+    uv[tid] = u;
+    gB[tid] = a.dt * u;
+  }
+  __syncthreads();
+
+  // ---- Q.S on the matrix cores: acc[q][ii] = block-row (wave + 4 ii), column group q
+  const int r4 = lane >> 4, c4 = lane & 3, b = (lane >> 2) & 3;
+  const double* pa = QT + r4 * LD + c4;
+  const double* pb = Ss + r4 * LD;
+  const int colq = lane & 15;
+  const int coll = 4 * (4 * NQ + b % rem) + c4;
+  double acc[(NQ > 0 ? NQ : 1) * RW], accl[LW > 0 ? LW : 1];
+#pragma unroll
+  for (int u = 0; u < (NQ > 0 ? NQ : 1) * RW; u++) acc[u] = 0.0;
+#pragma unroll
+  for (int u = 0; u < (LW > 0 ? LW : 1); u++) accl[u] = 0.0;
+  int rowoff[RW], leftoff[LW > 0 ? LW : 1];
+#pragma unroll
+  for (int ii = 0; ii < RW; ii++) { const int I = wave + 4 * ii; rowoff[ii] = 4 * (I < NB ? I : NB - 1); }
+#pragma unroll
+  for (int vv = 0; vv < LW; vv++) {
+    const int v = wave + 4 * vv;
+    int ib = (v < NLEFT ? v : NLEFT - 1) * G + b / rem;
+    leftoff[vv] = 4 * (ib < NB ? ib : NB - 1);            // spare block slots read valid memory; result unused
+  }
+#pragma unroll
+  for (int kk = 0; kk < NB; kk++) {
+    double bq[NQ > 0 ? NQ : 1];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) bq[q] = pb[kk * 4 * LD + 16 * q + colq];
+    double bl = 0.0;
+    if (NLEFT > 0) bl = pb[kk * 4 * LD + coll];
+#pragma unroll
+    for (int ii = 0; ii < RW; ii++) {
+      if (NQ > 0) {
+        const double af = pa[kk * 4 * LD + rowoff[ii]];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q * RW + ii] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * RW + ii], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int vv = 0; vv < LW; vv++) {
+      const double af = pa[kk * 4 * LD + leftoff[vv]];
+      accl[vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bl, accl[vv], 0, 0, 0);
+    }
+  }
+  // ---- gLa = dt (Q S - u m^T), straight from the accumulators (16 contiguous doubles per lane group)
+#pragma unroll
+  for (int ii = 0; ii < RW; ii++) {
+    const int I = wave + 4 * ii;
+    const int row = 4 * I + r4;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int col = 16 * q + 4 * b + c4;
+      if (I < NB && row < D && col < D) gA[row * D + col] = a.dt * (acc[q * RW + ii] - uv[row] * mv[col]);
+    }
+  }
+#pragma unroll
+  for (int vv = 0; vv < LW; vv++) {
+    const int v = wave + 4 * vv;
+    const int Ib = v * G + b / rem;
+    const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
+    if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) gA[row * D + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
+  }
+}
+
 // small D (1..4): one thread per grid point, everything in registers
 template <int D>
 __global__ void __launch_bounds__(64) k_grad_small(GradArgs a) {
@@ -256,6 +387,23 @@ hipError_t launch_grad(const GradArgs& a, hipStream_t st) {
     return hipGetLastError();
   }
   if (a.D > kMaxSmallD) return hipErrorInvalidValue;
+  if (a.sigma_diag && !a.scalar_product) {
+    const int nb = (a.D + 3) / 4, P = 4 * nb;
+    const size_t lds = sizeof(double) * (size_t)(2 * P * (P + 1) + 3 * P);
+#define VGPA_GRAD_CASE(NBV)                                                                                          \
+  case NBV:                                                                                                          \
+    if (lds > 48 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)k_grad_mfma<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k_grad_mfma<NBV>, dim3(a.Np, a.batch), dim3(NT), lds, st, a);                                  \
+    return hipGetLastError();
+    switch (nb) {
+      VGPA_GRAD_CASE(2) VGPA_GRAD_CASE(3) VGPA_GRAD_CASE(4) VGPA_GRAD_CASE(5) VGPA_GRAD_CASE(6) VGPA_GRAD_CASE(7)
+      VGPA_GRAD_CASE(8) VGPA_GRAD_CASE(9) VGPA_GRAD_CASE(10) VGPA_GRAD_CASE(11) VGPA_GRAD_CASE(12)
+      VGPA_GRAD_CASE(13) VGPA_GRAD_CASE(14) VGPA_GRAD_CASE(15) VGPA_GRAD_CASE(16)
+      default: break;
+    }
+#undef VGPA_GRAD_CASE
+  }
   const int LD = a.D + 1;
   const size_t lds = sizeof(double) * (size_t)((a.sigma_diag ? 2 : 3) * a.D * LD + 3 * a.D);
   if (lds > 48 * 1024)

@@ -265,6 +265,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.strideA = a.strideB = c->len_x;
   a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
+  a.scalar_product = (c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) ? 1 : 0;
   hipError_t e = launch_grad(a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "gradient launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;

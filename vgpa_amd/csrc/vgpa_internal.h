@@ -74,6 +74,7 @@ struct ObsArgs {
 
 struct GradArgs {
   int model, D, Np, batch, sigma_diag;
+  int scalar_product;       // diagnostics: VALU inner products instead of the matrix-core product (VGPA_FLAG_FORCE_GENERIC)
   double dt;
   double theta[kMaxTheta];
   const double* isig;       // [D][D] Sigma^-1
