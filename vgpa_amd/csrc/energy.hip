@@ -422,38 +422,57 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 #if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 2
   return;
 #endif
-  // ---- 3. v_p, lane = sigma point.  chi(p, i) = m_i + sgn_p L[i][r_p]  (p = 0: the mean)
-  for (int pass = 0; pass * 64 < M; pass++) {
-    const int p = pass * 64 + l;
-    const bool pact = p < M;
-    const int pc = pact ? p : 0;
+  // ---- 3. v_p.  Lane j < D evaluates BOTH sigma points of column j (p = 1+j: m + L[:,j] and p = 1+D+j: m - L[:,j]) in
+  //         one sequential pass over i -- they share every LDS operand; the mean point p = 0 is evaluated in parallel
+  //         over i.  chi(p, i) = m_i + sgn_p L[i][col_p]; the flat np.roll of the reference (quirk Q1) makes the
+  //         neighbours at the row ends come from the sigma points p-1 and p+1.
+  double vplus = 0.0, vminus = 0.0, v0 = 0.0;
+  {
     auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
     auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
     auto chi = [&](int q, int i) { return S.mv[i] + sgn_of(q) * S.Lm[i * LD + col_of(q)]; };
-    const int rp = col_of(pc);
-    const double sp = sgn_of(pc);
-    const int pm = wrap(pc - 1, M), pp = wrap(pc + 1, M);
-    // window: xm2 = X(w-2), xm1 = X(w-1), x0 = X(w), x1 = X(w+1) with w = p*D + i (flat, wrapping over M*D)
-    double xm2 = chi(pm, D - 2), xm1 = chi(pm, D - 1), x0 = chi(pc, 0), x1 = (D > 1) ? chi(pc, 1) : chi(pp, 0);
-    double acc = 0.0;
+    const int jc = act ? l : 0;
+    const int pP = 1 + jc, pM = 1 + D + jc;
+    const int pPm = pP - 1, pPp = pP + 1;                         // 0 <= pP-1, pP+1 <= D+1 <= M-1
+    const int pMm = pM - 1, pMp = wrap(pM + 1, M);
+    // windows over the flat index w = p*D + i: xm2 = X(w-2), xm1 = X(w-1), x0 = X(w), x1 = X(w+1)
+    double am2 = chi(pPm, D - 2), am1 = chi(pPm, D - 1), a0 = chi(pP, 0), a1 = chi(pP, 1);
+    double bm2 = chi(pMm, D - 2), bm1 = chi(pMm, D - 1), b0 = chi(pM, 0), b1 = chi(pM, 1);
+    const double* lcol = S.Lm + jc;
+    const double* gcol = S.Gm + jc;
     for (int i = 0; i < D; i++) {
-      const double lin = S.am[i] + sp * S.Gm[i * LD + rp];
-      const double res = ((x1 - xm2) * xm1 - x0 + theta) + lin - S.bv[i];
-      acc = __builtin_fma(S.sg[i], res * res, acc);
-      xm2 = xm1; xm1 = x0; x0 = x1;
+      const double gi = gcol[i * LD], ami = S.am[i], bvi = S.bv[i], sgi = S.sg[i];
+      const double ra = ((a1 - am2) * am1 - a0 + theta) + (ami + gi) - bvi;
+      const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
+      vplus = __builtin_fma(sgi, ra * ra, vplus);
+      vminus = __builtin_fma(sgi, rb * rb, vminus);
+      am2 = am1; am1 = a0; a0 = a1;
+      bm2 = bm1; bm1 = b0; b0 = b1;
       const int in = i + 2;
-      x1 = (in < D) ? chi(pc, in) : chi(pp, in - D);
+      if (in < D) {
+        const double mi = S.mv[in], li2 = lcol[in * LD];
+        a1 = mi + li2; b1 = mi - li2;
+      } else {
+        a1 = chi(pPp, in - D); b1 = chi(pMp, in - D);
+      }
     }
-    if (pact) S.vv[p] = acc;
-
+    // the mean point: lane i holds term i of the sum
+    if (act) {
+      const int i = l;
+      const double xm2 = (i >= 2) ? S.mv[i - 2] : chi(M - 1, D - 2 + i);
+      const double xm1 = (i >= 1) ? S.mv[i - 1] : chi(M - 1, D - 1);
+      const double x1 = (i + 1 < D) ? S.mv[i + 1] : chi(1, 0);
+      const double r0 = ((x1 - xm2) * xm1 - S.mv[i] + theta) + S.am[i] - S.bv[i];
+      v0 = S.sg[i] * (r0 * r0);
+    }
+    v0 = wave_sum(v0);
   }
-  wave_sync();
   const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
-  double e_part = act ? (S.vv[1 + l] + S.vv[1 + D + l]) : 0.0;
-  const double e_t = 0.5 * (w0 * S.vv[0] + w1 * wave_sum(e_part));
+  const double e_part = act ? (vplus + vminus) : 0.0;
+  const double e_t = 0.5 * (w0 * v0 + w1 * wave_sum(e_part));
   if (act) {
-    S.dl[l] = w1 * (S.vv[1 + l] - S.vv[1 + D + l]);
-    S.qq[l] = 0.5 * c * (w1 * (S.vv[1 + l] + S.vv[1 + D + l])) - e_t;
+    S.dl[l] = w1 * (vplus - vminus);
+    S.qq[l] = 0.5 * c * (w1 * (vplus + vminus)) - e_t;
   }
   if (l == 0) a.e_t[o] = e_t;
   wave_sync();
