@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
   }
   if (tid < D) {
     double s = 0.0;
-    for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
+    if (a.Am) s = a.Am[o * D + tid];
+    else for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
     const double r = -a.Ef[o * D + tid] - s + bt[tid];
     const double u = a.isig[tid * D + tid] * r + a.lam[o * D + tid];
     uv[tid] = u;

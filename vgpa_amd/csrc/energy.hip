@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   {
     double s = 0.0;
     for (int k = 0; k < D; k++) s = __builtin_fma(S.Gm[k * LD + li], S.mv[k], s);
-    if (act) S.am[l] = s;
+    if (act) { S.am[l] = s; if (a.Am) a.Am[o * D + l] = s; }
     double acc[WaveGemmGeo<NB>::NU];
     wave_gemm<NB, 0>(S.Gm, S.Lm, LD, acc);
     wave_sync();                                 // every lane is done reading A^T before G overwrites it

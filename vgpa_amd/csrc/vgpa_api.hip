@@ -25,7 +25,7 @@ struct vgpa_ctx {
   // device buffers
   std::vector<void*> allocs;
   const double* xcur = nullptr;   // where the kernels read [A|b] from (d_x or the caller's device buffer)
-  double *d_x = nullptr, *d_m = nullptr, *d_S = nullptr, *d_Ef = nullptr, *d_dEm = nullptr, *d_dEs = nullptr;
+  double *d_x = nullptr, *d_m = nullptr, *d_S = nullptr, *d_Ef = nullptr, *d_dEm = nullptr, *d_dEs = nullptr, *d_Am = nullptr;
   double *d_lam = nullptr, *d_psi = nullptr, *d_g = nullptr, *d_et = nullptr, *d_eobs = nullptr, *d_esde = nullptr;
   double *d_f = nullptr, *d_jm = nullptr, *d_Edf = nullptr, *d_jm_dense = nullptr, *d_js_dense = nullptr;
   double *d_m0 = nullptr, *d_S0 = nullptr, *d_Sigma = nullptr, *d_isig = nullptr, *d_isg = nullptr;
@@ -204,6 +204,7 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
   a.e_t = c->d_et; a.Ef = c->d_Ef; a.Edf = edf; a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.status = c->d_status;
+  a.Am = (c->cfg.model == VGPA_MODEL_L96) ? c->d_Am : nullptr;
   return a;
 }
 
@@ -265,6 +266,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.strideA = a.strideB = c->len_x;
   a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
+  a.Am = c->d_Am;                                  // written by the L96 energy kernel of the same sweep (else null)
   a.scalar_product = (c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) ? 1 : 0;
   hipError_t e = launch_grad(a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "gradient launch failed: %s", hipGetErrorString(e));
@@ -410,6 +412,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   TRY(dev_alloc(c, &c->d_m, BN * D));
   TRY(dev_alloc(c, &c->d_S, BN * DD));
   TRY(dev_alloc(c, &c->d_Ef, BN * D));
+  if (cfg->model == VGPA_MODEL_L96 && D <= kMaxSmallD) TRY(dev_alloc(c, &c->d_Am, BN * D));
   TRY(dev_alloc(c, &c->d_dEm, BN * D));
   TRY(dev_alloc(c, &c->d_dEs, BN * DD));
   TRY(dev_alloc(c, &c->d_lam, BN * D));

@@ -55,6 +55,7 @@ struct EnergyArgs {
   double* Edf;              // [B][Np][D][D] or nullptr
   double* dEm;              // [B][Np][D]
   double* dEs;              // [B][Np][D][D]
+  double* Am;               // [B][Np][D] A_t m_t, a by-product the gradient assembly reuses (L96 kernel; may be nullptr)
   int32_t* status;          // [B] device status word (bit0: S_t not positive definite)
 };
 
@@ -83,6 +84,7 @@ struct GradArgs {
   const double* m; const double* S;
   const double* lam; const double* psi;
   const double* Ef;
+  const double* Am;         // [B][Np][D] A_t m_t left by the energy kernel, or nullptr (then recomputed)
   const double* Edf;        // dense [B][Np][D][D] or nullptr (then recomputed from the model)
   double* g;                // [B][Np*D*D + Np*D]
 };
