@@ -49,6 +49,95 @@ def test_large_d_matches_oracle(method, d, n):
     assert rel_err(lam, lam_o) < TOL and rel_err(psi, psi_o) < TOL
 
 
+class _ThreadComm:
+    """torch.distributed look-alike for `world` virtual ranks living in threads of ONE process that share one GPU:
+    the collectives are barrier-ordered device copies.  Lets the row-sharded HIP kernels (row0 > 0, Mp < D, the packed
+    column-chunk GEMM output) run on a one-GPU box; the RCCL calls themselves are covered by construction
+    (same call sites) and by the gloo test below."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
+
+    def view(self, rank):
+        return _RankComm(self, rank)
+
+
+class _RankComm:
+    def __init__(self, comm, rank):
+        self.c, self.rank = comm, rank
+
+    def get_world_size(self, group=None):
+        return self.c.world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def _exchange(self, inp):
+        import torch
+        torch.cuda.synchronize()
+        self.c.slots[self.rank] = inp
+        self.c.barrier.wait()
+
+    def _done(self):
+        import torch
+        torch.cuda.synchronize()
+        self.c.barrier.wait()
+
+    def all_to_all_single(self, out, inp, group=None):
+        self._exchange(inp)
+        n = inp.numel() // self.c.world
+        for q in range(self.c.world):
+            out[q * n:(q + 1) * n] = self.c.slots[q][self.rank * n:(self.rank + 1) * n]
+        self._done()
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        self._exchange(inp)
+        n = inp.numel()
+        for q in range(self.c.world):
+            if q != self.rank:
+                out[q * n:(q + 1) * n] = self.c.slots[q]
+        self._done()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+@pytest.mark.parametrize("d,world", [(128, 2), (192, 4), (96, 3)])
+def test_row_sharded_hip_kernels_with_virtual_ranks(method, d, world):
+    """The sharded recursion on the real HIP kernels: every virtual rank must reproduce the unsharded oracle."""
+    import threading
+    import torch
+    from vgpa_amd.large_d import ShardedRecursion
+    n = 7
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
+    mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
+    lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
+    comm = _ThreadComm(world)
+    errs, fails = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            rec = ShardedRecursion(method, 0.01, d, comm=comm.view(rank))
+            assert rec.world == world and rec.Mp == d // world and rec.row0 == rank * (d // world)
+            mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
+            lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
+            torch.cuda.synchronize()
+            errs[rank] = max(rel_err(mt.cpu().numpy(), mt_o), rel_err(st.cpu().numpy(), st_o),
+                             rel_err(lam.cpu().numpy(), lam_o), rel_err(psi.cpu().numpy(), psi_o))
+        except BaseException as exc:      # noqa: BLE001 - a dead thread would leave the others at the barrier
+            fails.append(exc)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not fails, fails
+    assert all(e is not None and e < TOL for e in errs), errs
+
+
 @pytest.mark.gpu
 def test_large_d_agrees_with_small_d_kernels_at_the_boundary():
     """D = 64 runs on the LDS-resident kernels, the per-stage GEMM path must give the same numbers."""

@@ -72,7 +72,9 @@ def _is_symmetric(t):
 class ShardedRecursion:
     """(m_t, S_t) and (lam_t, Psi_t) for D > 64 on one GPU or row-sharded over a process group."""
 
-    def __init__(self, method, dt, dim_d, group=None, backend=None, device=None):
+    def __init__(self, method, dt, dim_d, group=None, backend=None, device=None, comm=None):
+        """`comm`: object with torch.distributed's get_world_size / get_rank / all_to_all_single /
+        all_gather_into_tensor (default: torch.distributed itself when a process group is initialised)."""
         import torch
         import torch.distributed as dist
         method = str(method).lower()
@@ -82,7 +84,7 @@ class ShardedRecursion:
             raise ValueError(f" Discrete time step should be strictly positive -> {dt}.")
         self.method, self.dt, self.D = method, float(dt), int(dim_d)
         self.group = group
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.dist = comm if comm is not None else (dist if (dist.is_available() and dist.is_initialized()) else None)
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
         if self.D % self.world != 0:
