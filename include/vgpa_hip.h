@@ -133,6 +133,14 @@ int vgpa_free_energy_dev(vgpa_ctx* ctx, const double* x_dev, double* f_host);
 int vgpa_sweep_enqueue(vgpa_ctx* ctx, const double* x_dev, double* g_dev);
 int vgpa_fetch_f(vgpa_ctx* ctx, double* f_host);    /* syncs, checks the device status word */
 
+/* vgpa_energy plus the two hyper-parameter members of <model>.energy()'s return tuple, which the reference computes but
+ * nothing consumes (ornstein_uhlenbeck.py:222-226, double_well.py:250-254, lorenz_63.py:329-342, lorenz_96.py:421-434).
+ * dEsde_dth: [B] (OU, DW), [B][3] (L63), [B][D] (L96); dEsde_dsig: [B] (1-D) or [B][D][D]; both NULL or both given
+ * (D <= 64).  Every output may be NULL. */
+int vgpa_energy_full(vgpa_ctx* ctx, const double* lin_a, const double* off_b, const double* mt, const double* st,
+                     double* Esde, double* Efx, double* Edf, double* dEsde_dm, double* dEsde_ds,
+                     double* dEsde_dth, double* dEsde_dsig);
+
 /* gradient from the cached state into a DEVICE buffer (df(x) of SCG, src/numerics/optim_scg.py:100,235) */
 int vgpa_gradient_dev(vgpa_ctx* ctx, double* g_dev);
 

@@ -17,7 +17,9 @@ def pytest_configure(config):
 
 
 def golden_tags():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Sweep fixtures (one per model / stepper case); host_terms.npz holds the host-side helper vectors."""
+    tags = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [t for t in tags if t != "host_terms"]
 
 
 def load_golden(tag):

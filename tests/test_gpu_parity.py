@@ -59,12 +59,28 @@ def test_backward_sweep(golden, flags):
 def test_model_energy(golden):
     p = problem_from_golden(golden)
     a, b = split_x(golden["x"], p["vgp"].dim_n, p["d"])
-    esde, (ef, edf), (dm, ds, *_) = p["model"].energy(a, b, golden["mt"], golden["st"], list(golden["obs_t"]))
+    esde, (ef, edf), (dm, ds, dth, dsig) = p["model"].energy(a, b, golden["mt"], golden["st"], list(golden["obs_t"]))
     assert abs(esde - float(golden["Esde"])) <= TOL * abs(float(golden["Esde"]))
+    # the hyper-parameter members of the tuple: computed by the reference, consumed by nothing
+    assert rel_err(np.asarray(dth), golden["dEsde_dth"]) < TOL
+    assert rel_err(np.asarray(dsig), golden["dEsde_dSig"]) < TOL
     assert rel_err(ef, golden["Efx"]) < TOL
     assert rel_err(edf, golden["Edf"]) < TOL
     assert rel_err(dm, golden["dEsde_dm"]) < TOL
     assert rel_err(ds, golden["dEsde_ds"]) < TOL
+
+
+def test_noise_gradient_of_the_observation_energy():
+    """dEobs_dr (third member of GaussianLikelihood.gradients): 1-D values from the reference, n-D all zeros."""
+    from conftest import load_golden
+    z = load_golden("host_terms")
+    lik = va.GaussianLikelihood(z["obs_y"], list(z["obs_t"]), float(z["obs_noise"]), None, True)
+    dm, ds, dr = lik.gradients(z["obs_m"], z["obs_s"])
+    assert rel_err(dm, z["obs_dm"]) < TOL and rel_err(ds, z["obs_ds"]) < TOL and rel_err(dr, z["obs_dr"]) < 1e-13
+    g = load_golden("l63_rk4_p")
+    p = problem_from_golden(g)
+    _, _, dr = p["lik"].gradients(g["mt"], g["st"])
+    assert dr.shape == (g["mt"].shape[0], g["obs_y"].shape[0], g["obs_y"].shape[0]) and not dr.any()
 
 
 def test_observation_terms(golden):

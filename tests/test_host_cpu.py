@@ -132,3 +132,15 @@ def test_vargp_wiring_without_gpu(golden):
     assert v.dim_n == golden["time_window"].size
     assert v.dim_tot == v.dim_n * v.dim_d ** 2
     assert set(v.arg_out) >= {"m0", "s0"}
+
+
+def test_host_side_gradient_helpers_match_the_reference():
+    """PriorKL0.gradients and the 1-D dEobs_dr against vectors generated from the reference (tools/gen_golden.py);
+    both are host numpy in the reference too and sit outside the hot path."""
+    from conftest import load_golden
+    z = load_golden("host_terms")
+    mu0, tau0, m0, s0, lam0, psi0 = z["kl1_in"]
+    g = va.PriorKL0(mu0, tau0, True).gradients(m0, s0, lam0, psi0)
+    assert np.allclose([g[0], g[1]], [z["kl1_dm0"], z["kl1_ds0"]], rtol=1e-13, atol=0)
+    g = va.PriorKL0(z["kln_mu0"], z["kln_tau0"], False).gradients(z["kln_m0"], z["kln_s0"], z["kln_lam0"], z["kln_psi0"])
+    assert np.allclose(g[0], z["kln_dm0"], rtol=1e-12, atol=1e-14) and np.allclose(g[1], z["kln_ds0"], rtol=1e-12, atol=1e-14)

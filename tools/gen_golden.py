@@ -193,9 +193,45 @@ def anchors_of(c, r):
                 obs_y_sum=float(np.sum(c["obs_y"])), path_sum=float(np.sum(c["model"].sample_path)))
 
 
+def dump_host_terms():
+    """Inputs / outputs of the two host-side gradient helpers nothing on the hot path consumes:
+    PriorKL0.gradients (prior_kl0.py:94-175) and the 1-D dEobs_dr (gaussian_like.py:154-196)."""
+    rng = np.random.default_rng(2718)
+    out = {}
+    # 1-D KL0
+    mu0, tau0, m0, s0, lam0, psi0 = 1.0, 0.5, 0.7, 0.2, -0.3, 0.11
+    g = PriorKL0(mu0, tau0, True).gradients(m0, s0, lam0, psi0)
+    out.update(kl1_in=np.array([mu0, tau0, m0, s0, lam0, psi0]), kl1_dm0=g[0], kl1_ds0=g[1])
+    # n-D KL0
+    d = 5
+    q = rng.standard_normal((d, d))
+    tau = 0.5 * np.eye(d) + 0.05 * (q + q.T) / 2.0
+    q = rng.standard_normal((d, d))
+    s0n = 0.2 * np.eye(d) + 0.02 * (q + q.T) / 2.0
+    mu, m0n, lam = rng.standard_normal(d), rng.standard_normal(d), rng.standard_normal(d)
+    q = rng.standard_normal((d, d))
+    psi = (q + q.T) / 2.0
+    g = PriorKL0(mu, tau, False).gradients(m0n, s0n, lam, psi)
+    out.update(kln_mu0=mu, kln_tau0=tau, kln_m0=m0n, kln_s0=s0n, kln_lam0=lam, kln_psi0=psi, kln_dm0=g[0], kln_ds0=g[1])
+    # 1-D dEobs_dr
+    n = 40
+    m, s = rng.standard_normal(n), 0.1 + rng.random(n)
+    obs_t = [3, 9, 17, 31]
+    obs_y = rng.standard_normal(len(obs_t))
+    lik = GaussianLikelihood(obs_y, obs_t, 0.04, None, True)
+    dm, ds, dr = lik.gradients(m, s)
+    out.update(obs_m=m, obs_s=s, obs_t=np.asarray(obs_t), obs_y=obs_y, obs_noise=0.04, obs_dm=dm, obs_ds=ds, obs_dr=dr)
+    np.savez_compressed(os.path.join(OUT, "host_terms.npz"), **out)
+    print("host_terms        written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     skip_full = "--skip-full" in sys.argv
+    if "--host-terms-only" in sys.argv:
+        dump_host_terms()
+        return
+    dump_host_terms()
     anchors = {}
     for tag, name, method, tf, dd, pert in SHORT_CASES:
         c = build(name, method, tf, dim_d=dd, perturb=pert)

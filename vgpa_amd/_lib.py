@@ -25,7 +25,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_obs_energy", "vgpa_free_energy", "vgpa_gradient", "vgpa_sweep", "vgpa_energy_parts",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
-           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev",
+           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full",
            "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby"]
 
 P_DOUBLE = POINTER(c_double)
@@ -78,6 +78,7 @@ def load():
     lib.vgpa_solve_bwd.argtypes = [c_void_p] + [c_void_p] * 7
     lib.vgpa_energy.argtypes = [c_void_p] + [c_void_p] * 9
     lib.vgpa_obs_energy.argtypes = [c_void_p] + [c_void_p] * 5
+    lib.vgpa_energy_full.argtypes = [c_void_p] + [c_void_p] * 11
     lib.vgpa_free_energy.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.vgpa_gradient.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.vgpa_sweep.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
@@ -255,16 +256,26 @@ class Context:
                                              _ptr(lam), _ptr(psi)))
         return self._squeeze(lam), self._squeeze(psi)
 
-    def energy(self, lin_a, off_b, mt, st, want_edf=True):
+    def energy(self, lin_a, off_b, mt, st, want_edf=True, want_hyper=False):
+        """(Esde, Ef, Edf, dEsde_dm, dEsde_ds[, dEsde_dth, dEsde_dSig]) -- the last two with want_hyper (D <= 64)."""
         a, b, m, s = (_c64(v) for v in (lin_a, off_b, mt, st))
         esde = np.empty(self.B)
         ef, dm = np.empty(self._shape_v()), np.empty(self._shape_v())
         edf = np.empty(self._shape_m()) if want_edf else None
         ds = np.empty(self._shape_m())
-        self._check(self._lib.vgpa_energy(self._h, _ptr(a), _ptr(b), _ptr(m), _ptr(s), _ptr(esde), _ptr(ef),
-                                          _ptr(edf), _ptr(dm), _ptr(ds)))
+        dth = dsg = None
+        if want_hyper:
+            dth = np.empty(self.B) if self.D == 1 else np.empty((self.B, self.D))
+            dsg = np.empty(self.B) if self.D == 1 else np.empty((self.B, self.D, self.D))
+        self._check(self._lib.vgpa_energy_full(self._h, _ptr(a), _ptr(b), _ptr(m), _ptr(s), _ptr(esde), _ptr(ef),
+                                               _ptr(edf), _ptr(dm), _ptr(ds), _ptr(dth), _ptr(dsg)))
         sq = self._squeeze
-        return (float(esde[0]) if self.B == 1 else esde), sq(ef), (sq(edf) if want_edf else None), sq(dm), sq(ds)
+        out = ((float(esde[0]) if self.B == 1 else esde), sq(ef), (sq(edf) if want_edf else None), sq(dm), sq(ds))
+        if want_hyper:
+            one = self.B == 1
+            out += ((float(dth[0]) if self.D == 1 else dth[0]) if one else dth,
+                    (float(dsg[0]) if self.D == 1 else dsg[0]) if one else dsg)
+        return out
 
     def obs_energy(self, mt, st, want_jumps=True):
         m, s = _c64(mt), _c64(st)

@@ -363,7 +363,23 @@ __global__ void __launch_bounds__(NT) k_reduce(ReduceArgs a) {
   }
 }
 
+// out[prob][h] = sum_i dt (e[i+1][h] + e[i][h]) / 2 for the H interleaved integrands of one problem (grid = (H, batch))
+__global__ void __launch_bounds__(NT) k_trapz_multi(const double* e, int Np, int H, double dt, double* out) {
+  __shared__ double red[NT];
+  const int h = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
+  const double* ep = e + (size_t)prob * Np * H + h;
+  double part = 0.0;
+  for (int i = tid; i < Np - 1; i += NT) part += dt * (ep[(size_t)(i + 1) * H] + ep[(size_t)i * H]) / 2.0;
+  const double tot = block_sum(part, red);
+  if (tid == 0) out[(size_t)prob * H + h] = tot;
+}
+
 }  // namespace
+
+hipError_t launch_trapz_multi(const double* e, int Np, int H, int batch, double dt, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_trapz_multi, dim3(H, batch), dim3(NT), 0, st, e, Np, H, dt, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_obs(const ObsArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_obs, dim3(a.batch), dim3(NT), 0, st, a);

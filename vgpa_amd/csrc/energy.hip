@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(NT) k_energy_1d(EnergyArgs a) {
     if (a.Edf) a.Edf[o] = -th;
     a.dEm[o] = (m * q1 + th * ob - la * ob) / sg;
     a.dEs[o] = 0.5 * q1 / sg;
+    if (a.hyp) a.hyp[o] = ex2 * (th - la) + m * ob;                    // ornstein_uhlenbeck.py:222-223
   } else {  // double well: f(x) = 4x(theta - x^2)
     const double c = 4.0 * th + la, c2 = c * c;
     const double m2 = m * m, m3 = m2 * m, m4 = m2 * m2, m5 = m4 * m, m6 = m3 * m3;
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(NT) k_energy_1d(EnergyArgs a) {
     const double ds2 = 1.0, ds3 = 3 * m, ds4 = 6 * (m2 + s), ds6 = 15 * m4 + 90 * m2 * s + 45 * s2;
     a.dEm[o] = 0.5 * (16.0 * dm6 - 8.0 * c * dm4 + 8.0 * ob * dm3 + c2 * dm2 - 2.0 * ob * c) / sg;
     a.dEs[o] = 0.5 * (16.0 * ds6 - 8.0 * c * ds4 + 8.0 * ob * ds3 + c2 * ds2) / sg;
+    if (a.hyp) a.hyp[o] = c * ex2 - 4.0 * ex4 - ob * m;                   // double_well.py:250-251
   }
 }
 
@@ -163,6 +165,13 @@ __global__ void __launch_bounds__(64) k_energy_l63(EnergyArgs a) {
   ef[0] = vS * (my - mx);
   ef[1] = vR * mx - my - St[6] - mx * mz;
   ef[2] = St[3] + mx * my - vB * mz;
+  if (a.hyp) {   // <(f-g)' df/dtheta> (lorenz_63.py:572-633) and <(f-g)^2> per component (:343)
+    double* hp = a.hyp + o * 6;
+    hp[0] = Eyy * (vS + A12) + Exx * (vS - A11) + Exy * (A11 - 2 * vS - A12) + A13 * (Eyz - Exz) + b1 * (mx - my);
+    hp[1] = vR * Exx - Exy - Exxz + A21 * Exx + A22 * Exy + A23 * Exz - b2 * mx;
+    hp[2] = -Exyz + vB * Ezz - A31 * Exz - A32 * Eyz - A33 * Ezz + b3 * mz;
+    hp[3] = EX; hp[4] = EY; hp[5] = EZ;
+  }
   if (a.Edf) {
     double* e = a.Edf + o * 9;
     e[0] = -vS; e[1] = vS; e[2] = 0.0;
@@ -426,7 +435,8 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   //         one sequential pass over i -- they share every LDS operand; the mean point p = 0 is evaluated in parallel
   //         over i.  chi(p, i) = m_i + sgn_p L[i][col_p]; the flat np.roll of the reference (quirk Q1) makes the
   //         neighbours at the row ends come from the sigma points p-1 and p+1.
-  double vplus = 0.0, vminus = 0.0, v0 = 0.0;
+  double vplus = 0.0, vminus = 0.0, v0 = 0.0, r0sq = 0.0;
+  const bool hyper = a.hyp != nullptr;
   {
     auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
     auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
@@ -446,6 +456,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
       vplus = __builtin_fma(sgi, ra * ra, vplus);
       vminus = __builtin_fma(sgi, rb * rb, vminus);
+      if (hyper && act) S.Gm[i * LD + jc] = ra * ra + rb * rb;      // G[i][jc] has just been consumed by this lane
       am2 = am1; am1 = a0; a0 = a1;
       bm2 = bm1; bm1 = b0; b0 = b1;
       const int in = i + 2;
@@ -463,11 +474,26 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       const double xm1 = (i >= 1) ? S.mv[i - 1] : chi(M - 1, D - 1);
       const double x1 = (i + 1 < D) ? S.mv[i + 1] : chi(1, 0);
       const double r0 = ((x1 - xm2) * xm1 - S.mv[i] + theta) + S.am[i] - S.bv[i];
-      v0 = S.sg[i] * (r0 * r0);
+      r0sq = r0 * r0;
+      v0 = S.sg[i] * r0sq;
     }
     v0 = wave_sum(v0);
   }
   const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
+  if (hyper) {
+    // dEsde_dth(t) = <f> + A m - b (lorenz_96.py:421), dEsde_dSig(t) = m_bar = UT mean of (f-g)^2 per component (:424):
+    // lane i sums row i of the squared residuals left in Gm
+    wave_sync();
+    if (act) {
+      double sm = 0.0;
+      for (int j = 0; j < D; j++) sm += S.Gm[l * LD + j];
+      const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
+      const double efi = (St[ip1 * D + im1] - St[im2 * D + im1]) + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
+      double* hp = a.hyp + o * 2 * D;
+      hp[i] = efi + S.am[i] - S.bv[i];
+      hp[D + i] = w0 * r0sq + w1 * sm;
+    }
+  }
   const double e_part = act ? (vplus + vminus) : 0.0;
   const double e_t = 0.5 * (w0 * v0 + w1 * wave_sum(e_part));
   if (act) {

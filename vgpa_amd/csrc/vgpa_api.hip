@@ -33,6 +33,10 @@ struct vgpa_ctx {
   double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
   double* d_ld_ws = nullptr;      // workspace of the large-D drivers
   double* d_lde_ws = nullptr;     // workspace of the large-D energy / gradient kernels
+  double* d_hyp = nullptr;        // [B][Np][H] integrands of the hyper-parameter gradients (vgpa_energy_hyper only)
+  double* d_hypT = nullptr;       // [B][H] their trapezoids
+  bool hyp_on = false;
+  std::vector<double> h_isig;     // host copy of Sigma^-1 [D][D]
   double* d_vec_scratch = nullptr; // [2B coefficients | B results | B*bps partials] of the vector algebra
   size_t vec_scratch_n = 0;
   int lde_nb = 1;
@@ -205,6 +209,7 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
   a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
   a.e_t = c->d_et; a.Ef = c->d_Ef; a.Edf = edf; a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.status = c->d_status;
   a.Am = (c->cfg.model == VGPA_MODEL_L96) ? c->d_Am : nullptr;
+  a.hyp = c->hyp_on ? c->d_hyp : nullptr;
   return a;
 }
 
@@ -445,6 +450,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   HTRY(hipMemsetAsync(c->d_jsc, 0, sizeof(double) * DD, c->stream));
 
   TRY(upload(c, c->d_Sigma, sigma.data(), DD));
+  c->h_isig = isig;
   TRY(upload(c, c->d_isig, isig.data(), DD));
   TRY(upload(c, c->d_isg, isg.data(), (size_t)D));
   if (cfg->m0) TRY(upload(c, c->d_m0, cfg->m0, (size_t)D));
@@ -561,27 +567,75 @@ int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, con
   return vgpa_synchronize(c);
 }
 
-int vgpa_energy(vgpa_ctx* c, const double* lin_a, const double* off_b, const double* mt, const double* st,
-                double* esde, double* efx, double* edf, double* desde_dm, double* desde_ds) {
+// dEsde/dtheta and dEsde/dSigma of <model>.energy (ornstein_uhlenbeck.py:222-226, double_well.py:250-254,
+// lorenz_63.py:329-342, lorenz_96.py:421-434): the kernels emit the per-grid-point integrands, one trapezoid per
+// component reduces them, the O(D^3) scaling by Sigma^-1 is finished on the host.
+int vgpa_energy_full(vgpa_ctx* c, const double* lin_a, const double* off_b, const double* mt, const double* st,
+                     double* esde_out, double* efx, double* edf, double* desde_dm, double* desde_ds,
+                     double* desde_dth, double* desde_dsig) {
   if (!c || !lin_a || !off_b || !mt || !st) return fail(c, VGPA_ERR_ARG, "null argument");
+  if ((desde_dth != nullptr) != (desde_dsig != nullptr)) return fail(c, VGPA_ERR_ARG, "dEsde_dth and dEsde_dsig come together");
+  const bool hyper = desde_dth != nullptr;
+  if (hyper && c->cfg.model == VGPA_MODEL_NONE) return fail(c, VGPA_ERR_STATE, "context has no stochastic model");
+  if (hyper && c->D > kMaxSmallD) return fail(c, VGPA_ERR_UNSUPPORTED, "hyper-parameter gradients are built for D <= %d", kMaxSmallD);
   HIP_TRY(c, hipSetDevice(c->cfg.device));
+  const int D = c->D;
+  const int H = c->single ? 1 : 2 * D;
   const size_t BN = (size_t)c->B * c->Np;
   int rc;
   if (edf && !c->d_Edf && (rc = dev_alloc(c, &c->d_Edf, BN * c->DD))) return rc;
+  if (hyper && !c->d_hyp) {
+    if ((rc = dev_alloc(c, &c->d_hyp, BN * H))) return rc;
+    if ((rc = dev_alloc(c, &c->d_hypT, (size_t)c->B * H))) return rc;
+  }
   if ((rc = ingest_ab(c, lin_a, off_b))) return rc;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
-  if ((rc = run_energy(c, edf ? c->d_Edf : nullptr))) return rc;
+  c->hyp_on = hyper;
+  rc = run_energy(c, edf ? c->d_Edf : nullptr);
+  c->hyp_on = false;
+  if (rc) return rc;
   if ((rc = run_reduce(c))) return rc;
+  if (hyper) {
+    hipError_t e = launch_trapz_multi(c->d_hyp, c->Np, H, c->B, c->cfg.dt, c->d_hypT, c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "trapezoid launch failed: %s", hipGetErrorString(e));
+  }
   if ((rc = check_status(c))) return rc;
-  if (esde && (rc = download(c, esde, c->d_esde, (size_t)c->B))) return rc;
+  std::vector<double> T(hyper ? (size_t)c->B * H : 0), esde(c->B);
+  if ((rc = download(c, esde.data(), c->d_esde, esde.size()))) return rc;
+  if (hyper && (rc = download(c, T.data(), c->d_hypT, T.size()))) return rc;
   if (efx && (rc = download(c, efx, c->d_Ef, BN * c->D))) return rc;
   if (edf && (rc = download(c, edf, c->d_Edf, BN * c->DD))) return rc;
   if (desde_dm && (rc = download(c, desde_dm, c->d_dEm, BN * c->D))) return rc;
   if (desde_ds && (rc = download(c, desde_ds, c->d_dEs, BN * c->DD))) return rc;
   c->have_state = false;
-  return vgpa_synchronize(c);
+  if ((rc = vgpa_synchronize(c))) return rc;
+  if (esde_out) for (int p = 0; p < c->B; p++) esde_out[p] = esde[p];
+  if (!hyper) return VGPA_OK;
+  for (int p = 0; p < c->B; p++) {
+    const double* Tp = T.data() + (size_t)p * H;
+    if (c->single) {
+      desde_dth[p] = (c->cfg.model == VGPA_MODEL_DW ? 4.0 : 1.0) * Tp[0] / c->sigma1;
+      desde_dsig[p] = -esde[p] / c->sigma1;
+      continue;
+    }
+    const double* is = c->h_isig.data();
+    for (int i = 0; i < D; i++) desde_dth[(size_t)p * D + i] = is[(size_t)i * D + i] * Tp[i];
+    double* out = desde_dsig + (size_t)p * D * D;          // -0.5 * Sigma^-1 diag(v) Sigma^-1
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) {
+        double sacc = 0.0;
+        for (int k = 0; k < D; k++) sacc += (is[(size_t)i * D + k] * Tp[D + k]) * is[(size_t)k * D + j];
+        out[(size_t)i * D + j] = -0.5 * sacc;
+      }
+  }
+  return VGPA_OK;
+}
+
+int vgpa_energy(vgpa_ctx* c, const double* lin_a, const double* off_b, const double* mt, const double* st,
+                double* esde, double* efx, double* edf, double* desde_dm, double* desde_ds) {
+  return vgpa_energy_full(c, lin_a, off_b, mt, st, esde, efx, edf, desde_dm, desde_ds, nullptr, nullptr);
 }
 
 int vgpa_obs_energy(vgpa_ctx* c, const double* mt, const double* st, double* eobs, double* deobs_dm, double* deobs_ds) {

@@ -55,6 +55,7 @@ struct EnergyArgs {
   double* Edf;              // [B][Np][D][D] or nullptr
   double* dEm;              // [B][Np][D]
   double* dEs;              // [B][Np][D][D]
+  double* hyp;              // [B][Np][H] per-grid-point integrands of dEsde/dtheta, dEsde/dSigma (nullptr: skipped)
   double* Am;               // [B][Np][D] A_t m_t, a by-product the gradient assembly reuses (L96 kernel; may be nullptr)
   int32_t* status;          // [B] device status word (bit0: S_t not positive definite)
 };
@@ -108,6 +109,8 @@ hipError_t launch_obs_dense(const ObsArgs& a, const double* js_const, double* jm
                             hipStream_t st);
 hipError_t launch_grad(const GradArgs& a, hipStream_t st);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
+// out[p][h] = trapezoid over t of e[p][t][h]
+hipError_t launch_trapz_multi(const double* e, int Np, int H, int batch, double dt, double* out, hipStream_t st);
 hipError_t launch_edf(const EnergyArgs& a, hipStream_t st);   // dense <df/dx> on request
 
 // large-D (per-stage GEMM) single-rank drivers, large_d.hip

@@ -125,14 +125,18 @@ class StochasticProcess(object):
         if self.single_dim:
             n = m.size
             ctx = self._ctx_for(n, 1)
-            esde, ef, edf, dm, ds = ctx.energy(np.asarray(linear_a, dtype=float).reshape(n, 1, 1),
-                                               np.asarray(offset_b, dtype=float).reshape(n, 1),
-                                               m.reshape(n, 1), np.asarray(s, dtype=float).reshape(n, 1, 1))
-            return esde, (ef.reshape(n), edf.reshape(n)), (dm.reshape(n), ds.reshape(n), None, None)
+            esde, ef, edf, dm, ds, dth, dsg = ctx.energy(np.asarray(linear_a, dtype=float).reshape(n, 1, 1),
+                                                         np.asarray(offset_b, dtype=float).reshape(n, 1),
+                                                         m.reshape(n, 1), np.asarray(s, dtype=float).reshape(n, 1, 1),
+                                                         want_hyper=True)
+            return esde, (ef.reshape(n), edf.reshape(n)), (dm.reshape(n), ds.reshape(n), dth, dsg)
         n, d = m.shape
         ctx = self._ctx_for(n, d)
-        esde, ef, edf, dm, ds = ctx.energy(linear_a, offset_b, m, s)
-        return esde, (ef, edf), (dm, ds, None, None)
+        if d > 64:     # the hyper-parameter members (unused by VarGP) are not built for the large-D path
+            esde, ef, edf, dm, ds = ctx.energy(linear_a, offset_b, m, s)
+            return esde, (ef, edf), (dm, ds, None, None)
+        esde, ef, edf, dm, ds, dth, dsg = ctx.energy(linear_a, offset_b, m, s, want_hyper=True)
+        return esde, (ef, edf), (dm, ds, dth, dsg)
 
 
 def _as_noise_matrix(cls_name, sigma, dim_d):

@@ -87,13 +87,24 @@ class GaussianLikelihood(Likelihood):
         return self._run(m, s, False)
 
     def gradients(self, m, s=None):
-        """(dEobs_dm, dEobs_ds, dEobs_dr); dEobs_dr (unused by VarGP) is returned as None."""
+        """(dEobs_dm, dEobs_ds, dEobs_dr) (gaussian_like.py:154-243).  The jump terms come from the GPU; dEobs_dr --
+        which no caller consumes -- is the O(M) host expression in 1-D and, as in the reference, an all-zero
+        (dim_n, dim_o, dim_o) array in n-D (gaussian_like.py:230 allocates it and never fills it)."""
         _, jm, js = self._run(m, s, True)
-        return jm, js, None
+        obs_t = np.asarray(self.times)
+        if self.single_dim:
+            mo, so = np.asarray(m, dtype=float)[obs_t], np.asarray(s, dtype=float)[obs_t]
+            y = np.asarray(self.values, dtype=float)
+            d_r = np.zeros(np.asarray(m).shape[0])
+            d_r[obs_t] = -0.5 * ((y ** 2) - 2.0 * y * mo + ((mo ** 2) + so) + 1.0) / self.noise
+        else:
+            dim_o = np.asarray(self.values).shape[0]
+            d_r = np.zeros((np.asarray(m).shape[0], dim_o, dim_o))
+        return jm, js, d_r
 
 
 class PriorKL0(object):
-    """KL(q0 || p0) (src/var_bayes/prior_kl0.py:30-92), value only (its gradients have no caller)."""
+    """KL(q0 || p0) (src/var_bayes/prior_kl0.py:30-92) and its gradients (:94-175); host side: constant in x."""
 
     def __init__(self, mu0, tau0, single_dim: bool = True) -> None:
         self.mu0 = np.asarray(mu0)
@@ -116,3 +127,17 @@ class PriorKL0(object):
         # Q5: z0.T.dot(z0) is a scalar that numpy broadcasts over the whole matrix.
         return 0.5 * (chol_logdet(self.tau0.dot(inv_s0)) +
                       np.sum(np.diag(inv_tau0.dot(z0.T.dot(z0) + s0 - self.tau0))))
+
+    def gradients(self, m0, s0, lam0, psi0):
+        """(dKL0/dm0, dKL0/ds0) including the Lagrange multipliers at t = 0 (prior_kl0.py:94-175)."""
+        z0 = m0 - self.mu0
+        if self.single_dim:
+            return lam0 + z0 / self.tau0, psi0 + 0.5 * (1.0 / self.tau0 - 1.0 / s0)
+
+        def spd_inv(x):
+            c_inv = np.linalg.solve(np.linalg.cholesky(x), np.eye(x.shape[0]))
+            return c_inv.T.dot(c_inv)
+
+        d_m0 = lam0 + np.linalg.solve(self.tau0, z0.T).T
+        d_s0 = psi0 + 0.5 * (spd_inv(self.tau0) - spd_inv(np.asarray(s0)))
+        return d_m0, d_s0
