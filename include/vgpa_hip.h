@@ -67,7 +67,10 @@ enum {
 /* config flags */
 enum {
   VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
-  VGPA_FLAG_FOUR_WAVES = 2     /* diagnostics: MFMA steppers with four waves per problem where eight are the default */
+  VGPA_FLAG_FOUR_WAVES = 2,    /* diagnostics: MFMA steppers with four waves per problem where eight are the default */
+  VGPA_FLAG_STREAM_LARGE_D = 4 /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and
+                                  dEsde_dS_t live in chunk buffers; VGPA_FETCH_PSIT is unavailable).  Chosen automatically
+                                  when the resident arrays would not fit into free device memory. */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;
@@ -155,6 +158,14 @@ int vgpa_vec_asum(vgpa_ctx* ctx, const double* a_dev, uint64_t seglen, double* o
  * coefficient drops its operand entirely (0*inf = 0), which is how finished problems are frozen */
 int vgpa_vec_axpby(vgpa_ctx* ctx, uint64_t seglen, const double* alpha_host, const double* x_dev,
                    const double* beta_host_or_null, const double* y_dev_or_null, double* out_dev);
+
+/* tuning knobs (tests / benchmarks); returns VGPA_ERR_ARG for an unknown option or a value out of range */
+enum vgpa_option {
+  VGPA_OPT_LD_CHUNK = 1        /* grid points per chunk of the time-chunked large-D sweep (>= 1) */
+};
+int vgpa_set_option(vgpa_ctx* ctx, int option, int64_t value);
+/* 1 if the context runs the time-chunked large-D sweep (VGPA_FLAG_STREAM_LARGE_D or chosen for lack of memory) */
+int vgpa_is_streaming(vgpa_ctx* ctx);
 
 /* raw device memory helpers so that hosts without a HIP binding can own device buffers */
 int vgpa_dev_alloc(vgpa_ctx* ctx, uint64_t bytes, void** out);

@@ -304,3 +304,39 @@ def test_large_d_fused_sweep(d, n, method):
     from test_gpu_edge_cases import make_problem, check
     p, x = make_problem("L96", d, n, method=method)
     check(p, x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+@pytest.mark.parametrize("d,n,chunk", [(80, 23, 5), (96, 12, 11), (72, 30, 1), (128, 9, 64)])
+def test_time_chunked_sweep_equals_the_resident_one(d, n, chunk, method):
+    """VGPA_FLAG_STREAM_LARGE_D keeps only x, S_t and the gradient resident (BASELINE config 4 does not fit otherwise):
+    F, the gradient and the state that is still kept must equal the resident sweep's and the oracle's; chunk sizes
+    that do / do not divide the grid, a single-point chunk and one chunk for the whole grid."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    from vgpa_amd._lib import FLAG_STREAM_LARGE_D, OPT_LD_CHUNK
+    p, x = make_problem("L96", d, n, method=method)
+    res = gpu_context(p)
+    assert not res.streaming
+    f_r, g_r = res.sweep(x)
+    st = gpu_context(p, flags=FLAG_STREAM_LARGE_D)
+    assert st.streaming
+    st.set_option(OPT_LD_CHUNK, chunk)
+    f_s, g_s = st.sweep(x)
+    assert f_s == f_r and np.array_equal(g_s, g_r)              # same kernels, same order per grid point
+    f_o, g_o, state = vo.sweep(p, x, faithful=False)
+    assert abs(f_s - f_o) <= TOL * abs(f_o) and rel_err(g_s, g_o) < TOL
+    # split evaluation: free_energy (no backward pass needed for F), then the gradient from the cached (m, S)
+    assert st.free_energy(x) == f_r
+    assert np.array_equal(st.gradient(None), g_r)
+    for key in ("mt", "st", "lamt"):
+        assert np.array_equal(st.fetch(key), res.fetch(key)), key
+    with pytest.raises(NotImplementedError):
+        st.fetch("psit")
+    # device-resident entry points
+    xb, gb = st.alloc(x.size), st.alloc(x.size)
+    xb.upload(x)
+    assert st.sweep_dev(xb, gb) == f_r and np.array_equal(gb.download(), g_r)
+    with pytest.raises(RuntimeError):
+        st.set_option(OPT_LD_CHUNK, 3)                          # buffers exist already
+    st.close(); res.close()

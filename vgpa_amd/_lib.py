@@ -18,6 +18,9 @@ MODEL_IDS = {"NONE": -1, "OU": 0, "DW": 1, "L63": 2, "L96": 3}
 METHOD_IDS = {"euler": 0, "heun": 1, "rk2": 2, "rk4": 3}
 FETCH_IDS = {"mt": 0, "st": 1, "lamt": 2, "psit": 3, "Efx": 4, "Edf": 5, "dEsde_dm": 6, "dEsde_ds": 7, "Esde_t": 8}
 FLAG_FORCE_GENERIC = 1
+FLAG_FOUR_WAVES = 2
+FLAG_STREAM_LARGE_D = 4
+OPT_LD_CHUNK = 1
 
 # exported symbols, checked by the CPU test-suite against include/vgpa_hip.h
 SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version", "vgpa_device_count",
@@ -25,7 +28,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_obs_energy", "vgpa_free_energy", "vgpa_gradient", "vgpa_sweep", "vgpa_energy_parts",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
-           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full",
+           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming",
            "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby"]
 
 P_DOUBLE = POINTER(c_double)
@@ -100,6 +103,8 @@ def load():
     lib.vgpa_vec_absmax.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_asum.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_axpby.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.vgpa_set_option.argtypes = [c_void_p, c_int, c_int64]
+    lib.vgpa_is_streaming.argtypes = [c_void_p]
     lib.vgpa_profile_begin.argtypes = [c_void_p]
     lib.vgpa_profile_end.argtypes = [c_void_p, P_DOUBLE, P_DOUBLE, P_DOUBLE, P_DOUBLE, POINTER(c_int64)]
     if lib.vgpa_abi_version() != ABI_VERSION:
@@ -383,6 +388,13 @@ class Context:
         be = None if y is None else np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (self.B,)))
         self._check(self._lib.vgpa_vec_axpby(self._h, self._seglen(x), _ptr(al), x.ptr,
                                              None if y is None else _ptr(be), None if y is None else y.ptr, out.ptr))
+
+    def set_option(self, option, value):
+        self._check(self._lib.vgpa_set_option(self._h, int(option), int(value)))
+
+    @property
+    def streaming(self):
+        return bool(self._lib.vgpa_is_streaming(self._h))
 
     def synchronize(self):
         self._check(self._lib.vgpa_synchronize(self._h))

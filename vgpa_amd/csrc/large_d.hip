@@ -356,42 +356,59 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
   return hipSuccess;
 }
 
-hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
-                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st) {
-  const size_t DD = (size_t)D * D;
+// One backward step t -> t-1.  At/Am = A_t / A_{t-1}, Gt/Gm = dEsde_dS at t / t-1, gt/gmm = dEsde_dm at t / t-1,
+// (Pt, lt) = (Psi_t, lam_t), (Pn, ln) = where (Psi_{t-1}, lam_{t-1}) go, (Jn, jn) = jump of index t-1 or nullptr.
+hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const double* Am, const double* Gt, const double* Gm,
+                       const double* gt, const double* gmm, const double* Pt, const double* lt, double* Pn, double* ln,
+                       const double* Jn, const double* jn, double* ws, hipStream_t st) {
   const Work w = carve_work(ws, D);
   const double h = 0.5 * dt;
+  StageSpec s{};
+  s.fwd = false; s.base = Pt; s.vbase = lt;
+  auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
+                 const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
+                 double cx, double cf, bool jump) {
+    s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
+    s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
+    s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
+  };
+  if (method == VGPA_ODE_EULER) {
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+  } else if (method == VGPA_ODE_HEUN) {
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(run_stage(D, w, s, st));
+  } else if (method == VGPA_ODE_RK2) {
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+  } else {
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+    set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
+    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+  }
+  return hipSuccess;
+}
+
+// Whole backward recursion with every Psi_t stored.  Jumps: dense arrays (jm, js: [Np][D], [Np][D][D]) or, when
+// obs_idx != nullptr, sparse ones (obs_idx[t] = n >= 0: jump vector jm[n][:] and the constant matrix js).
+hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
+                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st,
+                        const int32_t* obs_idx) {
+  const size_t DD = (size_t)D * D;
   LD_TRY(hipMemsetAsync(psi + (size_t)(Np - 1) * DD, 0, DD * sizeof(double), st));
   LD_TRY(hipMemsetAsync(lam + (size_t)(Np - 1) * D, 0, D * sizeof(double), st));
   for (int t = Np - 1; t > 0; t--) {
-    const double *At = A + t * DD, *Am = At - DD, *Gt = gs + t * DD, *Gm = Gt - DD;
-    const double *gt = gm + (size_t)t * D, *gmm = gt - D;
-    const double *Pt = psi + t * DD, *lt = lam + (size_t)t * D;
-    double *Pn = psi + (t - 1) * DD, *ln = lam + (size_t)(t - 1) * D;
-    const double *Jn = js + (t - 1) * DD, *jn = jm + (size_t)(t - 1) * D;
-    StageSpec s{};
-    s.fwd = false; s.base = Pt; s.vbase = lt;
-    auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
-                   const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
-                   double cx, double cf, bool jump) {
-      s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
-      s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
-      s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
-    };
-    if (method == VGPA_ODE_EULER) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
-    } else if (method == VGPA_ODE_HEUN) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(run_stage(D, w, s, st));
-    } else if (method == VGPA_ODE_RK2) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    const double *Jn, *jn;
+    if (obs_idx) {
+      const int n = obs_idx[t - 1];
+      Jn = n >= 0 ? js : nullptr;
+      jn = n >= 0 ? jm + (size_t)n * D : nullptr;
     } else {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-      set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+      Jn = js + (size_t)(t - 1) * DD; jn = jm + (size_t)(t - 1) * D;
     }
+    LD_TRY(ld_bwd_step(method, dt, D, A + t * DD, A + (t - 1) * DD, gs + t * DD, gs + (t - 1) * DD, gm + (size_t)t * D,
+                       gm + (size_t)(t - 1) * D, psi + t * DD, lam + (size_t)t * D, psi + (t - 1) * DD,
+                       lam + (size_t)(t - 1) * D, Jn, jn, ws, st));
   }
   return hipSuccess;
 }

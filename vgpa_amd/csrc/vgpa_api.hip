@@ -33,6 +33,11 @@ struct vgpa_ctx {
   double *d_op_m0 = nullptr, *d_op_S0 = nullptr, *d_op_Sigma = nullptr;
   double* d_ld_ws = nullptr;      // workspace of the large-D drivers
   double* d_lde_ws = nullptr;     // workspace of the large-D energy / gradient kernels
+  // time-chunked ("streamed") large-D sweep: Psi_t and dEsde_dS_t live only in chunk buffers of ld_chunk + 1 matrices
+  bool stream_ld = false;
+  int ld_chunk = 0;
+  double *d_dEs_c = nullptr, *d_psi_c = nullptr;
+  std::vector<int32_t> h_obs_idx; // host copy of obs_idx [Np]
   double* d_hyp = nullptr;        // [B][Np][H] integrands of the hyper-parameter gradients (vgpa_energy_hyper only)
   double* d_hypT = nullptr;       // [B][H] their trapezoids
   bool hyp_on = false;
@@ -81,6 +86,10 @@ int dev_alloc(vgpa_ctx* c, T** p, size_t count) {
   return VGPA_OK;
 }
 
+// buffers that only some entry points need are allocated on first use
+template <typename T>
+int ensure(vgpa_ctx* c, T** p, size_t count) { return *p ? VGPA_OK : dev_alloc(c, p, count); }
+
 template <typename T>
 int upload(vgpa_ctx* c, T* dst, const T* src, size_t count) {
   HIP_TRY(c, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
@@ -118,6 +127,7 @@ static inline const double* ctx_b(vgpa_ctx* c) { return c->xcur + (size_t)c->Np 
 
 static int ingest_x(vgpa_ctx* c, const double* x, bool on_device) {
   if (on_device) { c->xcur = x; return VGPA_OK; }
+  { int rc = ensure(c, &c->d_x, (size_t)c->B * c->len_x); if (rc) return rc; }
   HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (size_t)c->B * c->len_x * sizeof(double), hipMemcpyHostToDevice, c->stream));
   c->xcur = c->d_x;
   return VGPA_OK;
@@ -126,6 +136,7 @@ static int ingest_x(vgpa_ctx* c, const double* x, bool on_device) {
 // operator-level inputs arrive as separate [B][Np][D][D] / [B][Np][D] host arrays: pack them into the x layout
 static int ingest_ab(vgpa_ctx* c, const double* lin_a, const double* off_b) {
   const size_t na = (size_t)c->Np * c->DD, nb = (size_t)c->Np * c->D;
+  { int rc = ensure(c, &c->d_x, (size_t)c->B * c->len_x); if (rc) return rc; }
   c->xcur = c->d_x;
   if (lin_a) HIP_TRY(c, hipMemcpy2DAsync(c->d_x, c->len_x * sizeof(double), lin_a, na * sizeof(double), na * sizeof(double), c->B, hipMemcpyHostToDevice, c->stream));
   if (off_b) HIP_TRY(c, hipMemcpy2DAsync(c->d_x + na, c->len_x * sizeof(double), off_b, nb * sizeof(double), nb * sizeof(double), c->B, hipMemcpyHostToDevice, c->stream));
@@ -178,12 +189,18 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
 }
 
 static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
+  int rc;
+  if ((rc = ensure(c, &c->d_psi, (size_t)c->B * c->Np * c->DD))) return rc;
+  if ((rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD))) return rc;
   if (c->D > kMaxSmallD) {
-    if (!sym || !dense_jumps) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric dEsde_ds / dEobs_ds (dense jumps)");
-    int rc = ensure_ld_ws(c);
-    if (rc) return rc;
-    hipError_t e = ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm_dense,
-                                    c->d_js_dense, c->d_lam, c->d_psi, c->d_ld_ws, c->stream);
+    if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric dEsde_ds / dEobs_ds");
+    if ((rc = ensure_ld_ws(c))) return rc;
+    // operator-level calls bring dense jump arrays; the fused sweep uses the sparse ones (obs index on the host)
+    hipError_t e = dense_jumps
+        ? ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm_dense, c->d_js_dense,
+                           c->d_lam, c->d_psi, c->d_ld_ws, c->stream)
+        : ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm, c->d_jsc,
+                           c->d_lam, c->d_psi, c->d_ld_ws, c->stream, c->h_obs_idx.data());
     if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D backward sweep failed: %s", hipGetErrorString(e));
     return VGPA_OK;
   }
@@ -221,6 +238,7 @@ static int ensure_lde_ws(vgpa_ctx* c) {
 }
 
 static int run_energy(vgpa_ctx* c, double* edf) {
+  { int rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD); if (rc) return rc; }
   if (c->D > kMaxSmallD) {
     if (c->cfg.model != VGPA_MODEL_L96) return fail(c, VGPA_ERR_UNSUPPORTED, "large-D energy terms exist for Lorenz-96 only");
     int rc = ensure_lde_ws(c);
@@ -278,8 +296,90 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   return VGPA_OK;
 }
 
+// ---- time-chunked large-D sweep (BASELINE config 4: Np x D x D arrays do not all fit in HBM) -------------------------
+// Keeps x, S_t and the gradient (caller's buffer); Psi_t and dEsde_dS_t exist only for a chunk of ld_chunk + 1 grid
+// points.  From the last grid point backwards, per chunk [t0, t1]:  energy terms of the chunk -> backward steps
+// t1 .. t0+1 (Psi in the chunk buffer, lam_t in full) -> gradient of the grid points whose Psi_t is now final.
+// g_dev == nullptr: energy integrand only (what F needs).  Same kernels, same per-grid-point arithmetic as the
+// resident path, so the results are identical.
+static int stream_pass(vgpa_ctx* c, double* g_dev) {
+  const int D = c->D, Np = c->Np, C = c->ld_chunk;
+  const size_t DD = c->DD;
+  int rc;
+  if ((rc = ensure_lde_ws(c))) return rc;
+  if ((rc = ensure_ld_ws(c))) return rc;
+  if ((rc = ensure(c, &c->d_dEs_c, (size_t)(C + 1) * DD))) return rc;
+  if (g_dev && (rc = ensure(c, &c->d_psi_c, (size_t)(C + 1) * DD))) return rc;
+  if (g_dev && !c->sigma_diag) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D gradient needs a diagonal system noise matrix");
+  const double *A = ctx_A(c), *b = ctx_b(c);
+  hipStream_t st = c->stream;
+  int t1 = Np - 1;
+  if (g_dev) HIP_TRY(c, hipMemsetAsync(c->d_lam + (size_t)t1 * D, 0, sizeof(double) * D, st));
+  bool first = true;
+  while (true) {
+    const int t0 = (t1 - C > 0) ? (t1 - C) : 0;
+    const int n = t1 - t0 + 1;
+    hipError_t e = ld::lde_energy(D, n, c->theta[0], c->d_isg, A + (size_t)t0 * DD, b + (size_t)t0 * D, c->d_m + (size_t)t0 * D,
+                                  c->d_S + (size_t)t0 * DD, c->d_et + t0, c->d_Ef + (size_t)t0 * D, nullptr,
+                                  c->d_dEm + (size_t)t0 * D, c->d_dEs_c, c->d_status, c->d_lde_ws, c->lde_nb, st);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
+    if (g_dev) {
+      // Psi_{t1} sits in slot n-1: zero at the very end of the grid, else carried over from slot 0 of the previous chunk
+      if (first) HIP_TRY(c, hipMemsetAsync(c->d_psi_c + (size_t)(n - 1) * DD, 0, sizeof(double) * DD, st));
+      for (int t = t1; t > t0; t--) {
+        const int k = t - t0;
+        const int nobs = c->h_obs_idx[t - 1];
+        e = ld::ld_bwd_step(c->cfg.method, c->cfg.dt, D, A + (size_t)t * DD, A + (size_t)(t - 1) * DD,
+                            c->d_dEs_c + (size_t)k * DD, c->d_dEs_c + (size_t)(k - 1) * DD, c->d_dEm + (size_t)t * D,
+                            c->d_dEm + (size_t)(t - 1) * D, c->d_psi_c + (size_t)k * DD, c->d_lam + (size_t)t * D,
+                            c->d_psi_c + (size_t)(k - 1) * DD, c->d_lam + (size_t)(t - 1) * D,
+                            nobs >= 0 ? c->d_jsc : nullptr, nobs >= 0 ? c->d_jm + (size_t)nobs * D : nullptr, c->d_ld_ws, st);
+        if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D backward step failed: %s", hipGetErrorString(e));
+      }
+      // gradient of (t0, t1] -- and of t0 itself once the grid start is reached
+      const int g0 = (t0 == 0) ? 0 : t0 + 1;
+      const int gn = t1 - g0 + 1;
+      double* gA = g_dev + (size_t)g0 * DD;
+      double* gB = g_dev + (size_t)Np * DD + (size_t)g0 * D;
+      e = ld::lde_grad(D, gn, c->cfg.dt, c->d_isg, A + (size_t)g0 * DD, b + (size_t)g0 * D, c->d_m + (size_t)g0 * D,
+                       c->d_S + (size_t)g0 * DD, c->d_lam + (size_t)g0 * D, c->d_psi_c + (size_t)(g0 - t0) * DD,
+                       c->d_Ef + (size_t)g0 * D, gA, gB, c->d_lde_ws, c->lde_nb, st);
+      if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
+    }
+    if (t0 == 0) break;
+    if (g_dev) {   // Psi_{t0} becomes Psi_{t1} of the next chunk: slot 0 -> slot (t0 - t0_next)
+      const int t0n = (t0 - C > 0) ? (t0 - C) : 0;
+      HIP_TRY(c, hipMemcpyAsync(c->d_psi_c + (size_t)(t0 - t0n) * DD, c->d_psi_c, sizeof(double) * DD, hipMemcpyDeviceToDevice, st));
+    }
+    t1 = t0;
+    first = false;
+  }
+  return VGPA_OK;
+}
+
+// fwd -> E_obs -> chunked [E_sde terms -> bwd -> gradient] -> F, for the streamed large-D context
+static int enqueue_stream_sweep(vgpa_ctx* c, double* g_dev) {
+  if (!c->full) return fail(c, VGPA_ERR_STATE, "context was created without m0/s0/observations (ODE-only)");
+  int rc;
+  prof_collect(c);
+  HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  prof_mark(c, 0);
+  if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
+  prof_mark(c, 1);
+  hipError_t e = launch_obs(obs_args(c), c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
+  prof_mark(c, 2);
+  if ((rc = stream_pass(c, g_dev))) return rc;
+  prof_mark(c, 3);
+  if ((rc = run_reduce(c))) return rc;
+  c->have_state = true;
+  if (g_dev && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+  return VGPA_OK;
+}
+
 // fwd -> E_obs -> E_sde terms -> bwd -> F     (VarGP.free_energy, variational.py:141-200)
 static int enqueue_free_energy(vgpa_ctx* c) {
+  if (c->stream_ld) return enqueue_stream_sweep(c, nullptr);
   if (!c->full) return fail(c, VGPA_ERR_STATE, "context was created without m0/s0/observations (ODE-only)");
   int rc;
   prof_collect(c);
@@ -291,18 +391,7 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
   if ((rc = run_energy(c, nullptr))) return rc;
   prof_mark(c, 2);
-  if (c->D > kMaxSmallD) {      // the large-D backward driver consumes dense jump arrays
-    const size_t BN = (size_t)c->B * c->Np;
-    if (!c->d_jm_dense) {
-      if ((rc = dev_alloc(c, &c->d_jm_dense, BN * c->D))) return rc;
-      if ((rc = dev_alloc(c, &c->d_js_dense, BN * c->DD))) return rc;
-    }
-    HIP_TRY(c, hipMemsetAsync(c->d_jm_dense, 0, sizeof(double) * BN * c->D, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_js_dense, 0, sizeof(double) * BN * c->DD, c->stream));
-    e = launch_obs_dense(obs_args(c), c->d_jsc, c->d_jm_dense, c->d_js_dense, c->stream);
-    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs dense launch failed: %s", hipGetErrorString(e));
-  }
-  if ((rc = run_bwd(c, c->D > kMaxSmallD, c->sym_inputs))) return rc;
+  if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
   prof_mark(c, 3);
   if ((rc = run_reduce(c))) return rc;
   c->have_state = true;
@@ -413,16 +502,12 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   c->sym_inputs = is_symmetric(sigma.data(), D) && (!cfg->s0 || is_symmetric(cfg->s0, D));
 
   const size_t BN = (size_t)c->B * c->Np;
-  TRY(dev_alloc(c, &c->d_x, (size_t)c->B * c->len_x));
   TRY(dev_alloc(c, &c->d_m, BN * D));
   TRY(dev_alloc(c, &c->d_S, BN * DD));
   TRY(dev_alloc(c, &c->d_Ef, BN * D));
   if (cfg->model == VGPA_MODEL_L96 && D <= kMaxSmallD) TRY(dev_alloc(c, &c->d_Am, BN * D));
   TRY(dev_alloc(c, &c->d_dEm, BN * D));
-  TRY(dev_alloc(c, &c->d_dEs, BN * DD));
   TRY(dev_alloc(c, &c->d_lam, BN * D));
-  TRY(dev_alloc(c, &c->d_psi, BN * DD));
-  TRY(dev_alloc(c, &c->d_g, (size_t)c->B * c->len_x));
   TRY(dev_alloc(c, &c->d_et, BN));
   TRY(dev_alloc(c, &c->d_eobs, (size_t)c->B));
   TRY(dev_alloc(c, &c->d_esde, (size_t)c->B));
@@ -505,7 +590,19 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
     TRY(upload(c, c->d_obs_t, cfg->obs_t, (size_t)c->M));
     TRY(upload(c, c->d_obs_y, cfg->obs_y, (size_t)c->M * D));
   }
+  c->h_obs_idx = obs_idx;
   TRY(upload(c, c->d_obs_idx, obs_idx.data(), (size_t)c->Np));
+  if (D > kMaxSmallD && c->full && cfg->model == VGPA_MODEL_L96) {
+    // resident large-D sweep: S, dEsde_dS, Psi next to the caller's x and gradient.  Stream when asked to, or when
+    // that does not fit into what is free on the device now.
+    size_t free_b = 0, total_b = 0;
+    HTRY(hipMemGetInfo(&free_b, &total_b));
+    const double need = 8.0 * (double)BN * (double)DD * 4.0;        // dEs + Psi + the caller's x and g still to come
+    c->stream_ld = (cfg->flags & VGPA_FLAG_STREAM_LARGE_D) != 0 || need > 0.9 * (double)free_b;
+    c->ld_chunk = ld::lde_batch(D);
+    if (c->ld_chunk > c->Np - 1) c->ld_chunk = c->Np - 1;
+    if (c->ld_chunk < 1) c->ld_chunk = 1;
+  }
   TRY(upload(c, c->d_Q, Q.data(), DD));
   TRY(upload(c, c->d_K, K.data(), DD));
   TRY(upload(c, c->d_rinv, rinv.data(), (size_t)D));
@@ -556,6 +653,8 @@ int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, con
   }
   if ((rc = ingest_ab(c, lin_a, nullptr))) return rc;
   if ((rc = upload(c, c->d_dEm, desde_dm, BN * c->D))) return rc;
+  if ((rc = ensure(c, &c->d_dEs, BN * c->DD))) return rc;
+  if ((rc = ensure(c, &c->d_psi, BN * c->DD))) return rc;
   if ((rc = upload(c, c->d_dEs, desde_ds, BN * c->DD))) return rc;
   if ((rc = upload(c, c->d_jm_dense, deobs_dm, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_js_dense, deobs_ds, BN * c->DD))) return rc;
@@ -692,7 +791,21 @@ int vgpa_fetch_f(vgpa_ctx* c, double* f_host) {
   return check_status(c);
 }
 
+static int finish_gradient(vgpa_ctx* c, double* g_dev);
+
+// F and the gradient in one go (df(x, eval_fun=True)): the streamed context folds both into one chunked pass
+static int enqueue_sweep(vgpa_ctx* c, double* g_dev) {
+  if (c->stream_ld) return enqueue_stream_sweep(c, g_dev);
+  int rc = enqueue_free_energy(c);
+  return rc ? rc : finish_gradient(c, g_dev);
+}
+
 static int finish_gradient(vgpa_ctx* c, double* g_dev) {
+  if (c->stream_ld) {            // cached state = (m, S): the chunked pass recomputes the energy terms on its way back
+    int rc = stream_pass(c, g_dev);
+    if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+    return rc;
+  }
   int rc = run_grad(c, g_dev);
   if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
   return rc;
@@ -702,13 +815,13 @@ int vgpa_gradient(vgpa_ctx* c, const double* x_or_null, double* g) {
   if (!c || !g) return fail(c, VGPA_ERR_ARG, "null argument");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
+  if ((rc = ensure(c, &c->d_g, (size_t)c->B * c->len_x))) return rc;
   if (x_or_null) {
     if ((rc = ingest_x(c, x_or_null, false))) return rc;
-    if ((rc = enqueue_free_energy(c))) return rc;
+    if ((rc = enqueue_sweep(c, c->d_g))) return rc;
   } else if (!c->have_state) {
     return fail(c, VGPA_ERR_STATE, "gradient(x, eval_fun=False) needs the state cached by a previous free_energy");
-  }
-  if ((rc = finish_gradient(c, c->d_g))) return rc;
+  } else if ((rc = finish_gradient(c, c->d_g))) return rc;
   if ((rc = download(c, g, c->d_g, (size_t)c->B * c->len_x))) return rc;
   return check_status(c);
 }
@@ -717,9 +830,9 @@ int vgpa_sweep(vgpa_ctx* c, const double* x, double* f, double* g) {
   if (!c || !x || !f || !g) return fail(c, VGPA_ERR_ARG, "null argument");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
+  if ((rc = ensure(c, &c->d_g, (size_t)c->B * c->len_x))) return rc;
   if ((rc = ingest_x(c, x, false))) return rc;
-  if ((rc = enqueue_free_energy(c))) return rc;
-  if ((rc = finish_gradient(c, c->d_g))) return rc;
+  if ((rc = enqueue_sweep(c, c->d_g))) return rc;
   if ((rc = download(c, g, c->d_g, (size_t)c->B * c->len_x))) return rc;
   return vgpa_fetch_f(c, f);
 }
@@ -728,8 +841,7 @@ int vgpa_sweep_enqueue(vgpa_ctx* c, const double* x_dev, double* g_dev) {
   if (!c || !x_dev || !g_dev) return fail(c, VGPA_ERR_ARG, "null argument");
   int rc;
   if ((rc = ingest_x(c, x_dev, true))) return rc;
-  if ((rc = enqueue_free_energy(c))) return rc;
-  return finish_gradient(c, g_dev);
+  return enqueue_sweep(c, g_dev);
 }
 
 int vgpa_sweep_dev(vgpa_ctx* c, const double* x_dev, double* f_host, double* g_dev) {
@@ -760,10 +872,14 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
     case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;
     case VGPA_FETCH_ST: rc = download(c, out, c->d_S, BN * c->DD); break;
     case VGPA_FETCH_LAMT: rc = download(c, out, c->d_lam, BN * c->D); break;
-    case VGPA_FETCH_PSIT: rc = download(c, out, c->d_psi, BN * c->DD); break;
+    case VGPA_FETCH_PSIT:
+      if (!c->d_psi || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "Psi_t is not kept by the time-chunked large-D sweep");
+      rc = download(c, out, c->d_psi, BN * c->DD); break;
     case VGPA_FETCH_EFX: rc = download(c, out, c->d_Ef, BN * c->D); break;
     case VGPA_FETCH_DESDE_DM: rc = download(c, out, c->d_dEm, BN * c->D); break;
-    case VGPA_FETCH_DESDE_DS: rc = download(c, out, c->d_dEs, BN * c->DD); break;
+    case VGPA_FETCH_DESDE_DS:
+      if (!c->d_dEs || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "dEsde_dS is not kept by the time-chunked large-D sweep");
+      rc = download(c, out, c->d_dEs, BN * c->DD); break;
     case VGPA_FETCH_ESDE_T: rc = download(c, out, c->d_et, BN); break;
     case VGPA_FETCH_EDF: {
       if (!c->d_Edf && (rc = dev_alloc(c, &c->d_Edf, BN * c->DD))) return rc;
@@ -824,6 +940,20 @@ int vgpa_vec_axpby(vgpa_ctx* c, uint64_t seglen, const double* alpha, const doub
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "axpby failed: %s", hipGetErrorString(e));
   return VGPA_OK;
 }
+
+int vgpa_set_option(vgpa_ctx* c, int option, int64_t value) {
+  if (!c) return VGPA_ERR_ARG;
+  if (option == VGPA_OPT_LD_CHUNK) {
+    if (value < 1) return fail(c, VGPA_ERR_ARG, "chunk must be >= 1");
+    if (value > c->Np - 1) value = c->Np > 1 ? c->Np - 1 : 1;
+    if (c->d_dEs_c || c->d_psi_c) return fail(c, VGPA_ERR_STATE, "the chunk buffers exist already: set the option before the first sweep");
+    c->ld_chunk = (int)value;
+    return VGPA_OK;
+  }
+  return fail(c, VGPA_ERR_ARG, "unknown option %d", option);
+}
+
+int vgpa_is_streaming(vgpa_ctx* c) { return (c && c->stream_ld) ? 1 : 0; }
 
 // ---- raw device memory ------------------------------------------------------------------------------
 int vgpa_dev_alloc(vgpa_ctx* c, uint64_t bytes, void** out) {

@@ -119,7 +119,11 @@ size_t ld_workspace_doubles(int D);
 hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, const double* b, const double* m0,
                         const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st);
 hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
-                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st);
+                        const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st,
+                        const int32_t* obs_idx_host = nullptr);
+hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const double* Am, const double* Gt, const double* Gm,
+                       const double* gt, const double* gmm, const double* Pt, const double* lt, double* Pn, double* ln,
+                       const double* Jn, const double* jn, double* ws, hipStream_t st);
 size_t lde_workspace_doubles(int D, int nb);
 int lde_batch(int D);
 hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
