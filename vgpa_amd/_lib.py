@@ -161,6 +161,13 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class ExternalBuffer:
+    """A device allocation owned by someone else (e.g. a torch tensor's storage), passed by raw pointer."""
+
+    def __init__(self, ptr, count):
+        self.ptr, self.count = c_void_p(int(ptr)), int(count)
+
+
 class Context:
     """
     Owns one vgpa_ctx.  `model` in {"NONE","OU","DW","L63","L96"}, `method` in {"euler","heun","rk2","rk4"}.
