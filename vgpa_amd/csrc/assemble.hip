@@ -68,6 +68,52 @@ __global__ void __launch_bounds__(NT) k_obs(ObsArgs a) {
   if (tid == 0) a.eobs[prob] = 0.5 * (tot + a.obs_const);
 }
 
+// n-D, one workgroup per (observation, problem): the variant for large D / many observations.  part[prob][n] = term_n.
+__global__ void __launch_bounds__(NT) k_obs_nd(ObsArgs a) {
+  __shared__ double red[NT];
+  const int D = a.D, M = a.n_obs, n = blockIdx.x, prob = blockIdx.y, tid = threadIdx.x;
+  const int64_t tn = a.obs_t[n];
+  const double* y = a.obs_y + (size_t)n * D;
+  const double* mt = a.m + ((size_t)prob * a.Np + tn) * D;
+  const double* S = a.S + (size_t)prob * a.Np * D * D;
+  double* jm = a.jm_sparse + ((size_t)prob * M + n) * D;
+  double part = 0.0;
+  if (a.diag) {
+    for (int i = tid; i < D; i += NT) {
+      const double w = y[i] - mt[i];
+      jm[i] = -(a.K[(size_t)i * D + i] * w);
+      part += w * (a.Q[(size_t)i * D + i] * w) + a.rinv_diag[i] * S[((size_t)n * D + i) * D + i];   // Q4: S[n], not S[t_n]
+    }
+  } else {
+    // one wave per row i: coalesced reads of row i of Q and K
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < D; i += NT / 64) {
+      double qrow = 0.0, krow = 0.0;
+      for (int j = lane; j < D; j += 64) {
+        const double w = y[j] - mt[j];
+        qrow = __builtin_fma(a.Q[(size_t)i * D + j], w, qrow);
+        krow = __builtin_fma(a.K[(size_t)i * D + j], w, krow);
+      }
+      for (int o = 32; o > 0; o >>= 1) { qrow += __shfl_xor(qrow, o, 64); krow += __shfl_xor(krow, o, 64); }
+      if (lane == 0) {
+        jm[i] = -krow;
+        part += (y[i] - mt[i]) * qrow + a.rinv_diag[i] * S[((size_t)n * D + i) * D + i];
+      }
+    }
+  }
+  const double tot = block_sum(part, red);
+  if (tid == 0) a.part[(size_t)prob * M + n] = tot;
+}
+
+__global__ void __launch_bounds__(NT) k_obs_fin(ObsArgs a) {
+  __shared__ double red[NT];
+  const int M = a.n_obs, prob = blockIdx.x, tid = threadIdx.x;
+  double part = 0.0;
+  for (int n = tid; n < M; n += NT) part += a.part[(size_t)prob * M + n];
+  const double tot = block_sum(part, red);
+  if (tid == 0) a.eobs[prob] = 0.5 * (tot + a.obs_const);
+}
+
 // dense jump arrays for the operator-level API (zero off the observation rows)
 __global__ void __launch_bounds__(NT) k_obs_dense(ObsArgs a, const double* js_const, double* jm_dense, double* js_dense) {
   const int D = a.D, M = a.n_obs, prob = blockIdx.y, n = blockIdx.x;
@@ -382,6 +428,11 @@ hipError_t launch_trapz_multi(const double* e, int Np, int H, int batch, double 
 }
 
 hipError_t launch_obs(const ObsArgs& a, hipStream_t st) {
+  if (a.part && !a.single && a.n_obs > 0) {
+    hipLaunchKernelGGL(k_obs_nd, dim3(a.n_obs, a.batch), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL(k_obs_fin, dim3(a.batch), dim3(NT), 0, st, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_obs, dim3(a.batch), dim3(NT), 0, st, a);
   return hipGetLastError();
 }

@@ -275,17 +275,28 @@ hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // Single-rank drivers (one GPU owns every row): the per-step / per-stage loop of the four steppers, all launches on
 // one stream.  `ws` is a workspace of at least ld_workspace_doubles(D) doubles.
-size_t ld_workspace_doubles(int D) { return (size_t)5 * D * D + 4 * (size_t)D; }
+// mid-point operand 0.5 (A_k + A_{k+1}) (runge_kutta2.py:74, runge_kutta4.py:74): formed ONCE per step and shared by
+// the two stages that use it; the GEMM that averages while staging its A tile streams both operands and is ~2.3x
+// slower at D = 1024 (measured: 156 us vs 67 us) -- that variant stays for the row-sharded driver.
+__global__ void __launch_bounds__(256) k_mid(const double* __restrict__ a0, const double* __restrict__ a1, double* __restrict__ out,
+                                             size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = 0.5 * (a0[i] + a1[i]);
+}
+
+size_t ld_workspace_doubles(int D) { return (size_t)6 * D * D + 4 * (size_t)D; }
 
 namespace {
 struct Work {
-  double *W, *K1, *K23, *XA, *XB, *xvA, *xvB, *k1v, *k23v;
+  double *W, *K1, *K23, *XA, *XB, *AM, *xvA, *xvB, *k1v, *k23v;
 };
+// which pair of operands the mid-point buffer AM currently averages (valid inside one step)
+struct MidCache { const double* a0 = nullptr; const double* a1 = nullptr; };
 Work carve_work(double* ws, int D) {
   const size_t DD = (size_t)D * D;
   Work w;
   w.W = ws; w.K1 = w.W + DD; w.K23 = w.K1 + DD; w.XA = w.K23 + DD; w.XB = w.XA + DD;
-  w.xvA = w.XB + DD; w.xvB = w.xvA + D; w.k1v = w.xvB + D; w.k23v = w.k1v + D;
+  w.AM = w.XB + DD;
+  w.xvA = w.AM + DD; w.xvB = w.xvA + D; w.k1v = w.xvB + D; w.k23v = w.k1v + D;
   return w;
 }
 
@@ -301,8 +312,18 @@ struct StageSpec {
   int kstore, final_mode; double cx, cf;
 };
 
-hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st) {
-  GemmArgs g{D, D, D, s.Am0, s.Am1, D, s.X, D, w.W, D};
+hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, MidCache* mc = nullptr) {
+  const double *ga0 = s.Am0, *ga1 = s.Am1;
+  if (ga1 && mc) {
+    if (mc->a0 != ga0 || mc->a1 != ga1) {
+      const size_t n = (size_t)D * D;
+      const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+      hipLaunchKernelGGL(k_mid, dim3(blocks), dim3(256), 0, st, ga0, ga1, w.AM, n);
+      mc->a0 = ga0; mc->a1 = ga1;
+    }
+    ga0 = w.AM; ga1 = nullptr;
+  }
+  GemmArgs g{D, D, D, ga0, ga1, D, s.X, D, w.W, D};
   hipError_t e = launch_gemm(!s.fwd, g, st);
   if (e != hipSuccess) return e;
   StageArgs a{};
@@ -330,6 +351,7 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
     const double *Sk = S + k * DD, *mk = m + (size_t)k * D;
     double *Sn = S + (k + 1) * DD, *mn = m + (size_t)(k + 1) * D;
     StageSpec s{};
+    MidCache mc{};
     s.fwd = true; s.E0 = Sigma; s.base = Sk; s.vbase = mk;
     auto set = [&](const double* am0, const double* am1, const double* av0, const double* av1, const double* X,
                    const double* xv, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
@@ -338,19 +360,19 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
       s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
     };
     if (method == VGPA_ODE_EULER) {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st, &mc));
     } else if (method == VGPA_ODE_HEUN) {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st));
-      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st, &mc));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(run_stage(D, w, s, st, &mc));
     } else if (method == VGPA_ODE_RK2) {
       // covariance predictor: S_k stands in for A_k (reference quirk, runge_kutta2.py:96); mean predictor: A_k
-      set(Sk, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
-      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+      set(Sk, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st, &mc));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(run_stage(D, w, s, st, &mc));
     } else {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
-      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st));
-      set(Ak, Ak1, Ak, Ak1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st));
-      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(run_stage(D, w, s, st));
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st, &mc));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(run_stage(D, w, s, st, &mc));
+      set(Ak, Ak1, Ak, Ak1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(run_stage(D, w, s, st, &mc));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(run_stage(D, w, s, st, &mc));
     }
   }
   return hipSuccess;
@@ -364,6 +386,7 @@ hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const dou
   const Work w = carve_work(ws, D);
   const double h = 0.5 * dt;
   StageSpec s{};
+  MidCache mc{};
   s.fwd = false; s.base = Pt; s.vbase = lt;
   auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
                  const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
@@ -373,18 +396,18 @@ hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const dou
     s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
   };
   if (method == VGPA_ODE_EULER) {
-    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st, &mc));
   } else if (method == VGPA_ODE_HEUN) {
-    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(run_stage(D, w, s, st));
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st, &mc));
+    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(run_stage(D, w, s, st, &mc));
   } else if (method == VGPA_ODE_RK2) {
-    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st, &mc));
+    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st, &mc));
   } else {
-    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-    set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st));
-    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st));
+    set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st, &mc));
+    set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(run_stage(D, w, s, st, &mc));
+    set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(run_stage(D, w, s, st, &mc));
+    set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(run_stage(D, w, s, st, &mc));
   }
   return hipSuccess;
 }

@@ -38,6 +38,8 @@ struct vgpa_ctx {
   int ld_chunk = 0;
   double *d_dEs_c = nullptr, *d_psi_c = nullptr;
   std::vector<int32_t> h_obs_idx; // host copy of obs_idx [Np]
+  bool obs_diag = false;          // diagonal R and H = I: Q, K are diagonal
+  double* d_obs_part = nullptr;   // [B][M] per-observation energy terms (large-D observation kernel)
   double* d_hyp = nullptr;        // [B][Np][H] integrands of the hyper-parameter gradients (vgpa_energy_hyper only)
   double* d_hypT = nullptr;       // [B][H] their trapezoids
   bool hyp_on = false;
@@ -259,6 +261,7 @@ static ObsArgs obs_args(vgpa_ctx* c) {
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.n_obs = c->M; a.single = c->single ? 1 : 0;
   a.obs_t = c->d_obs_t; a.obs_y = c->d_obs_y; a.Q = c->d_Q; a.K = c->d_K; a.rinv_diag = c->d_rinv;
   a.obs_const = c->obs_const; a.m = c->d_m; a.S = c->d_S; a.jm_sparse = c->d_jm; a.eobs = c->d_eobs;
+  a.diag = c->obs_diag ? 1 : 0; a.part = c->d_obs_part;
   return a;
 }
 
@@ -586,6 +589,8 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
       c->obs_const = c->M * (D * std::log(2.0 * M_PI) + logdet);
       }
       c->sym_inputs = c->sym_inputs && is_symmetric(jsc.data(), D);
+      c->obs_diag = r_diag;
+      if (D > kMaxSmallD) TRY(dev_alloc(c, &c->d_obs_part, (size_t)c->B * c->M));   // one workgroup per observation
     }
     TRY(upload(c, c->d_obs_t, cfg->obs_t, (size_t)c->M));
     TRY(upload(c, c->d_obs_y, cfg->obs_y, (size_t)c->M * D));

@@ -72,6 +72,8 @@ struct ObsArgs {
   const double* S;          // [B][Np][D][D]
   double* jm_sparse;        // [B][M][D]
   double* eobs;             // [B]
+  int diag;                 // Q and K are diagonal (diagonal R, H = I)
+  double* part;             // [B][M] per-observation terms of the n-D energy (grid-parallel variant) or nullptr
 };
 
 struct GradArgs {
@@ -104,7 +106,7 @@ hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
-hipError_t launch_obs(const ObsArgs& a, hipStream_t st);
+hipError_t launch_obs(const ObsArgs& a, hipStream_t st);   // uses the grid-parallel variant when a.part != nullptr
 hipError_t launch_obs_dense(const ObsArgs& a, const double* js_const, double* jm_dense, double* js_dense,
                             hipStream_t st);
 hipError_t launch_grad(const GradArgs& a, hipStream_t st);
