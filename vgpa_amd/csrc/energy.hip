@@ -640,7 +640,7 @@ __device__ __forceinline__ void l96_syrk_rows(const double* __restrict__ pa, con
   }
 }
 
-__host__ __device__ inline size_t l96w4_lds_doubles(int D) { return l96_lds_doubles(D) + 8 * (size_t)l96_dp(D); }
+__host__ __device__ inline size_t l96w4_lds_doubles(int D) { return l96_lds_doubles(D) + 12 * (size_t)l96_dp(D); }
 
 template <int NB>
 __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
   S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
   S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
   double* vpart = S.vv + (2 * D + 1) + 7;          // [2][4][Dp] partial residual sums of the four waves
-  vpart = (double*)(((size_t)vpart) & ~(size_t)7);
+  double* xdiag = vpart + 8 * Dp;                  // [NB][4][4] inverses of the diagonal blocks of L
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
   const double theta = a.theta[0];
@@ -710,37 +710,74 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
 #if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 0
   return;
 #endif
-  // ---- 1. Cholesky, left-looking in panels of four columns: wave 0 (the 40-pivot chain is sequential)
-  if (wave == 0) {
-    bool bad = false;
-    for (int j0 = 0; j0 < Dp && !bad; j0 += 4) {
-      const double* rowi = S.Lm + li * LD;
-      double s0 = rowi[j0], s1 = rowi[j0 + 1], s2 = rowi[j0 + 2], s3 = rowi[j0 + 3];
-      const double* p0 = S.Lm + j0 * LD;
-      const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
-#pragma unroll 4
-      for (int k = 0; k < j0; k++) {
-        const double av = rowi[k];
-        s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
-        s2 = __builtin_fma(-av, p2[k], s2); s3 = __builtin_fma(-av, p3[k], s3);
+  // ---- 1. Cholesky, left-looking in panels of four columns.  Per panel p:
+  //   (a) every wave: U = L[4p:, :4p] . L[4p:4p+4, :4p]^T on the matrix cores -- wave w owns the block-rows
+  //       p + 4w + b (b = block of the 4x4x4_4b instruction) -- subtracted from the panel in place;
+  //   (b) wave 0: the four pivots of the panel (lane = row; the 40-pivot chain is the sequential part).
+  for (int p = 0; p < NB; p++) {
+    if (p > 0) {
+      if (p + 4 * wave < NB) {                               // wave-uniform: this wave has a block-row in the panel
+        const int Ib = p + 4 * wave + b;
+        const bool rowok = Ib < NB;
+        const int Ic = rowok ? Ib : NB - 1;
+        const double* arow = S.Lm + (4 * Ic + c4) * LD + r4;  // A-operand [i][k] = L[4I + i][4kk + k]
+        const double* brow = S.Lm + (4 * p + c4) * LD + r4;   // B-operand [k][j] = L[4p + j][4kk + k]
+        double u = 0.0;
+        for (int kk = 0; kk < p; kk++) u = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * kk], brow[4 * kk], u, 0, 0, 0);
+        if (rowok) S.Lm[(4 * Ib + r4) * LD + 4 * p + c4] -= u;   // D[i = r4][j = c4] of block b
       }
-      double lq[4], sq[4] = {s0, s1, s2, s3};
+      __syncthreads();
+    }
+    if (wave == 0) {
+      const int j0 = 4 * p;
+      const double* rowi = S.Lm + li * LD;
+      const double sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
+      double lq[4];
+      bool bad = false;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int j = j0 + q;
         double sx = sq[q];
 #pragma unroll
         for (int q2 = 0; q2 < q; q2++) sx = __builtin_fma(-lq[q2], lane_value(lq[q2], j), sx);
+#if defined(VGPA_W4_FAKE_LANE)
+        const double piv = sx + 1.0;
+#else
         const double piv = lane_value(sx, j);
+#endif
+#if !defined(VGPA_W4_FAKE_LANE) && !defined(VGPA_W4_FAKE_RSQ)
         if (!(piv > 0.0)) bad = true;
-        const double rdv = rsqrt(piv), dg = piv * rdv;
+#endif
+#if defined(VGPA_W4_FAKE_RSQ)
+        const double rdv = piv * 0.1, dg = piv * rdv;
+#else
+        const double rdv = rsqrt(piv), dg = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
+#endif
         lq[q] = (l > j) ? sx * rdv : 0.0;
         if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? dg : 0.0);
         if (l == j) S.rd[j] = rdv;
       }
-      wave_sync();
+      if (bad && l == 0) s_bad = 1;
     }
-    if (bad && l == 0) s_bad = 1;
+    __syncthreads();
+    if (s_bad) break;
+  }
+  // inverses of the 4x4 diagonal blocks of L (lane I < NB of wave 0; read after the next workgroup barrier)
+  if (!s_bad && tid < NB) {
+    const double* tb = S.Lm + (4 * tid) * LD + 4 * tid;
+    const double x00 = S.rd[4 * tid], x11 = S.rd[4 * tid + 1], x22 = S.rd[4 * tid + 2], x33 = S.rd[4 * tid + 3];
+    const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
+    const double x10 = -(t10 * x00) * x11;
+    const double x21 = -(t21 * x11) * x22;
+    const double x32 = -(t32 * x22) * x33;
+    const double x20 = -(t20 * x00 + t21 * x10) * x22;
+    const double x31 = -(t31 * x11 + t32 * x21) * x33;
+    const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
+    double* xo = xdiag + 16 * tid;
+    xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
+    xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
+    xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
+    xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
   }
   __syncthreads();
   if (s_bad) {
@@ -900,37 +937,37 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
     if (l == 0) a.e_t[o] = e_t;
     wave_sync();
 
-    // ---- 4. X = L^-1 into Gm, lane = column c (private), four rows at a time: wave 0
-    for (int i0 = 0; i0 < Dp; i0 += 4) {
-      const double* r0p = S.Lm + i0 * LD;
-      const double* r1p = r0p + LD; const double* r2p = r1p + LD; const double* r3p = r2p + LD;
-      double s0 = (i0 == l) ? 1.0 : 0.0, s1 = (i0 + 1 == l) ? 1.0 : 0.0, s2 = (i0 + 2 == l) ? 1.0 : 0.0,
-             s3 = (i0 + 3 == l) ? 1.0 : 0.0;
-      const double* xc = S.Gm + li;
-#pragma unroll 4
-      for (int k = 0; k < i0; k++) {
-        const double xv = xc[k * LD];
-        s0 = __builtin_fma(-r0p[k], xv, s0); s1 = __builtin_fma(-r1p[k], xv, s1);
-        s2 = __builtin_fma(-r2p[k], xv, s2); s3 = __builtin_fma(-r3p[k], xv, s3);
-      }
-      const double x0 = s0 * S.rd[i0];
-      s1 = __builtin_fma(-r1p[i0], x0, s1);
-      const double x1 = s1 * S.rd[i0 + 1];
-      s2 = __builtin_fma(-r2p[i0], x0, s2); s2 = __builtin_fma(-r2p[i0 + 1], x1, s2);
-      const double x2 = s2 * S.rd[i0 + 2];
-      s3 = __builtin_fma(-r3p[i0], x0, s3); s3 = __builtin_fma(-r3p[i0 + 1], x1, s3); s3 = __builtin_fma(-r3p[i0 + 2], x2, s3);
-      const double x3 = s3 * S.rd[i0 + 3];
-      if (pad) {
-        double* xw = S.Gm + i0 * LD + l;
-        xw[0] = x0; xw[LD] = x1; xw[2 * LD] = x2; xw[3 * LD] = x3;
+  }
+  __syncthreads();
+
+  // ---- 4. X = L^-1 into Gm by blocked forward substitution on the matrix cores.  Wave w owns the column blocks
+  //         4w .. 4w+3 of X for every block-row, so the recursion over block-rows needs no workgroup barrier:
+  //           T_b   = sum_{K < I} L[I][K] . X[K][J_b]          (accumulator; J_b = 4w + b)
+  //           X[I][J_b] = -inv(L[I][I]) . T_b                  (T_b is already laid out as the B-operand)
+  //         with X[I][I] = inv(L[I][I]) and zeros above the diagonal.
+  {
+    const int Jb = 4 * wave + b;
+    if (4 * wave < NB) {
+      double* xcol = S.Gm + r4 * LD + 4 * Jb + c4;           // X[4K + r4][4 J_b + c4]: B-operand and output position
+      const bool colok = Jb < NB;
+      for (int I = 0; I < NB; I++) {
+        double xo = 0.0;
+        if (I >= 4 * wave) {                                 // wave-uniform
+          const double* arow = S.Lm + (4 * I + c4) * LD + r4;  // A-operand [i][k] = L[4I + i][4K + k]
+          double tacc = 0.0;
+          for (int K = 4 * wave; K < I; K++)
+            tacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * K], colok ? xcol[4 * K * LD] : 0.0, tacc, 0, 0, 0);
+          const double xd = xdiag[16 * I + 4 * c4 + r4];     // A-operand [i][k] = inv(L[I][I])[i][k], lane (c4 = i, r4 = k)
+          const double prod = __builtin_amdgcn_mfma_f64_4x4x4f64(xd, tacc, 0.0, 0, 0, 0);
+          xo = (Jb < I) ? -prod : ((Jb == I) ? xdiag[16 * I + 4 * r4 + c4] : 0.0);
+        }
+        if (colok) xcol[4 * I * LD] = xo;                    // D[i = r4][j = c4]: X[4I + r4][4 J_b + c4]
+        wave_sync();
       }
     }
   }
   __syncthreads();
 
-#if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 4
-  return;
-#endif
   // ---- 5. dE/dm = (c/2) X^T delta (wave 3); dE/dS = (c/2) X^T diag(q) X on the matrix cores, q applied to the
   //         B fragment on the fly (no scaled copy of X in LDS); <f> by wave 2
   if (wave == 3) {
@@ -1029,7 +1066,10 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
     if (!a.one_wave) {
-      const size_t lds4 = l96w4_lds_doubles(a.D) * sizeof(double);
+      size_t lds4 = l96w4_lds_doubles(a.D) * sizeof(double);
+#ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
+      lds4 += VGPA_L96_LDSPAD;
+#endif
       const long long ntasks = (long long)a.Np * a.batch;
       if (ntasks > 0x7fffffffLL) return hipErrorInvalidValue;
 #define VGPA_L96W4_CASE(NBV)                                                                                            \
