@@ -260,8 +260,10 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
 hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
   // 128-row tiles reuse B twice as much; fall back to 64-row tiles when they would leave CUs without a workgroup
   const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128);
+  const long long wg64 = (long long)((g.N + BN - 1) / BN) * ((g.M + 63) / 64);
   if (wg128 >= 2 * 256) launch_gemm_bm<128>(transa, g, st);
-  else launch_gemm_bm<64>(transa, g, st);
+  else if (wg64 >= 2 * 256) launch_gemm_bm<64>(transa, g, st);
+  else launch_gemm_bm<32>(transa, g, st);      // D = 1024: 512 workgroups, two per CU hide each other's k-tile latency
   return hipGetLastError();
 }
 
