@@ -194,7 +194,7 @@ def main():
         "parity_check_rel_err_F": check,
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
         from oracle import vgpa_oracle as vo
         z = dict(model="L96", method=args.method, dt=dt, theta=8.0, sigma=p["model"].sigma, m0=p["m0"], s0=p["s0"],
                  mu0=p["mu0"], tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"],
