@@ -141,9 +141,12 @@ struct Geo {
   static constexpr int S1 = MAXU / 2;                     // slots [0,S1) use B fragment 0, slots [S1,MAXU) fragment 1
   static constexpr int P = 4 * NB;                        // padded dimension
   // LDS operand layouts ("k-pair interleaved"): element (k, c) of an operand matrix sits at
-  //     ((k >> 3) * 4 + (k & 3)) * LD + 2 * c + ((k >> 2) & 1)
-  // i.e. the fragments of two consecutive k-steps (kk = k >> 2 even / odd) are adjacent, so ONE ds_read_b128 per lane
-  // fetches both (a lone wave per SIMD reaches the LDS rate with b128 reads but only ~1/5 of it with b64 reads,
+  //     ((k >> 3) * 4 + ((k >> 1) & 3)) * LD + 2 * c + (k & 1)
+  // Rows 2j and 2j+1 share a 16-byte unit.  The eight rows 8g .. 8g+7 feed TWO k-steps of the 4x4x4 instruction: lane
+  // group r4 supplies row 8g + 2 r4 to the first and row 8g + 2 r4 + 1 to the second (any split of the eight rows into
+  // two sets of four works as long as both operands use the same one), so ONE ds_read_b128 per lane
+  // fetches both -- and the lanes r4 = 0, 1 of a 32-lane store group, which own ADJACENT rows of the stage state, write
+  // the two halves of the same units instead of colliding on the same banks (a lone wave per SIMD reaches the LDS rate with b128 reads but only ~1/5 of it with b64 reads,
   // MI355X_MICROARCH.md s.LDS).  LDX = 0 (mod 32) doubles makes the 16-wide B rows conflict-free for the b128 lane
   // groups; LDA = 8 or 24 (mod 32) doubles spreads the four 4-wide A rows of a fragment over the 64 banks.
   static constexpr int KKE = NB + (NB & 1);               // k-steps rounded up to even (extra rows are zero)
@@ -158,7 +161,7 @@ struct Geo {
 };
 
 // offset of element (k, c) in a k-pair interleaved operand matrix with leading dimension LD
-__host__ __device__ constexpr int pair_off(int k, int c, int LD) { return ((k >> 3) * 4 + (k & 3)) * LD + 2 * c + ((k >> 2) & 1); }
+__host__ __device__ constexpr int pair_off(int k, int c, int LD) { return ((k >> 3) * 4 + ((k >> 1) & 3)) * LD + 2 * c + (k & 1); }
 
 template <int NB, int NW>
 struct Lds {
