@@ -402,10 +402,12 @@ size_t lde_workspace_doubles(int D, int nb) {
   return (size_t)nb * (3 * DD + (size_t)lde::NBLK * D + 4 * (size_t)D + (2 * (size_t)D + 1));
 }
 
-int lde_batch(int D) {
+// grid points per batch for a workspace budget in bytes: the diagonal-block kernel runs ONE wave per (grid point,
+// 64 x 64 block) and D / 64 of them in sequence, so small batches leave the chip idle (D = 4096 with a 1 GB budget: 2)
+int lde_batch(int D, double budget_bytes) {
   const double per_t = 3.1 * D * D * 8.0;
-  int nb = (int)(1.0e9 / per_t);
-  return nb < 1 ? 1 : (nb > 64 ? 64 : nb);
+  int nb = (int)(budget_bytes / per_t);
+  return nb < 1 ? 1 : (nb > 128 ? 128 : nb);
 }
 
 #define LDE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)

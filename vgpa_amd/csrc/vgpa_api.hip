@@ -47,6 +47,7 @@ struct vgpa_ctx {
   double* d_vec_scratch = nullptr; // [2B coefficients | B results | B*bps partials] of the vector algebra
   size_t vec_scratch_n = 0;
   int lde_nb = 1;
+  double lde_budget = 1.0e9;      // bytes the batched large-D energy workspace may take
   int64_t* d_obs_t = nullptr;
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
@@ -235,7 +236,7 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
 
 static int ensure_lde_ws(vgpa_ctx* c) {
   if (c->d_lde_ws) return VGPA_OK;
-  c->lde_nb = ld::lde_batch(c->D);
+  c->lde_nb = ld::lde_batch(c->D, c->lde_budget);
   if (c->lde_nb > c->Np) c->lde_nb = c->Np;
   return dev_alloc(c, &c->d_lde_ws, ld::lde_workspace_doubles(c->D, c->lde_nb));
 }
@@ -605,7 +606,8 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
     HTRY(hipMemGetInfo(&free_b, &total_b));
     const double need = 8.0 * (double)BN * (double)DD * 4.0;        // dEs + Psi + the caller's x and g still to come
     c->stream_ld = (cfg->flags & VGPA_FLAG_STREAM_LARGE_D) != 0 || need > 0.9 * (double)free_b;
-    c->ld_chunk = ld::lde_batch(D);
+    c->lde_budget = std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b));   // workspace of the batched energy terms
+    c->ld_chunk = ld::lde_batch(D, c->lde_budget) - 1;   // a chunk evaluates ld_chunk + 1 grid points: exactly one energy batch
     if (c->ld_chunk > c->Np - 1) c->ld_chunk = c->Np - 1;
     if (c->ld_chunk < 1) c->ld_chunk = 1;
   }

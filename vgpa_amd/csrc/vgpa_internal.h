@@ -128,7 +128,7 @@ hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const dou
                        const double* gt, const double* gmm, const double* Pt, const double* lt, double* Pn, double* ln,
                        const double* Jn, const double* jn, double* ws, hipStream_t st);
 size_t lde_workspace_doubles(int D, int nb);
-int lde_batch(int D);
+int lde_batch(int D, double budget_bytes);
 hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
                       const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
                       double* ws, int nbmax, hipStream_t st);
