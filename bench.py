@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=40)
     ap.add_argument("--method", default="RK4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-problem", action="store_true",
+                    help="skip the single-problem latency probe (so that a kernel profile of the run holds batched launches only)")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) stepping kernels")
     return ap.parse_args()
 
@@ -127,7 +129,7 @@ def main():
 
     # ---- single-problem latency (what one SCG evaluation costs), rank 0, outside the timed region
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_single_problem:
         c1 = va.Context("L96", args.method, d, n_pts, dt, sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"],
                         obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=1,
                         device=local_rank, flags=flags)
@@ -156,21 +158,41 @@ def main():
     total_sweeps = B * args.steps * world
     value = total_sweeps / elapsed
     steps = max(args.steps, 1)
-    # dominant kernel: the backward (Psi) stepping kernel; one launch integrates B problems
+    # per-kernel rooflines; the one reported as `roofline` is the kernel with the longest launch (the dominant one)
     fwd_s, bwd_s = prof["fwd_ms"] / steps * 1e-3, prof["bwd_ms"] / steps * 1e-3
-    dom, dom_s = ("solve_bwd", bwd_s) if bwd_s >= fwd_s else ("solve_fwd", fwd_s)
+    en_s, gr_s = prof["energy_ms"] / steps * 1e-3, prof["grad_ms"] / steps * 1e-3
     alg_flop = B * (n_pts - 1) * 8.0 * d ** 3               # RK4: 4 stages x one D^3 product (symmetry) x 2 flop
-    alg_bytes_fwd = B * 8.0 * n_pts * (2 * d * d + 2 * d)   # read A,b ; write S,m
-    alg_bytes_bwd = B * 8.0 * n_pts * (3 * d * d + 2 * d)   # read A, dEsde/dS, dEsde/dm ; write Psi, lam
-    alg_bytes = alg_bytes_bwd if dom == "solve_bwd" else alg_bytes_fwd
-    tfl = alg_flop / dom_s / 1e12
-    gbs = alg_bytes / dom_s / 1e9
-    traffic = None
+    tj = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        key = f"{dom}_B{B}_D{d}_Np{n_pts}"
-        traffic = tj.get(key)
+
+    def traffic_of(name):
+        return tj.get(f"{name}_B{B}_D{d}_Np{n_pts}")
+
+    kernels = {
+        # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
+        "solve_fwd": dict(bound="mfma", seconds=fwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
+                          alg_bytes=B * 8.0 * n_pts * (2 * d * d + 2 * d)),       # read A,b ; write S,m
+        "solve_bwd": dict(bound="mfma", seconds=bwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
+                          alg_bytes=B * 8.0 * n_pts * (3 * d * d + 2 * d)),       # read A, dEsde/dS, dEsde/dm ; write Psi, lam
+        # per-grid-point kernels: HBM (energy: AI = 4 D^3 / (24 D^2) = D/6 flop/B; gradient: 2 D^3 / (32 D^2) = D/16)
+        "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (3 * d * d + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
+                           unit="GB/s"),                                          # read S, A, m, b ; write dEsde/dS, dEsde/dm, <f>, A m, e_t
+        "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * (4 * d * d + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
+                     unit="GB/s"),                                                # read A, S, Psi + vectors ; write gLa, gLb
+    }
+    roof = {}
+    for name, k in kernels.items():
+        ach = k["alg"] / max(k["seconds"], 1e-12) / k["scale"]
+        roof[name] = {"bound": k["bound"], "kernel": name, "achieved": ach, "peak": k["peak"], "unit": k["unit"],
+                      "frac": ach / k["peak"], "traffic": traffic_of(name), "launch_ms": 1e3 * k["seconds"],
+                      ("alg_flop_per_launch" if k["bound"] == "mfma" else "alg_bytes_per_launch"): k["alg"]}
+    dom = max(kernels, key=lambda n: kernels[n]["seconds"])
+    dom_s = kernels[dom]["seconds"]
+    step_dom = "solve_bwd" if bwd_s >= fwd_s else "solve_fwd"
+    alg_bytes = kernels[step_dom]["alg_bytes"]
+    gbs = alg_bytes / kernels[step_dom]["seconds"] / 1e9
     sweep_bytes = 8.0 * n_pts * (5 * d * d + 6 * d)         # SURVEY.md s.8d algorithmic bytes of one fused sweep
     out = {
         "metric": "fwd+bwd sweeps/sec (free-energy+grad eval), Lorenz96 D=40 N=1000",
@@ -180,15 +202,14 @@ def main():
         "config": {"workload": f"Lorenz96 D={d}, {args.method.upper()}, Np={n_pts} (BASELINE configs[2])",
                    "batch_per_gpu": B, "sharding": "independent problems per GPU, no collective",
                    "kernels": "generic" if args.generic else "mfma"},
-        "roofline": {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tfl / FP64_PEAK_TFLOPS, "traffic": traffic,
-                     "launch_ms": 1e3 * dom_s, "alg_flop_per_launch": alg_flop,
-                     "note": "fp64 stepping kernel at D=40 is matrix-pipe bound (AI = D/2 flop/B > ridge ~10)"},
-        "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": dict(roof[dom], note="kernel with the longest launch of the sweep; energy+obs phase = k_energy_l96_w4 + k_obs "
+                                         "(0.1 ms); all four kernels under roofline_kernels"),
+        "roofline_kernels": roof,
+        "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
                          "whole_sweep_GBs": sweep_bytes * value / world / 1e9,
                          "whole_sweep_frac": sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS},
-        "phase_ms_per_step": {"fwd": 1e3 * fwd_s, "energy+obs": prof["energy_ms"] / steps, "bwd": 1e3 * bwd_s,
+        "phase_ms_per_step": {"fwd": 1e3 * fwd_s, "energy+obs": 1e3 * en_s, "bwd": 1e3 * bwd_s,
                               "reduce+grad": prof["grad_ms"] / steps},
         "single_problem": single,
         "parity_check_rel_err_F": check,
