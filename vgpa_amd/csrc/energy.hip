@@ -640,7 +640,12 @@ __device__ __forceinline__ void l96_syrk_rows(const double* __restrict__ pa, con
   }
 }
 
-__host__ __device__ inline size_t l96w4_lds_doubles(int D) { return l96_lds_doubles(D) + 12 * (size_t)l96_dp(D); }
+// two matrices + 7 vectors + vv[1 + Dp] (v_0, r0^2) + vpart[8][Dp] + xdiag[NB][16]: 4089 doubles at D = 40, i.e. five
+// tasks per CU (5 x 32 KB = 160 KB)
+__host__ __device__ inline size_t l96w4_lds_doubles(int D) {
+  const size_t dp = l96_dp(D);
+  return 2 * dp * l96_ld(D) + 7 * dp + (dp + 1) + 8 * dp + 4 * dp;
+}
 
 template <int NB>
 __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
@@ -659,7 +664,7 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
   L96Lds S;
   S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
   S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
-  double* vpart = S.vv + (2 * D + 1) + 7;          // [2][4][Dp] partial residual sums of the four waves
+  double* vpart = S.vv + (Dp + 1);                 // [2][4][Dp] partial residual sums of the four waves
   double* xdiag = vpart + 8 * Dp;                  // [NB][4][4] inverses of the diagonal blocks of L
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
