@@ -683,8 +683,13 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
     for (int q = 0; q < EPT; q++) {
       const int e = tid + q * NT;
       const bool in = e < DD;
+#if defined(VGPA_W4_NOMEM)   // diagnostic build only: synthetic operands instead of the HBM reads (wrong results)
+      sv[q] = in ? ((e % (D + 1)) == 0 ? 2.0 : 0.001) : 0.0;
+      av[q] = in ? 0.01 * (double)(e & 7) : 0.0;
+#else
       sv[q] = in ? St[e] : 0.0;
       av[q] = in ? At[e] : 0.0;
+#endif
     }
     if (tid == 0) s_bad = 0;
     if (D < Dp) {
@@ -1001,7 +1006,11 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int col = 16 * q + 4 * b + c4;
+#if defined(VGPA_W4_NOMEM)
+        if (I < NB && row < D && col < D && acc[q * RW + ii] == 1.2345e300) ds[row * D + col] = 0.0;
+#else
         if (I < NB && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[q * RW + ii];
+#endif
       }
     }
 #pragma unroll
