@@ -888,6 +888,13 @@ __global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
       double* gcol = S.Gm + jc;
       for (int i = i_lo; i < i_hi; i++) {
         const double gi = gcol[i * LD], ami = S.am[i], bvi = S.bv[i], sgi = S.sg[i];
+#if defined(VGPA_W4_EXTRA_LDS)   // diagnostic build only: six more LDS reads per row (is the kernel bound by LDS instructions?)
+        {
+          const volatile double* vq = S.qq;
+          double junk = vq[i] + vq[i + 1] + vq[i + 2] + vq[i + 3] + vq[i + 4] + vq[i + 5];    // (runs into rd[]: still inside the carve-up)
+          if (junk == 1.2345e300) vplus += 1.0;
+        }
+#endif
         const double ra = ((a1 - am2) * am1 - a0 + theta) + (ami + gi) - bvi;
         const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
         vplus = __builtin_fma(sgi, ra * ra, vplus);
