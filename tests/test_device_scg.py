@@ -85,3 +85,21 @@ def test_batched_device_scg_equals_independent_runs():
         assert int(run.statistics["MaxIt"][k]) == its
         assert abs(fb[k] - fs) <= 1e-9 * abs(fs)
         assert np.abs(xb[k] - xs).max() <= 1e-7 * np.abs(xs).max()
+
+
+@pytest.mark.parametrize("stream", [False, True])
+def test_device_scg_on_the_large_d_path(stream):
+    """D > 64: the GEMM-per-stage drivers (resident and time-chunked) behind the same optimiser."""
+    from vgpa_amd._lib import FLAG_STREAM_LARGE_D
+    p = build_problem("L96", "RK4", 0.5, 0.01, 72)
+    args = (p["model"], p["m0"], p["s0"], p["fwd"], p["bwd"], p["lik"], p["kl0"], p["obs_y"], p["obs_t"])
+    v = va.VarGP(*args, flags=FLAG_STREAM_LARGE_D if stream else 0)
+    assert v._context().streaming == stream
+    x0 = v.initialization()
+    opts = {"max_it": 4, "x_tol": 1e-6, "f_tol": 1e-8}
+    host = va.SCG(v.free_energy, v.gradient, dict(opts))
+    x_h, f_h = host(x0.copy())
+    dev = v.device_scg(dict(opts))
+    x_d, f_d = dev(x0.copy())
+    assert abs(f_d - f_h) <= 1e-9 * abs(f_h) and np.abs(x_d - x_h).max() <= 1e-7 * np.abs(x_h).max()
+    assert f_d < v.free_energy(x0)
