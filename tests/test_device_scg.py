@@ -103,3 +103,25 @@ def test_device_scg_on_the_large_d_path(stream):
     x_d, f_d = dev(x0.copy())
     assert abs(f_d - f_h) <= 1e-9 * abs(f_h) and np.abs(x_d - x_h).max() <= 1e-7 * np.abs(x_h).max()
     assert f_d < v.free_energy(x0)
+
+
+def test_optimiser_trace_equals_the_references_at_baseline_size():
+    """Three SCG iterations at BASELINE configs[2] (L96, D=40, RK4, Np=1001): the objective after every iteration, the
+    trust-region scale and the final x must equal what the REFERENCE produced (tests/golden/scg_trace_config3.json,
+    generated by tools/gen_scg_anchor.py in 101 s of CPU time) -- for the host SCG and for the device-resident one."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "scg_trace_config3.json")))
+    p = build_problem("L96", "RK4", 10.0, 0.01, 40)
+    v = p["vgp"]
+    x0 = v.initialization()
+    opts = {"max_it": 3, "x_tol": 1e-6, "f_tol": 1e-8, "display": False}
+    for make in (lambda: va.SCG(v.free_energy, v.gradient, dict(opts)), lambda: v.device_scg(dict(opts))):
+        opt = make()
+        x, fx = opt(x0.copy())
+        st = opt.statistics
+        assert np.allclose(np.asarray(st["fx"])[:3].ravel(), ref["fx_trace"], rtol=1e-9, atol=0)
+        assert np.allclose(np.asarray(st["beta"])[:3].ravel(), ref["beta_trace"], rtol=1e-12, atol=0)
+        assert abs(fx - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
+        assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-11 * ref["x_norm"]
