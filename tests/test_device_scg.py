@@ -125,3 +125,31 @@ def test_optimiser_trace_equals_the_references_at_baseline_size():
         assert np.allclose(np.asarray(st["beta"])[:3].ravel(), ref["beta_trace"], rtol=1e-12, atol=0)
         assert abs(fx - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
         assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-11 * ref["x_norm"]
+
+
+def test_whole_optimisation_equals_the_references_at_baseline_size():
+    """The reference's complete optimisation at BASELINE configs[2] (SCG until its own termination: 30 iterations, 50
+    objective evaluations, 523 s of CPU time; tests/golden/scg_full_config3.json): same iteration count, same number
+    of evaluations, same objective after every iteration, same trust-region scale, same minimum."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "scg_full_config3.json")))
+    n_it = ref["MaxIt_stat"]
+    p = build_problem("L96", "RK4", 10.0, 0.01, 40)
+    v = p["vgp"]
+    x0 = v.initialization()
+    opts = {"max_it": 500, "x_tol": 1e-6, "f_tol": 1e-8, "display": False}
+    host = va.SCG(v.free_energy, v.gradient, dict(opts))
+    x, fx = host(x0.copy())
+    st = host.statistics
+    assert st["MaxIt"] == n_it and st["f_eval"] == ref["f_eval"]
+    assert np.allclose(st["fx"][:n_it], ref["fx_trace"][:n_it], rtol=1e-9, atol=0)
+    assert np.allclose(st["beta"][:n_it], ref["beta_trace"][:n_it], rtol=1e-12, atol=0)
+    assert abs(fx - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
+    assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-11 * ref["x_norm"]
+    dev = v.device_scg(dict(opts))
+    x_d, f_d = dev(x0.copy())
+    assert int(dev.statistics["MaxIt"][0]) == n_it
+    assert np.allclose(dev.statistics["fx"][:n_it, 0], ref["fx_trace"][:n_it], rtol=1e-9, atol=0)
+    assert abs(f_d - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
