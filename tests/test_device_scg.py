@@ -153,3 +153,23 @@ def test_whole_optimisation_equals_the_references_at_baseline_size():
     assert int(dev.statistics["MaxIt"][0]) == n_it
     assert np.allclose(dev.statistics["fx"][:n_it, 0], ref["fx_trace"][:n_it], rtol=1e-9, atol=0)
     assert abs(f_d - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
+
+
+@pytest.mark.parametrize("cfg", ["config1", "config2"])
+def test_whole_optimisation_of_the_small_configs(cfg):
+    """BASELINE configs[0] (OU, Euler) and configs[1] (Lorenz-63, RK4), t in [0, 10]: the reference's complete SCG run
+    (52 / 57 iterations, 110 / 159 evaluations; tests/golden/scg_full_config{1,2}.json) against the host SCG here."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, f"scg_full_{cfg}.json")))
+    n_it = ref["MaxIt_stat"]
+    p = build_problem(ref["model"], ref["method"], ref["tf"], 0.01, None)
+    v = p["vgp"]
+    host = va.SCG(v.free_energy, v.gradient, {"max_it": ref["max_it"], "x_tol": 1e-6, "f_tol": 1e-8, "display": False})
+    x, fx = host(v.initialization())
+    st = host.statistics
+    assert st["MaxIt"] == n_it and st["f_eval"] == ref["f_eval"]
+    assert np.allclose(st["fx"][:n_it], ref["fx_trace"], rtol=1e-7, atol=0)
+    assert abs(fx - ref["f_final"]) <= 1e-8 * abs(ref["f_final"])
+    assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-7 * ref["x_norm"]
