@@ -150,8 +150,13 @@ def test_whole_optimisation_equals_the_references_at_baseline_size():
     assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-11 * ref["x_norm"]
     dev = v.device_scg(dict(opts))
     x_d, f_d = dev(x0.copy())
-    assert int(dev.statistics["MaxIt"][0]) == n_it
-    assert np.allclose(dev.statistics["fx"][:n_it, 0], ref["fx_trace"][:n_it], rtol=1e-9, atol=0)
+    # The last ~20 iterations make no progress (beta grows by 4 per rejected step until the step falls under x_tol) and
+    # the stopping test |f_new - f_old| <= 1e-8 sits at the rounding level of F ~ 3.7e4, so the device-resident variant
+    # (different summation order in its dot products) may stop a couple of rejected steps earlier or later.
+    n_dev = int(dev.statistics["MaxIt"][0])
+    assert abs(n_dev - n_it) <= 3
+    n_cmp = min(n_dev, n_it)
+    assert np.allclose(dev.statistics["fx"][:n_cmp, 0], ref["fx_trace"][:n_cmp], rtol=1e-9, atol=0)
     assert abs(f_d - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
 
 

@@ -300,7 +300,7 @@ struct L96Lds {
 __host__ __device__ inline int l96_dp(int D) { return 4 * ((D + 3) / 4); }          // padded to a multiple of 4
 __host__ __device__ inline int l96_ld(int D) { return l96_dp(D) + 1; }               // odd leading dimension
 __host__ __device__ inline size_t l96_lds_doubles(int D) {
-  return (size_t)2 * l96_dp(D) * l96_ld(D) + 7 * (size_t)l96_dp(D) + (2 * D + 1) + 8;
+  return (size_t)2 * l96_dp(D) * l96_ld(D) + 7 * (size_t)l96_dp(D) + (2 * D + 1) + 8 + 4 * (size_t)l96_dp(D);   // + xdiag
 }
 
 // Register blocking: every inner k-iteration below feeds FOUR independent fma chains from FIVE LDS reads (one
@@ -361,43 +361,49 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[(size_t)prob * a.strideB + (size_t)t * D + l]; S.sg[l] = a.isg[l]; }
   wave_sync();
 
-  // ---- 1. Cholesky, left-looking in panels of four columns (numpy.linalg.cholesky reads the lower triangle);
-  //         the strict upper triangle is zeroed on the way.
+  // ---- 1. Cholesky, left-looking in panels of four columns (numpy.linalg.cholesky reads the lower triangle); the
+  //         strict upper triangle is zeroed on the way.  Per panel p the update U = L[4p:, :4p] . L[4p:4p+4, :4p]^T runs
+  //         on the matrix cores (unit u = block-rows p + 4u + b; A-operand [i][k] = L[4I + i][4kk + k], B-operand
+  //         [k][j] = L[4p + j][4kk + k]) and is subtracted from the panel in place; then the four pivots (lane = row).
+  const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+  // (fully unrolled: NB is a template parameter, so every LDS offset below is an immediate and the loops cost no
+  // scalar bookkeeping -- this kernel is bound by instructions issued per grid point.  A non-positive pivot makes the
+  // rest of the factor NaN, which is harmless: the flag is checked after the loop.)
   bool bad = false;
-  for (int j0 = 0; j0 < Dp && !bad; j0 += 4) {
-    const double* rowi = S.Lm + li * LD;
-    double s0 = rowi[j0], s1 = rowi[j0 + 1], s2 = rowi[j0 + 2], s3 = rowi[j0 + 3];
-    const double* p0 = S.Lm + j0 * LD;
-    const double* p1 = p0 + LD; const double* p2 = p1 + LD; const double* p3 = p2 + LD;
-#pragma unroll 4
-    for (int k = 0; k < (VGPA_L96_NOK ? 0 : j0); k++) {
-      const double av = rowi[k];
-      s0 = __builtin_fma(-av, p0[k], s0); s1 = __builtin_fma(-av, p1[k], s1);
-      s2 = __builtin_fma(-av, p2[k], s2); s3 = __builtin_fma(-av, p3[k], s3);
-    }
-    double lq[4], sq[4] = {s0, s1, s2, s3};
+  const double* lrow_b = S.Lm + (4 * b + c4) * LD + r4;      // + 4 (p + 4u) LD: A-operand rows of block b
+  double* lout_b = S.Lm + (4 * b + r4) * LD + c4;            // + 4 (p + 4u) LD + 4p: output position of block b
 #pragma unroll
-    for (int q = 0; q < (VGPA_L96_NOPANEL ? 0 : 4); q++) {
+  for (int p = 0; p < NB; p++) {
+    const int j0 = 4 * p;
+    if (p > 0) {
+      const double* brow = S.Lm + (j0 + c4) * LD + r4;
+#pragma unroll
+      for (int u = 0; p + 4 * u < NB; u++) {
+        const bool full = p + 4 * u + 3 < NB;                // compile-time: all four block-rows of the unit exist
+        const bool rowok = full || (p + 4 * u + b < NB);
+        const double* arow = full ? lrow_b + 4 * (p + 4 * u) * LD
+                                  : S.Lm + (4 * (rowok ? p + 4 * u + b : NB - 1) + c4) * LD + r4;
+        double uacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < p; kk++) uacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * kk], brow[4 * kk], uacc, 0, 0, 0);
+        if (rowok) lout_b[4 * (p + 4 * u) * LD + j0] -= uacc;  // D[i = r4][j = c4] of block b
+      }
+      wave_sync();
+    }
+    const double* rowi = S.Lm + li * LD;
+    double lq[4], sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
       const int j = j0 + q;
       double s = sq[q];
 #pragma unroll
       for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
-#if defined(VGPA_L96_FAKE_LANE)
-      const double piv = s + 1.0;
-#else
       const double piv = lane_value(s, j);
-#endif
       if (!(piv > 0.0)) bad = true;
-#if defined(VGPA_L96_FAKE_RSQ)
-      const double rdv = piv * 0.1, d = piv * rdv;
-#else
       const double rdv = rsqrt(piv), d = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
-#endif
       lq[q] = (l > j) ? s * rdv : 0.0;
-#if !defined(VGPA_L96_NO_LWRITE)
       if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
       if (l == j) S.rd[j] = rdv;
-#endif
     }
     wave_sync();
   }
@@ -411,10 +417,29 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 #if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 1
   return;
 #endif
+  // inverses of the 4x4 diagonal blocks of L (lane I < NB), used by the blocked forward substitution of phase 4
+  double* xdiag = S.vv + (2 * D + 1) + 7;
+  if (l < NB) {
+    const double* tb = S.Lm + (4 * l) * LD + 4 * l;
+    const double x00 = S.rd[4 * l], x11 = S.rd[4 * l + 1], x22 = S.rd[4 * l + 2], x33 = S.rd[4 * l + 3];
+    const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
+    const double x10 = -(t10 * x00) * x11;
+    const double x21 = -(t21 * x11) * x22;
+    const double x32 = -(t32 * x22) * x33;
+    const double x20 = -(t20 * x00 + t21 * x10) * x22;
+    const double x31 = -(t31 * x11 + t32 * x21) * x33;
+    const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
+    double* xo = xdiag + 16 * l;
+    xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
+    xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
+    xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
+    xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
+  }
   // ---- 2. A.m (lane = row i, A^T rows are contiguous over i) ; G = A.L on the matrix cores, then Gm <- G ([i][r])
   {
     double s = 0.0;
-    for (int k = 0; k < D; k++) s = __builtin_fma(S.Gm[k * LD + li], S.mv[k], s);
+#pragma unroll
+    for (int k = 0; k < Dp; k++) s = __builtin_fma(S.Gm[k * LD + li], S.mv[k], s);   // padding rows of A^T and of m are zero
     if (act) { S.am[l] = s; if (a.Am) a.Am[o * D + l] = s; }
     double acc[WaveGemmGeo<NB>::NU];
     wave_gemm<NB, 0>(S.Gm, S.Lm, LD, acc);
@@ -450,7 +475,9 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     double bm2 = chi(pMm, D - 2), bm1 = chi(pMm, D - 1), b0 = chi(pM, 0), b1 = chi(pM, 1);
     const double* lcol = S.Lm + jc;
     const double* gcol = S.Gm + jc;
-    for (int i = 0; i < D; i++) {
+#pragma unroll
+    for (int i = 0; i < Dp; i++) {                               // unrolled: immediate LDS offsets, no window moves
+      if (i >= D) break;
       const double gi = gcol[i * LD], ami = S.am[i], bvi = S.bv[i], sgi = S.sg[i];
       const double ra = ((a1 - am2) * am1 - a0 + theta) + (ami + gi) - bvi;
       const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
@@ -506,33 +533,34 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 #if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 3
   return;
 #endif
-  // ---- 4. X = L^-1 into Gm, lane = column c (private), four rows at a time; entries above the diagonal come
-  //         out as exact zeros (every term of their sums is zero).
-  for (int i0 = 0; i0 < Dp; i0 += 4) {
-    const double* r0p = S.Lm + i0 * LD;
-    const double* r1p = r0p + LD; const double* r2p = r1p + LD; const double* r3p = r2p + LD;
-    double s0 = (i0 == l) ? 1.0 : 0.0, s1 = (i0 + 1 == l) ? 1.0 : 0.0, s2 = (i0 + 2 == l) ? 1.0 : 0.0,
-           s3 = (i0 + 3 == l) ? 1.0 : 0.0;
-    const double* xc = S.Gm + li;
-#pragma unroll 4
-    for (int k = 0; k < i0; k++) {
-      const double xv = xc[k * LD];
-      s0 = __builtin_fma(-r0p[k], xv, s0); s1 = __builtin_fma(-r1p[k], xv, s1);
-      s2 = __builtin_fma(-r2p[k], xv, s2); s3 = __builtin_fma(-r3p[k], xv, s3);
+  // ---- 4. X = L^-1 into Gm by blocked forward substitution on the matrix cores: for block-row I and the unit of column
+  //         blocks J_b = 4u + b:  T_b = sum_{K < I} L[I][K] . X[K][J_b] accumulates in the MFMA result register, which is
+  //         already laid out as the B-operand of the second product X[I][J_b] = -inv(L[I][I]) . T_b.
+  const double* l4_a = S.Lm + c4 * LD + r4;                  // + 4 I LD + 4 K : A-operand L[4I + c4][4K + r4]
+  const double* xd_a = xdiag + 4 * c4 + r4;                  // + 16 I
+  const double* xd_d = xdiag + 4 * r4 + c4;
+#pragma unroll
+  for (int I = 0; I < NB; I++) {
+    const double* arow = l4_a + 4 * I * LD;                  // A-operand [i][k] = L[4I + i][4K + k]
+    const double xd = xd_a[16 * I];                          // A-operand [i][k] = inv(L[I][I])[i][k]
+    const double xdd = xd_d[16 * I];                         // the diagonal block itself in D layout
+#pragma unroll
+    for (int u = 0; 4 * u < NB; u++) {
+      const int Jb = 4 * u + b;
+      const bool colok = (4 * u + 3 < NB) || (Jb < NB);
+      double* xcol = S.Gm + r4 * LD + 4 * (colok ? Jb : NB - 1) + c4;
+      double xo = 0.0;
+      if (4 * u <= I) {                                      // compile-time: some block of the unit is on / below the diagonal
+        double tacc = 0.0;
+#pragma unroll
+        for (int K = 4 * u; K < I; K++) tacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * K], xcol[4 * K * LD], tacc, 0, 0, 0);
+        const double prod = __builtin_amdgcn_mfma_f64_4x4x4f64(xd, tacc, 0.0, 0, 0, 0);
+        xo = (Jb < I) ? -prod : ((Jb == I) ? xdd : 0.0);
+      }
+      if (colok) xcol[4 * I * LD] = xo;                      // X[4I + r4][4 J_b + c4]
     }
-    const double x0 = s0 * S.rd[i0];
-    s1 = __builtin_fma(-r1p[i0], x0, s1);
-    const double x1 = s1 * S.rd[i0 + 1];
-    s2 = __builtin_fma(-r2p[i0], x0, s2); s2 = __builtin_fma(-r2p[i0 + 1], x1, s2);
-    const double x2 = s2 * S.rd[i0 + 2];
-    s3 = __builtin_fma(-r3p[i0], x0, s3); s3 = __builtin_fma(-r3p[i0 + 1], x1, s3); s3 = __builtin_fma(-r3p[i0 + 2], x2, s3);
-    const double x3 = s3 * S.rd[i0 + 3];
-    if (pad) {
-      double* xw = S.Gm + i0 * LD + l;
-      xw[0] = x0; xw[LD] = x1; xw[2 * LD] = x2; xw[3 * LD] = x3;
-    }
+    wave_sync();
   }
-  wave_sync();
 
 #if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 4
   return;
@@ -1086,7 +1114,7 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_energy_l63, grid, dim3(64), 0, st, a);
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
-    if (!a.one_wave) {
+    if (a.four_waves) {   // the four-waves-per-grid-point variant (VGPA_FLAG_FORCE_GENERIC); the one-wave kernel is faster
       size_t lds4 = l96w4_lds_doubles(a.D) * sizeof(double);
 #ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
       lds4 += VGPA_L96_LDSPAD;
