@@ -231,7 +231,7 @@ struct WaveGemmGeo {
 
 template <int NB, int MODE>
 __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const double* __restrict__ Bm, int LD,
-                                          double (&acc)[WaveGemmGeo<NB>::NU]) {
+                                          double (&acc)[WaveGemmGeo<NB>::NU], const double* __restrict__ bscale = nullptr) {
   using g = WaveGemmGeo<NB>;
   const int l = threadIdx.x & 63, r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
   constexpr int rem = g::REM ? g::REM : 1;
@@ -244,12 +244,13 @@ __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const 
   const int ileft = b / rem;                                 // block-row offset inside a left-over unit
 #pragma unroll
   for (int kk = 0; kk < NB; kk++) {
+    const double bs = bscale ? bscale[4 * kk + r4] : 1.0;      // B[k][j] <- bscale[k] * B[k][j] applied to the fragment
     double bq[g::NQ > 0 ? g::NQ : 1];
 #pragma unroll
     for (int q = 0; q < g::NQ; q++)
-      if (kk >= 4 * q) bq[q] = pb[kk * 4 * LD + 16 * q + colq];
+      if (kk >= 4 * q) bq[q] = bscale ? bs * pb[kk * 4 * LD + 16 * q + colq] : pb[kk * 4 * LD + 16 * q + colq];
     double bl = 0.0;
-    if (g::NLEFT > 0 && kk >= 4 * g::NQ) bl = pb[kk * 4 * LD + coll];
+    if (g::NLEFT > 0 && kk >= 4 * g::NQ) bl = bscale ? bs * pb[kk * 4 * LD + coll] : pb[kk * 4 * LD + coll];
 #pragma unroll
     for (int I = 0; I < NB; I++) {
       if (MODE == 1 && kk < I) continue;
@@ -565,19 +566,16 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 #if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 4
   return;
 #endif
-  // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X.  Lm <- diag(q) X (L is no longer needed).
+  // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
     for (int k = 0; k < Dp; k++) s = __builtin_fma(S.Gm[k * LD + li], S.dl[k], s);   // X[k][l] = 0 for k < l
     if (act) a.dEm[o * D + l] = 0.5 * c * s;
   }
-  for (int k = 0; k < Dp; k++)
-    if (pad) S.Lm[k * LD + l] = S.qq[k] * S.Gm[k * LD + l];
-  wave_sync();
   double* ds = a.dEs + o * D * D;
   {
     double acc[WaveGemmGeo<NB>::NU];
-    wave_gemm<NB, 1>(S.Gm, S.Lm, LD, acc);       // X^T (diag(q) X)
+    wave_gemm<NB, 1>(S.Gm, S.Gm, LD, acc, S.qq);   // X^T (diag(q) X): q applied to the B fragments on the fly
 #pragma unroll
     for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
       int row, col; bool ok;
