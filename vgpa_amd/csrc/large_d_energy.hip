@@ -25,6 +25,10 @@ struct GemmB {
   double* C; long long ldc, sC;
   double alpha, beta;
   int lower_only;                         // skip tiles that lie strictly above the diagonal
+  int k_tri;                              // operands with known zero blocks: 1 = op(B)[k][j] = 0 for k < j (B lower
+                                          // triangular): the k loop of a tile starts at its first column; 2 = also
+                                          // op(A)[i][k] = 0 for k < i: it starts at max(first row, first column).
+                                          // Only exact zeros are skipped, so the result is bit-identical.
 };
 
 template <bool TA, bool TB, int BM>
@@ -84,10 +88,16 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
   const int nk = (g.K + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
+  int kt0 = 0;
+  if (g.k_tri == 1) kt0 = j0 / BK;
+  else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
+  if (kt0 > nk) kt0 = nk;
+  if (kt0 < nk) {
+    load_tiles(kt0 * BK);
+    store_tiles(kt0 & 1);
+  }
   __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
+  for (int kt = kt0; kt < nk; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
     const double* as = As[cur] + fk * LDAS + (BM / 2) * wm + fi;
@@ -466,6 +476,7 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
       GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
       a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = C + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = X; a1.ldb = D; a1.sB = DD;
       a1.C = T1; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
+      a1.k_tri = 1;                                  // X[0:r0, 0:r0] is lower triangular
       LDE_TRY(gemm_b(false, false, a1, nb, st));
       GemmB a2{};  // X[I, 0:r0] = -X_II T1
       a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = X + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = T1; a2.ldb = D;
@@ -476,6 +487,7 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     GemmB gg{};
     gg.M = D; gg.N = D; gg.K = D; gg.A = At; gg.lda = D; gg.sA = DD; gg.B = C; gg.ldb = D; gg.sB = DD; gg.C = G; gg.ldc = D;
     gg.sC = DD; gg.alpha = 1.0; gg.beta = 0.0;
+    gg.k_tri = 1;                                    // L is lower triangular (strict upper part zeroed above)
     LDE_TRY(gemm_b(false, false, gg, nb, st));
     hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, At, DD, mt, (long long)D, am, (long long)D, 1.0);
     // ---- residuals, scalars
@@ -490,6 +502,7 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     GemmB sy{};
     sy.M = D; sy.N = D; sy.K = D; sy.A = X; sy.lda = D; sy.sA = DD; sy.B = C; sy.ldb = D; sy.sB = DD;
     sy.C = dEs + (size_t)t0 * DD; sy.ldc = D; sy.sC = DD; sy.alpha = 0.5 * c; sy.beta = 0.0;
+    sy.k_tri = 2;                                    // X^T[i][k] = X[k][i] = 0 for k < i and (q X)[k][j] = 0 for k < j
     LDE_TRY(gemm_b(true, false, sy, nb, st));
     if (Edf) hipLaunchKernelGGL(k_edf, dim3(eg, nb), dim3(NT), 0, st, D, mt, Edf + (size_t)t0 * DD);
     LDE_TRY(hipGetLastError());
