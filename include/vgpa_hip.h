@@ -68,6 +68,8 @@ enum {
 enum {
   VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
   VGPA_FLAG_FOUR_WAVES = 2,    /* diagnostics: MFMA steppers with four waves per problem where eight are the default */
+  VGPA_FLAG_LIBRARY_GEMM = 8,  /* D > 64: rocBLAS dgemm (dlopen'ed) for the plain stage products W = A.X / A^T.Psi instead of the
+                                  hand-written MFMA GEMM; everything fused stays hand-written.  Off by default. */
   VGPA_FLAG_STREAM_LARGE_D = 4 /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and
                                   dEsde_dS_t live in chunk buffers; VGPA_FETCH_PSIT is unavailable).  Chosen automatically
                                   when the resident arrays would not fit into free device memory. */

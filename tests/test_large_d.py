@@ -340,3 +340,23 @@ def test_time_chunked_sweep_equals_the_resident_one(d, n, chunk, method):
     with pytest.raises(RuntimeError):
         st.set_option(OPT_LD_CHUNK, 3)                          # buffers exist already
     st.close(); res.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_library_gemm_backend_of_the_stage_product(method):
+    """VGPA_FLAG_LIBRARY_GEMM swaps the plain stage GEMM for rocBLAS dgemm (dlopen'ed); same sweep to 1e-9 of the oracle
+    and of the hand-written GEMM, resident and time-chunked."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    from vgpa_amd._lib import FLAG_LIBRARY_GEMM, FLAG_STREAM_LARGE_D
+    p, x = make_problem("L96", 96, 14, method=method)
+    f_o, g_o, _ = vo.sweep(p, x, faithful=False)
+    own = gpu_context(p)
+    f_h, g_h = own.sweep(x)
+    for flags in (FLAG_LIBRARY_GEMM, FLAG_LIBRARY_GEMM | FLAG_STREAM_LARGE_D):
+        ctx = gpu_context(p, flags=flags)
+        f, g = ctx.sweep(x)
+        assert abs(f - f_o) <= TOL * abs(f_o) and rel_err(g, g_o) < TOL
+        assert abs(f - f_h) <= 1e-12 * abs(f_h) and rel_err(g, g_h) < 1e-11
+        ctx.close()
+    own.close()

@@ -2,7 +2,7 @@
 """BASELINE configs[3]: Lorenz-96, D = 1024, RK4, N = 10000 (Np = 10001) on ONE MI355X -- the fused sweep
 (free energy + gradient) in the time-chunked mode that keeps only x, S_t and the gradient resident (3 x 84 GB).
 
-    python tools/bench_config4.py [D] [Np] [reps]
+    python tools/bench_config4.py [D] [Np] [reps] [lib]      # `lib`: rocBLAS dgemm for the plain stage products (yardstick)
 
 Inputs are generated on the device (torch is plumbing: memory + RNG): the build's own generator of SURVEY.md s.8d --
 Sigma = 4 I, S0 = 0.2 I, m0 = 8 + N(0,1), A_t = 8 I + 0.05 N(0,1)/sqrt(D), b_t = 8 m0 + N(0,1), observation density 8
@@ -23,10 +23,11 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     import vgpa_amd as va
-    from vgpa_amd._lib import ExternalBuffer, FLAG_STREAM_LARGE_D
+    from vgpa_amd._lib import ExternalBuffer, FLAG_STREAM_LARGE_D, FLAG_LIBRARY_GEMM
     d = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     n_req = int(sys.argv[2]) if len(sys.argv) > 2 else 10001
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    lib_gemm = len(sys.argv) > 4 and sys.argv[4] == "lib"
     dev = torch.device("cuda", 0)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     per_pt = 3 * (d * d + d) * 8                      # x, g, S (+ the vectors) per grid point
@@ -57,7 +58,7 @@ def main():
     g = torch.empty(len_x, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     ctx = va.Context("L96", "rk4", d, n, dt, sigma=4.0 * np.eye(d), theta=[8.0], m0=m0, s0=0.2 * np.eye(d), obs_t=obs_t,
-                     obs_y=obs_y, obs_noise=np.eye(d), e0=0.0, flags=FLAG_STREAM_LARGE_D)
+                     obs_y=obs_y, obs_noise=np.eye(d), e0=0.0, flags=FLAG_STREAM_LARGE_D | (FLAG_LIBRARY_GEMM if lib_gemm else 0))
     assert ctx.streaming
     xb, gb = ExternalBuffer(x.data_ptr(), len_x), ExternalBuffer(g.data_ptr(), len_x)
     t0 = time.perf_counter()
@@ -90,7 +91,7 @@ def main():
            "fwd_tflops": flop_rec / (pr["fwd_ms"] / reps) / 1e9,
            "sweep_tflops": flop_sweep / t_sweep / 1e12,
            "resident_GB": 3 * (d * d + d) * n * 8 / 1e9, "hbm_free_before_GB": free_b / 1e9, "hbm_free_after_GB": free_after / 1e9,
-           "chunk": None}
+           "stage_gemm": "rocBLAS dgemm (VGPA_FLAG_LIBRARY_GEMM)" if lib_gemm else "hand-written k_gemm"}
     if s_last is not None:
         out["S_T_asym"] = float(np.abs(s_last - s_last.T).max())
     print(json.dumps(out))

@@ -285,6 +285,8 @@ __global__ void __launch_bounds__(256) k_mid(const double* __restrict__ a0, cons
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = 0.5 * (a0[i] + a1[i]);
 }
 
+thread_local bool use_library_gemm = false;
+
 size_t ld_workspace_doubles(int D) { return (size_t)6 * D * D + 4 * (size_t)D; }
 
 namespace {
@@ -325,8 +327,20 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
     }
     ga0 = w.AM; ga1 = nullptr;
   }
-  GemmArgs g{D, D, D, ga0, ga1, D, s.X, D, w.W, D};
-  hipError_t e = launch_gemm(!s.fwd, g, st);
+  hipError_t e;
+  if (use_library_gemm && !ga1) {
+    // plain GEMM, one rank: cw = D is plain row-major.  Backward: W' = A^T.Psi would be a transposed-A product (slow in
+    // the library at D = 1024); Psi is symmetric, so Z = Psi.A = W'^T is computed instead -- the stage kernel uses W'
+    // and W'^T symmetrically (R = -G + W' + W'^T), only the order of its two additions changes.
+    // (measured: the library's transposed-A product runs at 31 / 66 / 74 TFLOP/s for D = 1024 / 2048 / 4096, its plain
+    // product at 50 / 60 / 67 -- the detour pays below D = 2048 only)
+    e = s.fwd ? library_gemm(false, D, D, D, ga0, D, s.X, D, w.W, D, st)
+              : (D < 2048 ? library_gemm(false, D, D, D, s.X, D, ga0, D, w.W, D, st)
+                          : library_gemm(true, D, D, D, ga0, D, s.X, D, w.W, D, st));
+  } else {
+    GemmArgs g{D, D, D, ga0, ga1, D, s.X, D, w.W, D};
+    e = launch_gemm(!s.fwd, g, st);
+  }
   if (e != hipSuccess) return e;
   StageArgs a{};
   a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;

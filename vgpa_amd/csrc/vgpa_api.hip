@@ -171,6 +171,7 @@ static int ensure_ld_ws(vgpa_ctx* c) {
 }
 
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
+  ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
   if (c->D > kMaxSmallD) {
     if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric s0 and sigma");
     int rc = ensure_ld_ws(c);
@@ -192,6 +193,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
 }
 
 static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
+  ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
   int rc;
   if ((rc = ensure(c, &c->d_psi, (size_t)c->B * c->Np * c->DD))) return rc;
   if ((rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD))) return rc;
@@ -308,6 +310,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
 // g_dev == nullptr: energy integrand only (what F needs).  Same kernels, same per-grid-point arithmetic as the
 // resident path, so the results are identical.
 static int stream_pass(vgpa_ctx* c, double* g_dev) {
+  ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
   const int D = c->D, Np = c->Np, C = c->ld_chunk;
   const size_t DD = c->DD;
   int rc;

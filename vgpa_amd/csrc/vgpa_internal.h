@@ -124,6 +124,11 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
 hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, const double* gm, const double* gs,
                         const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st,
                         const int32_t* obs_idx_host = nullptr);
+// optional rocBLAS backend of the plain stage GEMM (lib_gemm.cpp); `use_library_gemm` is read by the single-rank drivers
+bool library_gemm_available();
+hipError_t library_gemm(bool transa, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                        hipStream_t st);
+extern thread_local bool use_library_gemm;
 hipError_t ld_bwd_step(int method, double dt, int D, const double* At, const double* Am, const double* Gt, const double* Gm,
                        const double* gt, const double* gmm, const double* Pt, const double* lt, double* Pn, double* ln,
                        const double* Jn, const double* jn, double* ws, hipStream_t st);
