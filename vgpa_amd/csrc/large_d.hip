@@ -39,7 +39,8 @@ struct GemmArgs {
   int cw;
 };
 
-template <bool TRANSA, bool MID, int BM>
+// FULL: M, N, K are multiples of the tile sizes -- no bounds checks (each one is an EXEC-masked branch in the k loop)
+template <bool TRANSA, bool MID, int BM, bool FULL>
 __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
   constexpr int LDAS = BM + 17;   // odd: conflict-free transposing stores (NN), near conflict-free fragment reads
   constexpr int MT = BM / 32;     // 16-row MFMA tiles per wave along M (wave tile = (BM/2) x 32)
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
       else { k = tid & 15; i = (tid >> 4) + 16 * q; }
       const int gi = i0 + i, gk = k0 + k;
       double v = 0.0;
-      if (gi < g.M && gk < g.K) {
+      if (FULL || (gi < g.M && gk < g.K)) {
         const size_t idx = TRANSA ? ((size_t)gk * g.lda + gi) : ((size_t)gi * g.lda + gk);
         v = MID ? 0.5 * (g.A0[idx] + g.A1[idx]) : g.A0[idx];
       }
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     for (int q = 0; q < 4; q++) {
       const int j = tid & 63, k = (tid >> 6) + 4 * q;
       const int gj = j0 + j, gk = k0 + k;
-      rb[q] = (gj < g.N && gk < g.K) ? g.B[(size_t)gk * g.ldb + gj] : 0.0;
+      rb[q] = (FULL || (gj < g.N && gk < g.K)) ? g.B[(size_t)gk * g.ldb + gj] : 0.0;
     }
   };
   auto store_tiles = [&](int buf) {
@@ -244,17 +245,23 @@ __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
   }
 }
 
-template <int BM>
-static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
+template <int BM, bool FULL>
+static void launch_gemm_bm_f(bool transa, const GemmArgs& g, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
   const bool mid = g.A1 != nullptr;
   if (transa) {
-    if (mid) hipLaunchKernelGGL((k_gemm<true, true, BM>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm<true, false, BM>), grid, dim3(NT), 0, st, g);
+    if (mid) hipLaunchKernelGGL((k_gemm<true, true, BM, FULL>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<true, false, BM, FULL>), grid, dim3(NT), 0, st, g);
   } else {
-    if (mid) hipLaunchKernelGGL((k_gemm<false, true, BM>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm<false, false, BM>), grid, dim3(NT), 0, st, g);
+    if (mid) hipLaunchKernelGGL((k_gemm<false, true, BM, FULL>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<false, false, BM, FULL>), grid, dim3(NT), 0, st, g);
   }
+}
+
+template <int BM>
+static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
+  if (g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0) launch_gemm_bm_f<BM, true>(transa, g, st);
+  else launch_gemm_bm_f<BM, false>(transa, g, st);
 }
 
 hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
