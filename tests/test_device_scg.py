@@ -129,8 +129,8 @@ def test_optimiser_trace_equals_the_references_at_baseline_size():
 
 def test_whole_optimisation_equals_the_references_at_baseline_size():
     """The reference's complete optimisation at BASELINE configs[2] (SCG until its own termination: 30 iterations, 50
-    objective evaluations, 523 s of CPU time; tests/golden/scg_full_config3.json): same iteration count, same number
-    of evaluations, same objective after every iteration, same trust-region scale, same minimum."""
+    objective evaluations, 523 s of CPU time; tests/golden/scg_full_config3.json): same objective after every iteration,
+    same trust-region scale, same minimum; the iteration count may differ by the length of the stalled tail."""
     import json
     import os
     from conftest import GOLDEN_DIR
@@ -143,16 +143,19 @@ def test_whole_optimisation_equals_the_references_at_baseline_size():
     host = va.SCG(v.free_energy, v.gradient, dict(opts))
     x, fx = host(x0.copy())
     st = host.statistics
-    assert st["MaxIt"] == n_it and st["f_eval"] == ref["f_eval"]
-    assert np.allclose(st["fx"][:n_it], ref["fx_trace"][:n_it], rtol=1e-9, atol=0)
-    assert np.allclose(st["beta"][:n_it], ref["beta_trace"][:n_it], rtol=1e-12, atol=0)
+    # The last ~20 iterations make no progress (beta grows by 4 per rejected step until the step falls under x_tol) and
+    # the stopping test |f_new - f_old| <= 1e-8 sits at the rounding level of F ~ 3.7e4, so a run whose F differs from
+    # the reference's in the last bits (the kernels sum in a different order than numpy) may stop a couple of rejected
+    # steps earlier or later; every iteration both runs have is compared, and so is the minimum.
+    n_host = int(st["MaxIt"])
+    assert abs(n_host - n_it) <= 3 and abs(int(st["f_eval"]) - ref["f_eval"]) <= 3
+    n_cmp = min(n_host, n_it)
+    assert np.allclose(st["fx"][:n_cmp], ref["fx_trace"][:n_cmp], rtol=1e-9, atol=0)
+    assert np.allclose(st["beta"][:n_cmp], ref["beta_trace"][:n_cmp], rtol=1e-12, atol=0)
     assert abs(fx - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
     assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-11 * ref["x_norm"]
     dev = v.device_scg(dict(opts))
     x_d, f_d = dev(x0.copy())
-    # The last ~20 iterations make no progress (beta grows by 4 per rejected step until the step falls under x_tol) and
-    # the stopping test |f_new - f_old| <= 1e-8 sits at the rounding level of F ~ 3.7e4, so the device-resident variant
-    # (different summation order in its dot products) may stop a couple of rejected steps earlier or later.
     n_dev = int(dev.statistics["MaxIt"][0])
     assert abs(n_dev - n_it) <= 3
     n_cmp = min(n_dev, n_it)

@@ -317,7 +317,11 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
   const size_t o = (size_t)prob * a.Np + t;
   L96Lds S;
+#ifdef VGPA_L96_ALIAS   // diagnostic build only (WRONG results): one matrix in LDS, to measure what the occupancy would buy
+  S.Lm = smem; S.Gm = S.Lm; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
+#else
   S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
+#endif
   S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
@@ -596,6 +600,392 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       const int k = e / D, j = e - k * D;
       const int kp1 = wrap(k + 1, D), km1 = wrap(k - 1, D), km2 = wrap(k - 2, D);
       // same assignment order as the reference: later assignments win when indices coincide
+      double v = 0.0;
+      if (j == k) v = -1.0;
+      if (j == kp1) v = S.mv[km1];
+      if (j == km2) v = -S.mv[km1];
+      if (j == km1) v = S.mv[kp1] - S.mv[km2];
+      ed[e] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Lorenz-96, one wave per grid point with ONE matrix in LDS -- the shipped kernel whenever the hyper-parameter
+//  integrands are not asked for.  k_energy_l96 above is bound by the number of waves a CU can hold (measured: 5 / 4 / 3
+//  / 2 resident waves -> 6.35 / 7.7 / 9.9 / 14.0 ms), and that number is set by its two LDS matrices.  Here
+//    * A never goes through LDS: every lane loads its MFMA A-operand fragments A[16u + (l & 15)][4K + (l >> 4)] straight
+//      from HBM at kernel entry (they arrive while the Cholesky factorisation runs),
+//    * A.m and G = A.L use those fragments with the blocks of L as the shared operand (I-major units), so G stays in
+//      the accumulators: lane (b, r4, c4) holds G[16u + 4b + r4][4J + c4],
+//    * the sigma-point residuals are evaluated in that accumulator layout (four LDS reads of L per element, rows
+//      2 .. D-2; the three rows whose flat-roll neighbours belong to other sigma points -- 0, 1, D-1 (quirk Q1) -- are
+//      done afterwards with lane = column from three parked rows of G), summed over the rows by one ones-MFMA (k = r4)
+//      and four partial rows in LDS (b),
+//    * L^-1 overwrites L in place (block-row I of L is dead once block-row I of the inverse is known).
+//  LDS per grid point at D = 40: 18.9 KB instead of 30.5 KB -> 8 waves per CU instead of 5.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t l96r_lds_doubles(int D) {
+  const size_t dp = l96_dp(D);
+  return dp * l96_ld(D) + 7 * dp + 11 * dp;      // L + vectors + scratch (4 + 4 partial rows, 3 rows of G; later xdiag)
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_energy_l96_r(EnergyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int D = a.D, M = 2 * D + 1;
+  constexpr int Dp = 4 * NB, LD = Dp + 1, NUU = (NB + 3) / 4;
+  const int l = threadIdx.x;
+  const long long wid = blockIdx.x;
+  const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
+  const size_t o = (size_t)prob * a.Np + t;
+  L96Lds S;
+  S.Lm = smem; S.Gm = nullptr; S.mv = S.Lm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
+  S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
+  double* pv = S.vv;                 // [4][Dp] partial sums (over the rows of block-slot b) of the plus points
+  double* pw = pv + 4 * Dp;          // [4][Dp] ... of the minus points
+  double* gb = pw + 4 * Dp;          // [3][Dp] rows 0, 1, D-1 of G
+  double* xdiag = pv;                // phase 4 (the partial sums are dead by then)
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
+  const double* St = a.S + o * D * D;
+  const double theta = a.theta[0];
+  const double kappa = 1.05 * D, c = D + kappa;
+  const bool act = l < D;
+  const bool pad = l < Dp;
+  const int li = pad ? l : Dp - 1;
+  const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+
+  // ---- A-operand fragments of A, straight from HBM: unit u = block-rows 4u + b, fragment [i = c4][k = r4]
+  double af[NUU][NB];
+#pragma unroll
+  for (int u = 0; u < NUU; u++) {
+    const int row = 16 * u + (l & 15);
+#pragma unroll
+    for (int K = 0; K < NB; K++) {
+      const int col = 4 * K + r4;
+      af[u][K] = (row < D && col < D) ? At[row * D + col] : 0.0;
+    }
+  }
+
+  // ---- stage c*S into LDS (coalesced); padding: identity
+  if (D < Dp) {
+    for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
+  }
+  if (pad) { S.mv[l] = 0.0; S.bv[l] = 0.0; S.sg[l] = 0.0; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
+  wave_sync();
+  {
+    constexpr int EPL = (Dp * Dp + 63) / 64;
+    const int DD = D * D;
+    const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;
+#pragma unroll
+    for (int q0 = 0; q0 < EPL; q0 += 13) {
+      double sv[13];
+#pragma unroll
+      for (int u = 0; u < 13; u++) {
+        const int e = l + 64 * (q0 + u);
+        const bool in = (q0 + u < EPL) && (e < DD);
+        sv[u] = in ? St[e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 13; u++) {
+        const int e = l + 64 * (q0 + u);
+        if ((q0 + u < EPL) && (e < DD)) {
+          const int r = (int)(((unsigned)e * magic) >> 20), cc = e - r * D;
+          S.Lm[r * LD + cc] = c * sv[u];
+        }
+      }
+    }
+  }
+  if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
+  if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[(size_t)prob * a.strideB + (size_t)t * D + l]; S.sg[l] = a.isg[l]; }
+  wave_sync();
+
+  // ---- 1. Cholesky (identical to k_energy_l96)
+  bool bad = false;
+  const double* lrow_b = S.Lm + (4 * b + c4) * LD + r4;
+  double* lout_b = S.Lm + (4 * b + r4) * LD + c4;
+#pragma unroll
+  for (int p = 0; p < NB; p++) {
+    const int j0 = 4 * p;
+    if (p > 0) {
+      const double* brow = S.Lm + (j0 + c4) * LD + r4;
+#pragma unroll
+      for (int u = 0; p + 4 * u < NB; u++) {
+        const bool full = p + 4 * u + 3 < NB;
+        const bool rowok = full || (p + 4 * u + b < NB);
+        const double* arow = full ? lrow_b + 4 * (p + 4 * u) * LD
+                                  : S.Lm + (4 * (rowok ? p + 4 * u + b : NB - 1) + c4) * LD + r4;
+        double uacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < p; kk++) uacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * kk], brow[4 * kk], uacc, 0, 0, 0);
+        if (rowok) lout_b[4 * (p + 4 * u) * LD + j0] -= uacc;
+      }
+      wave_sync();
+    }
+    const double* rowi = S.Lm + li * LD;
+    double lq[4], sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = j0 + q;
+      double s = sq[q];
+#pragma unroll
+      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
+      const double piv = lane_value(s, j);
+      if (!(piv > 0.0)) bad = true;
+      const double rdv = rsqrt(piv), d = piv * rdv;
+      lq[q] = (l > j) ? s * rdv : 0.0;
+      if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
+      if (l == j) S.rd[j] = rdv;
+    }
+    wave_sync();
+  }
+  if (bad) {
+    if (l == 0) atomicOr(a.status + prob, 1);
+    return;
+  }
+
+#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 1
+  return;
+#endif
+  // ---- 2. A.m and G = A.L on the matrix cores, results stay in the accumulators (row 16u + 4b + r4, column 4J + c4)
+  double amr[NUU], gacc[NUU][NB];
+#pragma unroll
+  for (int u = 0; u < NUU; u++) {
+    amr[u] = 0.0;
+#pragma unroll
+    for (int J = 0; J < NB; J++) gacc[u][J] = 0.0;
+  }
+#pragma unroll
+  for (int K = 0; K < NB; K++) {
+    const double mk = S.mv[4 * K + r4];                       // B-operand [k = r4][j]: m in every column
+#pragma unroll
+    for (int u = 0; u < NUU; u++) amr[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], mk, amr[u], 0, 0, 0);
+    const double* lk = S.Lm + (4 * K + r4) * LD + c4;          // B-operand [k = r4][j = c4] = L[4K + r4][4J + c4], K >= J
+#pragma unroll
+    for (int J = 0; J <= K; J++) {
+      const double lf = lk[4 * J];
+#pragma unroll
+      for (int u = 0; u < NUU; u++) gacc[u][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], lf, gacc[u][J], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // one K at a time: hoisting every L fragment up front costs 2 NB^2 registers
+  }
+#pragma unroll
+  for (int u = 0; u < NUU; u++) {
+    const int i = 16 * u + 4 * b + r4;
+    if (c4 == 0 && i < D) { S.am[i] = amr[u]; if (a.Am) a.Am[o * D + i] = amr[u]; }
+  }
+
+#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 2
+  return;
+#endif
+  // ---- 3. residuals of the sigma points m +- L[:, j] in accumulator layout, rows 2 .. D-2
+  // park rows 0, 1, D-1 of G for the boundary pass first (only the units that can hold them: compile-time test), so
+  // that the residual loop below is ONE basic block (with branches in between, the compiler sinks all the arithmetic
+  // below the last branch and keeps 8 NB NUU registers of LDS reads alive)
+#pragma unroll
+  for (int u = 0; u < NUU; u++) {
+    if (u == 0 || (16 * u <= Dp - 1 && 16 * u + 15 >= Dp - 4)) {
+      const int i = 16 * u + 4 * b + r4;
+      const int slot = (i == 0) ? 0 : ((i == 1) ? 1 : ((i == D - 1) ? 2 : -1));
+      if (slot >= 0) {
+#pragma unroll
+        for (int J = 0; J < NB; J++) gb[slot * Dp + 4 * J + c4] = gacc[u][J];
+      }
+    }
+  }
+  double vp[NB], vm[NB];
+#pragma unroll
+  for (int J = 0; J < NB; J++) { vp[J] = 0.0; vm[J] = 0.0; }
+#pragma unroll
+  for (int u = 0; u < NUU; u++) {
+    const int i = 16 * u + 4 * b + r4;
+    const bool ok = (i >= 2) && (i <= D - 2);
+    const int ir = ok ? i : 2;                                  // masked lanes read a valid interior row, weight 0
+    const double mm2 = S.mv[ir - 2], mm1 = S.mv[ir - 1], m0 = S.mv[ir], m1 = S.mv[ir + 1];
+    const double sgr = S.sg[ir];
+    const double bvi = S.bv[ir], sgi = ok ? sgr : 0.0, ami = amr[u];
+    const double* lp = S.Lm + (ir - 2) * LD + c4;
+#pragma unroll
+    for (int J = 0; J < NB; J++) {
+      const double e2 = lp[4 * J], e1 = lp[LD + 4 * J], e0 = lp[2 * LD + 4 * J], ep = lp[3 * LD + 4 * J];
+      const double gi = gacc[u][J];
+      const double a1 = m1 + ep, am2 = mm2 + e2, am1 = mm1 + e1, a0 = m0 + e0;
+      const double b1 = m1 - ep, bm2 = mm2 - e2, bm1 = mm1 - e1, b0 = m0 - e0;
+      const double ra = ((a1 - am2) * am1 - a0 + theta) + (ami + gi) - bvi;
+      const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
+      vp[J] = __builtin_fma(sgi, ra * ra, vp[J]);
+      vm[J] = __builtin_fma(sgi, rb * rb, vm[J]);
+      if ((J & 1) == 1) __builtin_amdgcn_sched_barrier(0);    // keep the scheduler from hoisting all 4 NB LDS reads (registers)
+    }
+  }
+  // sum over the rows: ones-MFMA adds the four r4 of a block slot, the four block slots b go through LDS
+  {
+    double rp[NB], rm[NB];
+#pragma unroll
+    for (int J = 0; J < NB; J++) {
+      rp[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, vp[J], 0.0, 0, 0, 0);
+      rm[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, vm[J], 0.0, 0, 0, 0);
+    }
+    if (r4 == 0) {
+#pragma unroll
+      for (int J = 0; J < NB; J++) {
+        pv[b * Dp + 4 * J + c4] = rp[J];
+        pw[b * Dp + 4 * J + c4] = rm[J];
+      }
+    }
+  }
+  wave_sync();
+
+  double vplus = 0.0, vminus = 0.0, v0 = 0.0;
+  {
+    auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
+    auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
+    auto chi = [&](int q, int i) { return S.mv[i] + sgn_of(q) * S.Lm[i * LD + col_of(q)]; };
+    const int jc = act ? l : 0;
+    vplus = (pv[jc] + pv[Dp + jc]) + (pv[2 * Dp + jc] + pv[3 * Dp + jc]);
+    vminus = (pw[jc] + pw[Dp + jc]) + (pw[2 * Dp + jc] + pw[3 * Dp + jc]);
+    // rows 0, 1 and D-1: the flat np.roll of the reference (quirk Q1) takes their neighbours from the sigma points
+    // p-1 and p+1.  Window over the flat index w = p*D + i: X(w-2), X(w-1), X(w), X(w+1).
+    const int pP = 1 + jc, pM = 1 + D + jc;
+    const int pPm = pP - 1, pPp = pP + 1;
+    const int pMm = pM - 1, pMp = wrap(pM + 1, M);
+    {
+      const double P0 = chi(pPm, D - 2), P1 = chi(pPm, D - 1), P2 = chi(pP, 0), P3 = chi(pP, 1), P4 = chi(pP, 2);
+      const double N0 = chi(pMm, D - 2), N1 = chi(pMm, D - 1), N2 = chi(pM, 0), N3 = chi(pM, 1), N4 = chi(pM, 2);
+      const double Q0 = chi(pP, D - 3), Q1 = chi(pP, D - 2), Q2 = chi(pP, D - 1), Q3 = chi(pPp, 0);
+      const double R0 = chi(pM, D - 3), R1 = chi(pM, D - 2), R2 = chi(pM, D - 1), R3 = chi(pMp, 0);
+      const double g0 = gb[jc], g1 = gb[Dp + jc], g2 = gb[2 * Dp + jc];
+      {
+        const double ami = S.am[0], bvi = S.bv[0], sgi = S.sg[0];
+        const double ra = ((P3 - P0) * P1 - P2 + theta) + (ami + g0) - bvi;
+        const double rb = ((N3 - N0) * N1 - N2 + theta) + (ami - g0) - bvi;
+        vplus = __builtin_fma(sgi, ra * ra, vplus);
+        vminus = __builtin_fma(sgi, rb * rb, vminus);
+      }
+      {
+        const double ami = S.am[1], bvi = S.bv[1], sgi = S.sg[1];
+        const double ra = ((P4 - P1) * P2 - P3 + theta) + (ami + g1) - bvi;
+        const double rb = ((N4 - N1) * N2 - N3 + theta) + (ami - g1) - bvi;
+        vplus = __builtin_fma(sgi, ra * ra, vplus);
+        vminus = __builtin_fma(sgi, rb * rb, vminus);
+      }
+      {
+        const double ami = S.am[D - 1], bvi = S.bv[D - 1], sgi = S.sg[D - 1];
+        const double ra = ((Q3 - Q0) * Q1 - Q2 + theta) + (ami + g2) - bvi;
+        const double rb = ((R3 - R0) * R1 - R2 + theta) + (ami - g2) - bvi;
+        vplus = __builtin_fma(sgi, ra * ra, vplus);
+        vminus = __builtin_fma(sgi, rb * rb, vminus);
+      }
+    }
+    // the mean point: lane i holds term i of the sum
+    if (act) {
+      const int i = l;
+      const double xm2 = (i >= 2) ? S.mv[i - 2] : chi(M - 1, D - 2 + i);
+      const double xm1 = (i >= 1) ? S.mv[i - 1] : chi(M - 1, D - 1);
+      const double x1 = (i + 1 < D) ? S.mv[i + 1] : chi(1, 0);
+      const double r0 = ((x1 - xm2) * xm1 - S.mv[i] + theta) + S.am[i] - S.bv[i];
+      v0 = S.sg[i] * (r0 * r0);
+    }
+    v0 = wave_sum(v0);
+  }
+  const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
+  const double e_part = act ? (vplus + vminus) : 0.0;
+  const double e_t = 0.5 * (w0 * v0 + w1 * wave_sum(e_part));
+  wave_sync();                                   // every lane has read the partial sums: xdiag may overwrite them
+  if (act) {
+    S.dl[l] = w1 * (vplus - vminus);
+    S.qq[l] = 0.5 * c * (w1 * (vplus + vminus)) - e_t;
+  }
+  if (l == 0) a.e_t[o] = e_t;
+  // inverses of the 4x4 diagonal blocks of L (lane I < NB)
+  if (l < NB) {
+    const double* tb = S.Lm + (4 * l) * LD + 4 * l;
+    const double x00 = S.rd[4 * l], x11 = S.rd[4 * l + 1], x22 = S.rd[4 * l + 2], x33 = S.rd[4 * l + 3];
+    const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
+    const double x10 = -(t10 * x00) * x11;
+    const double x21 = -(t21 * x11) * x22;
+    const double x32 = -(t32 * x22) * x33;
+    const double x20 = -(t20 * x00 + t21 * x10) * x22;
+    const double x31 = -(t31 * x11 + t32 * x21) * x33;
+    const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
+    double* xo = xdiag + 16 * l;
+    xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
+    xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
+    xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
+    xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
+  }
+  wave_sync();
+
+#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 4
+  return;
+#endif
+  // ---- 4. X = L^-1 IN PLACE by blocked forward substitution on the matrix cores (see k_energy_l96): block-row I of X
+  //         overwrites block-row I of L, which only step I reads; LDS operations of one wave execute in order.
+  const double* l4_a = S.Lm + c4 * LD + r4;
+  const double* xd_a = xdiag + 4 * c4 + r4;
+  const double* xd_d = xdiag + 4 * r4 + c4;
+#pragma unroll
+  for (int I = 0; I < NB; I++) {
+    const double* arow = l4_a + 4 * I * LD;
+    const double xd = xd_a[16 * I];
+    const double xdd = xd_d[16 * I];
+    double xo[NUU];
+    // all products of the block-row first (they read L[I][:]), then the stores (they overwrite it)
+#pragma unroll
+    for (int u = 0; u < NUU; u++) {
+      const int Jb = 4 * u + b;
+      const bool colok = (4 * u + 3 < NB) || (Jb < NB);
+      const double* xcol = S.Lm + r4 * LD + 4 * (colok ? Jb : NB - 1) + c4;
+      xo[u] = 0.0;
+      if (4 * u <= I) {
+        double tacc = 0.0;
+#pragma unroll
+        for (int K = 4 * u; K < I; K++) tacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * K], xcol[4 * K * LD], tacc, 0, 0, 0);
+        const double prod = __builtin_amdgcn_mfma_f64_4x4x4f64(xd, tacc, 0.0, 0, 0, 0);
+        xo[u] = (Jb < I) ? -prod : ((Jb == I) ? xdd : 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NUU; u++) {
+      const int Jb = 4 * u + b;
+      const bool colok = (4 * u + 3 < NB) || (Jb < NB);
+      if (colok) S.Lm[(4 * I + r4) * LD + 4 * Jb + c4] = xo[u];
+    }
+    wave_sync();
+  }
+
+#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 5
+  return;
+#endif
+  // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
+  {
+    double s = 0.0;
+    for (int k = 0; k < Dp; k++) s = __builtin_fma(S.Lm[k * LD + li], S.dl[k], s);
+    if (act) a.dEm[o * D + l] = 0.5 * c * s;
+  }
+  double* ds = a.dEs + o * D * D;
+  {
+    double acc[WaveGemmGeo<NB>::NU];
+    wave_gemm<NB, 1>(S.Lm, S.Lm, LD, acc, S.qq);
+#pragma unroll
+    for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
+      int row, col; bool ok;
+      wave_gemm_elem<NB>(u, row, col, ok);
+      if (ok && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[u];
+    }
+  }
+
+  // ---- <f> and optionally dense <df/dx>
+  if (act) {
+    const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
+    const double cxx = St[ip1 * D + im1] - St[im2 * D + im1];
+    a.Ef[o * D + i] = cxx + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
+  }
+  if (a.Edf) {
+    double* ed = a.Edf + o * D * D;
+    for (int e = l; e < D * D; e += 64) {
+      const int k = e / D, j = e - k * D;
+      const int kp1 = wrap(k + 1, D), km1 = wrap(k - 1, D), km2 = wrap(k - 2, D);
       double v = 0.0;
       if (j == k) v = -1.0;
       if (j == kp1) v = S.mv[km1];
@@ -1133,7 +1523,11 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
       }
 #undef VGPA_L96W4_CASE
     }
-    size_t lds = l96_lds_doubles(a.D) * sizeof(double);
+    const bool one_matrix = (a.hyp == nullptr);      // the hyper-parameter integrands need the second LDS matrix
+    size_t lds = (one_matrix ? l96r_lds_doubles(a.D) : l96_lds_doubles(a.D)) * sizeof(double);
+#ifdef VGPA_L96_ALIAS
+    lds -= (size_t)l96_dp(a.D) * l96_ld(a.D) * sizeof(double);
+#endif
 #ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
     lds += VGPA_L96_LDSPAD;
 #endif
@@ -1142,8 +1536,10 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
 #define VGPA_L96_CASE(NBV)                                                                                          \
   case NBV:                                                                                                         \
     if (lds > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_energy_l96<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(k_energy_l96<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);                             \
+      (void)hipFuncSetAttribute(one_matrix ? (const void*)k_energy_l96_r<NBV> : (const void*)k_energy_l96<NBV>,       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    if (one_matrix) hipLaunchKernelGGL(k_energy_l96_r<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);            \
+    else hipLaunchKernelGGL(k_energy_l96<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);                        \
     break;
     switch ((a.D + 3) / 4) {
       VGPA_L96_CASE(1) VGPA_L96_CASE(2) VGPA_L96_CASE(3) VGPA_L96_CASE(4) VGPA_L96_CASE(5) VGPA_L96_CASE(6)
