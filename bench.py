@@ -202,7 +202,7 @@ def main():
         "config": {"workload": f"Lorenz96 D={d}, {args.method.upper()}, Np={n_pts} (BASELINE configs[2])",
                    "batch_per_gpu": B, "sharding": "independent problems per GPU, no collective",
                    "kernels": "generic" if args.generic else "mfma"},
-        "roofline": dict(roof[dom], note="kernel with the longest launch of the sweep; energy+obs phase = k_energy_l96_w4 + k_obs "
+        "roofline": dict(roof[dom], note="kernel with the longest launch of the sweep; energy+obs phase = k_energy_l96_r + k_obs "
                                          "(0.1 ms); all four kernels under roofline_kernels"),
         "roofline_kernels": roof,
         "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

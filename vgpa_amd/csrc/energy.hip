@@ -767,7 +767,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int u = 0; u < NUU; u++) gacc[u][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], lf, gacc[u][J], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);     // one K at a time: hoisting every L fragment up front costs 2 NB^2 registers
   }
 #pragma unroll
   for (int u = 0; u < NUU; u++) {
@@ -815,7 +814,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
       vp[J] = __builtin_fma(sgi, ra * ra, vp[J]);
       vm[J] = __builtin_fma(sgi, rb * rb, vm[J]);
-      if ((J & 1) == 1) __builtin_amdgcn_sched_barrier(0);    // keep the scheduler from hoisting all 4 NB LDS reads (registers)
+      if (J == NB / 2 - 1 || J == NB - 1) __builtin_amdgcn_sched_barrier(0);    // keep the scheduler from hoisting all 4 NB LDS reads (registers)
     }
   }
   // sum over the rows: ones-MFMA adds the four r4 of a block slot, the four block slots b go through LDS
