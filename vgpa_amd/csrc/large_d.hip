@@ -19,6 +19,8 @@
 // (A lane map i = l & 15, k = l >> 4; B k = l >> 4, j = l & 15; C col = l & 15, row = (l >> 4) + 4 r -- probed,
 // profiles/r01_fp64_mfma_layout_probe.txt), LDS tiles stored k-major with leading dimensions chosen for
 // conflict-free b64 fragment reads, register-prefetched global loads, two LDS buffers, one barrier per k-step.
+#include <cstdlib>
+
 #include "vgpa_internal.h"
 
 namespace vgpa {
@@ -28,6 +30,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BN = 64, BK = 16, NT = 256;   // block tile BM x 64 (BM = 128, or 64 when 128 would not fill the chip)
 constexpr int LDBS = BN + 16;   // 80 = 16 (mod 32): conflict-free fragment reads
+// (diagnostic switch: VGPA_GEMM_SCALAR_LOADS=1 keeps the 8-byte-load kernel for full tiles)
+static const bool gemm_scalar_loads = [] { const char* e = getenv("VGPA_GEMM_SCALAR_LOADS"); return e && e[0] == '1'; }();
 
 struct GemmArgs {
   int M, N, K;              // C[M x N] = op(A)[M x K] . B[K x N]
@@ -169,6 +173,142 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Full tiles with 16-byte global loads (M, N, K multiples of the tile sizes, even leading dimensions, 16-byte aligned
+// operands): half the global-load and LDS-store instructions of k_gemm.  The A tile keeps the orientation it has in
+// HBM, so that its 16-byte pairs stay contiguous in LDS:
+//   NN (A row-major [i][k]):  As[i][LDK], LDK = 18 -- fragment read (i = l & 15, k = l >> 4) is conflict-free because
+//                             18 i (mod 32) runs over the even residues and the two k of a 32-lane group fill the odd ones
+//   TN (A stored  [k][i]):    As[k][BM + 16] as in k_gemm (k-major), b128 stores of 16 consecutive pairs
+//   B  (row-major [k][j]):    Bs[k][LDBS], b128 stores
+template <bool TRANSA, bool MID, int BM>
+__global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int LDK = 18;                       // NN: doubles per tile row (16 + 2)
+  constexpr int LDT = BM + 16;                  // TN: = 16 (mod 32)
+  constexpr int ASZ = TRANSA ? BK * LDT : BM * LDK;
+  constexpr int MT = BM / 32;
+  constexpr int AV = BM * BK / 2 / NT;          // 16-byte pairs of the A tile per thread (BM = 32: 1)
+  __shared__ __attribute__((aligned(16))) double As[2][ASZ];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  // per-thread global offsets of the first k-tile and LDS offsets of its pairs
+  size_t ga[AV], gb[2];
+  int sa[AV], sb[2];
+#pragma unroll
+  for (int q = 0; q < AV; q++) {
+    if (TRANSA) {
+      const int i2 = tid & (BM / 2 - 1), k = tid / (BM / 2) + (NT / (BM / 2)) * q;
+      ga[q] = (size_t)k * g.lda + i0 + 2 * i2;
+      sa[q] = k * LDT + 2 * i2;
+    } else {
+      const int kp = tid & 7, i = (tid >> 3) + 32 * q;
+      ga[q] = (size_t)(i0 + i) * g.lda + 2 * kp;
+      sa[q] = i * LDK + 2 * kp;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int j2 = tid & 31, k = (tid >> 5) + 8 * q;
+    gb[q] = (size_t)k * g.ldb + j0 + 2 * j2;
+    sb[q] = k * LDBS + 2 * j2;
+  }
+  const size_t astep = TRANSA ? (size_t)BK * g.lda : (size_t)BK, bstep = (size_t)BK * g.ldb;
+
+  d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
+  auto load_tiles = [&](int kt, d2 (&ra)[AV], d2 (&rb)[2]) {
+#pragma unroll
+    for (int q = 0; q < AV; q++) {
+      const size_t idx = ga[q] + (size_t)kt * astep;
+      const d2 v0 = *reinterpret_cast<const d2*>(g.A0 + idx);
+      if (MID) {
+        const d2 v1 = *reinterpret_cast<const d2*>(g.A1 + idx);
+        ra[q] = d2{0.5 * (v0[0] + v1[0]), 0.5 * (v0[1] + v1[1])};
+      } else {
+        ra[q] = v0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) rb[q] = *reinterpret_cast<const d2*>(g.B + gb[q] + (size_t)kt * bstep);
+  };
+  auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
+#pragma unroll
+    for (int q = 0; q < AV; q++) *reinterpret_cast<d2*>(&As[buf][sa[q]]) = ra[q];
+#pragma unroll
+    for (int q = 0; q < 2; q++) *reinterpret_cast<d2*>(&Bs[buf][sb[q]]) = rb[q];
+  };
+
+  d4 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int nk = g.K / BK;
+  auto compute = [&](int cur) {
+    const double* as = TRANSA ? As[cur] + fk * LDT + (BM / 2) * wm + fi : As[cur] + ((BM / 2) * wm + fi) * LDK + fk;
+    const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double af[MT], bf[2];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) af[mt] = TRANSA ? as[kk * 4 * LDT + 16 * mt] : as[16 * mt * LDK + kk * 4];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) bf[nt] = bs[kk * 4 * LDBS + 16 * nt];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  if constexpr (BM < 128) {
+    load_tiles(0, ra0, rb0);
+    store_tiles(0, ra0, rb0);
+    if (nk > 1) load_tiles(1, ra1, rb1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+      compute(0);
+      if (kt + 1 < nk) store_tiles(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+      compute(1);
+      if (kt + 2 < nk) store_tiles(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    load_tiles(0, ra0, rb0);
+    store_tiles(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tiles(kt + 1, ra0, rb0);
+      compute(cur);
+      if (kt + 1 < nk) store_tiles(cur ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+      const size_t chunk = (size_t)(gj / g.cw) * g.M * g.cw + (gj % g.cw);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
+        g.C[chunk + (size_t)gi * g.cw] = acc[mt][nt][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Fused element-wise stage kernel on the row block [row0, row0 + Mp) of a D x D symmetric recursion.
 //   R[r][j] = fwd ? (-(W[r][j]) - Wcol[j][r]) + E[r][j]          (E = Sigma)
 //                 : (-E[r][j] + Wcol[j][r]) + W[r][j]            (E = G_stage = dEsde_dS or its mid-point)
@@ -286,8 +426,25 @@ static void launch_gemm_bm_f(bool transa, const GemmArgs& g, hipStream_t st) {
 }
 
 template <int BM>
+static void launch_gemm_bm_v(bool transa, const GemmArgs& g, hipStream_t st) {
+  dim3 grid(g.N / BN, g.M / BM);
+  const bool mid = g.A1 != nullptr;
+  if (transa) {
+    if (mid) hipLaunchKernelGGL((k_gemm_v<true, true, BM>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_v<true, false, BM>), grid, dim3(NT), 0, st, g);
+  } else {
+    if (mid) hipLaunchKernelGGL((k_gemm_v<false, true, BM>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_v<false, false, BM>), grid, dim3(NT), 0, st, g);
+  }
+}
+
+template <int BM>
 static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
-  if (g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0) launch_gemm_bm_f<BM, true>(transa, g, st);
+  const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
+  auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const bool vec = full && g.lda % 2 == 0 && g.ldb % 2 == 0 && al16(g.A0) && al16(g.A1) && al16(g.B) && !gemm_scalar_loads;
+  if (vec) launch_gemm_bm_v<BM>(transa, g, st);
+  else if (full) launch_gemm_bm_f<BM, true>(transa, g, st);
   else launch_gemm_bm_f<BM, false>(transa, g, st);
 }
 
