@@ -9,6 +9,8 @@
 //                              panel     : L[R,J] = C[R,J] X_JJ^T                 (GEMM, in place)
 //                              trailing  : C[R,R] -= L[R,J] L[R,J]^T              (GEMM, lower tiles only)
 //   inverse  (by block rows):  T1 = L[I,0:I] X[0:I,0:I];  X[I,0:I] = -X_II T1     (2 GEMMs)
+#include <cstdlib>
+
 #include "vgpa_internal.h"
 
 namespace vgpa {
@@ -136,9 +138,130 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
     }
 }
 
+// Full 64 x 64 tiles, op(B) = B, 16-byte global loads, prefetch distance two (the treatment of ld::k_gemm_v, large_d.hip:
+// the A tile keeps its HBM orientation in LDS -- [i][18] for row-major A, k-major for A^T).  Same k order per output
+// element as k_gemm_b, i.e. the same bits.
+template <bool TA>
+__global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int BM = 64, LDK = 18, LDT = BM + 16, LDBS = BN + 16;
+  constexpr int ASZ = TA ? BK * LDT : BM * LDK;
+  constexpr int MT = BM / 32, AV = BM * BK / 2 / NT;
+  __shared__ __attribute__((aligned(16))) double As[2][ASZ];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  if (g.lower_only && j0 >= i0 + BM) return;
+  const double* A = g.A + (long long)blockIdx.z * g.sA;
+  const double* B = g.B + (long long)blockIdx.z * g.sB;
+  double* C = g.C + (long long)blockIdx.z * g.sC;
+  const int fi = lane & 15, fk = lane >> 4;
+  long long ga[AV], gb[2];
+  int sa[AV], sb[2];
+#pragma unroll
+  for (int q = 0; q < AV; q++) {
+    if (TA) {
+      const int i2 = tid & (BM / 2 - 1), k = tid / (BM / 2) + (NT / (BM / 2)) * q;
+      ga[q] = (long long)k * g.lda + i0 + 2 * i2;
+      sa[q] = k * LDT + 2 * i2;
+    } else {
+      const int kp = tid & 7, i = (tid >> 3) + 32 * q;
+      ga[q] = (long long)(i0 + i) * g.lda + 2 * kp;
+      sa[q] = i * LDK + 2 * kp;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int j2 = tid & 31, k = (tid >> 5) + 8 * q;
+    gb[q] = (long long)k * g.ldb + j0 + 2 * j2;
+    sb[q] = k * LDBS + 2 * j2;
+  }
+  const long long astep = TA ? (long long)BK * g.lda : (long long)BK, bstep = (long long)BK * g.ldb;
+  d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
+  auto load_tiles = [&](int kt, d2 (&ra)[AV], d2 (&rb)[2]) {
+#pragma unroll
+    for (int q = 0; q < AV; q++) ra[q] = *reinterpret_cast<const d2*>(A + ga[q] + (long long)kt * astep);
+#pragma unroll
+    for (int q = 0; q < 2; q++) rb[q] = *reinterpret_cast<const d2*>(B + gb[q] + (long long)kt * bstep);
+  };
+  auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
+#pragma unroll
+    for (int q = 0; q < AV; q++) *reinterpret_cast<d2*>(&As[buf][sa[q]]) = ra[q];
+#pragma unroll
+    for (int q = 0; q < 2; q++) *reinterpret_cast<d2*>(&Bs[buf][sb[q]]) = rb[q];
+  };
+  d4 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+  auto compute = [&](int cur) {
+    const double* as = TA ? As[cur] + fk * LDT + (BM / 2) * wm + fi : As[cur] + ((BM / 2) * wm + fi) * LDK + fk;
+    const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double af[MT], bf[2];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) af[mt] = TA ? as[kk * 4 * LDT + 16 * mt] : as[16 * mt * LDK + kk * 4];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) bf[nt] = bs[kk * 4 * LDBS + 16 * nt];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  const int nk = g.K / BK;
+  int kt0 = 0;
+  if (g.k_tri == 1) kt0 = j0 / BK;
+  else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
+  if (kt0 > nk) kt0 = nk;
+  if (kt0 < nk) {
+    load_tiles(kt0, ra0, rb0);
+    store_tiles(0, ra0, rb0);
+    if (kt0 + 1 < nk) load_tiles(kt0 + 1, ra1, rb1);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+    compute(0);
+    if (kt + 1 < nk) store_tiles(1, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+    compute(1);
+    if (kt + 2 < nk) store_tiles(0, ra0, rb0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
+        double* cp = C + (long long)gi * g.ldc + gj;
+        const double v = g.alpha * acc[mt][nt][r];
+        *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
+      }
+    }
+}
+
 hipError_t gemm_b(bool ta, bool tb, const GemmB& g, int nb, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || nb <= 0) return hipSuccess;
   dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  static const bool scalar_loads = [] { const char* e = getenv("VGPA_GEMM_SCALAR_LOADS"); return e && e[0] == '1'; }();
+  const bool vec = !tb && !scalar_loads && g.M % 64 == 0 && g.N % BN == 0 && g.K % BK == 0 && g.lda % 2 == 0 &&
+                   g.ldb % 2 == 0 && g.sA % 2 == 0 && g.sB % 2 == 0 && al16(g.A) && al16(g.B);
+  if (vec) {
+    if (ta) hipLaunchKernelGGL((k_gemm_bv<true>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_bv<false>), grid, dim3(NT), 0, st, g);
+    return hipGetLastError();
+  }
   if (ta && tb) hipLaunchKernelGGL((k_gemm_b<true, true, 64>), grid, dim3(NT), 0, st, g);
   else if (ta) hipLaunchKernelGGL((k_gemm_b<true, false, 64>), grid, dim3(NT), 0, st, g);
   else if (tb) hipLaunchKernelGGL((k_gemm_b<false, true, 64>), grid, dim3(NT), 0, st, g);
