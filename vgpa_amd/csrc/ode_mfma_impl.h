@@ -153,8 +153,8 @@ struct Geo {
   static constexpr int ROWS = 2 * KKE;                    // (KKE / 2) k-pairs x 4 rows
   static constexpr int LDX = 32 * ((2 * P + 31) / 32);
   static constexpr int LDA = 16 * ((2 * P - 8 + 15) / 16) + 8;   // = 8 or 24 (mod 32), >= 2P
-  static constexpr int LDW = P + 1;                       // exchange buffer for W^T (odd, plain row-major)
-  static constexpr int EPT = (P * P + NT - 1) / NT;       // A entries per thread for the HBM -> LDS staging
+  static constexpr int LDW = 32 * ((P + 31) / 32);        // exchange buffer for W^T (swizzled inside 32-column groups, w_off)
+  static constexpr int EPT = (P * P / 2 + NT - 1) / NT;   // 16-byte operand units (two A entries) per thread for the HBM -> LDS staging
   static constexpr int TRASH = NT;                        // one scratch double per thread for lanes without an element
   static constexpr size_t LDS_DOUBLES = (size_t)ROWS * LDX + (size_t)P * LDW + 3 * (size_t)ROWS * LDA +
                                         (size_t)(2 + NW) * P + TRASH + 8;
@@ -162,6 +162,12 @@ struct Geo {
 
 // offset of element (k, c) in a k-pair interleaved operand matrix with leading dimension LD
 __host__ __device__ constexpr int pair_off(int k, int c, int LD) { return ((k >> 3) * 4 + ((k >> 1) & 3)) * LD + 2 * c + (k & 1); }
+
+// offset of W[r][c] in the exchange buffer.  A 32-lane store group writes rows R, R+1 (R even) x 16 consecutive columns
+// and a load group reads 16 consecutive rows x columns R, R+1 (the transposed element of every lane): with bank =
+// c + 16 (r & 1) + 2 (r >> 1) (mod 32) both patterns touch 32 different banks (a plain odd leading dimension leaves
+// 7 two-way conflicts in every store).
+__host__ __device__ constexpr int w_off(int r, int c, int LD) { return r * LD + (c & ~31) + ((c + 16 * (r & 1) + 2 * (r >> 1)) & 31); }
 
 template <int NB, int NW>
 struct Lds {
@@ -185,8 +191,8 @@ struct Tab {
   static constexpr int MAXU = Geo<NB, NW>::MAXU;
   int colA[MAXU];   // 2*(4*I_b + (l&3))
   int colB0, colB1; // B-fragment columns of the group feeding slots [0,S1) / slots [S1,MAXU)
-  int offWw[MAXU];  // row*LDW + col
-  int offWr[MAXU];  // col*LDW + row
+  int offWw[MAXU];  // w_off(row, col)
+  int offWr[MAXU];  // w_off(col, row)
   int offX[MAXU];   // pair_off(row, col, LDX)
   int gofs[MAXU];   // row*D + col   (global element offset inside a D x D matrix)
   unsigned valid;   // per-lane bit s: this lane owns a real matrix element in slot s
@@ -229,8 +235,8 @@ __device__ __forceinline__ void build_tab(int D, Tab<NB, NW>& T) {
     constexpr int W_BASE = g::ROWS * g::LDX;
     constexpr int TRASH_BASE = g::ROWS * g::LDX + g::P * g::LDW + 3 * g::ROWS * g::LDA + (2 + NW) * g::P;
     T.colA[s] = 2 * (4 * Ib + c4);
-    T.offWw[s] = own ? (W_BASE + row * g::LDW + col) : (TRASH_BASE + ltid());
-    T.offWr[s] = own ? (W_BASE + col * g::LDW + row) : (TRASH_BASE + ltid());
+    T.offWw[s] = own ? (W_BASE + w_off(row, col, g::LDW)) : (TRASH_BASE + ltid());
+    T.offWr[s] = own ? (W_BASE + w_off(col, row, g::LDW)) : (TRASH_BASE + ltid());
     T.offX[s] = own ? pair_off(row, col, g::LDX) : (TRASH_BASE + ltid());
     T.gofs[s] = row * D + col;
     if (own) T.valid |= (1u << s);
@@ -357,35 +363,60 @@ __device__ __forceinline__ void publish(const Lds<NB, NW>& L, int D, const Tab<N
   VGPA_STAMP(8);                       // barrier B
 }
 
-// A(t) from HBM into registers, coalesced (thread e <-> A[e / D][e % D])
-template <int NB, int NW>
-__device__ __forceinline__ void load_a(const double* __restrict__ A, int DD, double (&a)[Geo<NB, NW>::EPT]) {
-#pragma unroll
-  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
-    const int e = ltid() + q * Geo<NB, NW>::NT;
-    a[q] = (e < DD) ? A[e] : 0.0;
-  }
-}
+// ---- A(t): HBM -> registers -> LDS operand buffer, in 16-byte operand units ----------------------------------------
+// The k-pair interleaved operand layout keeps rows 2p and 2p+1 of the operand in one 16-byte unit per column.  A staging
+// item is such a unit: (p, o) = rows 2p, 2p+1 of the operand at column o -- forward (operand = A^T) the elements
+// A[o][2p], A[o][2p+1], backward (operand = A) A[2p][o], A[2p+1][o].  Items are dealt with o fastest over the threads,
+// so a 16-lane group writes 16 consecutive units with ONE ds_write_b128: conflict-free.  (The first version wrote single
+// elements with the matrix column fastest: forward that is a transposing store whose 32-lane groups hit 8 banks, a
+// four-way conflict on every one of the 64 wave-stores of a step -- ~2 k LDS cycles per step.)  The forward HBM reads
+// become strided 8-byte loads (one row per lane); they are prefetched a whole step ahead and every 128-byte line is
+// still fetched once (the other lanes of the same instruction group use the rest of it).
+typedef double a2_t __attribute__((ext_vector_type(2)));
 
-// registers -> LDS operand buffer: forward stores A^T (Aop[c][r] = A[r][c]), backward stores A.
-template <int NB, int NW, bool FWD, bool MID>
-__device__ __forceinline__ void store_a(double* __restrict__ buf, int D, const int (&aofs)[Geo<NB, NW>::EPT],
-                                        const double (&a0)[Geo<NB, NW>::EPT], const double (&a1)[Geo<NB, NW>::EPT]) {
-#pragma unroll
-  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
-    if (aofs[q] >= 0) buf[aofs[q]] = MID ? 0.5 * (a0[q] + a1[q]) : a0[q];
-  }
-  (void)D;
-}
+template <int NB, int NW>
+struct AStage {
+  int g0[Geo<NB, NW>::EPT];   // global element offset of the unit's first entry (-1: none)
+  int g1[Geo<NB, NW>::EPT];   // ... of its second entry (-1: padding row)
+  int lo[Geo<NB, NW>::EPT];   // LDS offset of the unit inside an operand buffer (-1: no item)
+};
 
 template <int NB, int NW, bool FWD>
-__device__ __forceinline__ void build_aofs(int D, int (&aofs)[Geo<NB, NW>::EPT]) {
+__device__ __forceinline__ void build_astage(int D, AStage<NB, NW>& s) {
   using g = Geo<NB, NW>;
+  const int npair = (D + 1) / 2;
 #pragma unroll
   for (int q = 0; q < g::EPT; q++) {
-    const int e = ltid() + q * Geo<NB, NW>::NT;
-    const int r = e / D, c = e - r * D;
-    aofs[q] = (e < D * D) ? (FWD ? pair_off(c, r, g::LDA) : pair_off(r, c, g::LDA)) : -1;
+    const int e = ltid() + q * g::NT;
+    const int p = e / D, o = e - p * D;
+    const bool ok = p < npair;
+    const bool two = ok && (2 * p + 1 < D);
+    s.g0[q] = ok ? (FWD ? o * D + 2 * p : 2 * p * D + o) : -1;
+    s.g1[q] = two ? (FWD ? o * D + 2 * p + 1 : (2 * p + 1) * D + o) : -1;
+    s.lo[q] = ok ? pair_off(2 * p, o, g::LDA) : -1;
+  }
+}
+
+template <int NB, int NW>
+__device__ __forceinline__ void load_a(const double* __restrict__ A, const AStage<NB, NW>& s, a2_t (&a)[Geo<NB, NW>::EPT]) {
+#pragma unroll
+  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
+    a[q][0] = (s.g0[q] >= 0) ? A[s.g0[q]] : 0.0;
+    a[q][1] = (s.g1[q] >= 0) ? A[s.g1[q]] : 0.0;
+  }
+}
+
+// registers -> LDS operand buffer (MID: the mid-point 0.5 * (a0 + a1))
+template <int NB, int NW, bool MID>
+__device__ __forceinline__ void store_a(double* __restrict__ buf, const AStage<NB, NW>& s,
+                                        const a2_t (&a0)[Geo<NB, NW>::EPT], const a2_t (&a1)[Geo<NB, NW>::EPT]) {
+#pragma unroll
+  for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
+    if (s.lo[q] >= 0) {
+      a2_t v = a0[q];
+      if (MID) { v[0] = 0.5 * (a0[q][0] + a1[q][0]); v[1] = 0.5 * (a0[q][1] + a1[q][1]); }
+      *reinterpret_cast<a2_t*>(buf + s.lo[q]) = v;
+    }
   }
 }
 
@@ -415,13 +446,13 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
 #endif
   Tab<NB, NW> T;
   build_tab<NB, NW>(D, T);
-  int aofs[EPT];
-  build_aofs<NB, NW, true>(D, aofs);
+  AStage<NB, NW> AS;
+  build_astage<NB, NW, true>(D, AS);
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
   double sk[MAXU], sig[MAXU], w[MAXU], wt[MAXU], r[MAXU], acc1[MAXU], acc2[MAXU], xn[MAXU];
-  double aC[EPT], aN[EPT];
+  a2_t aC[EPT], aN[EPT];
   double mk = 0.0, vs = 0.0;
 #pragma unroll
   for (int s = 0; s < MAXU; s++) {
@@ -433,9 +464,9 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
     L.X[T.offX[s]] = sk[s];
   }
   if (vlane) { mk = a.m0[lane]; mt[lane] = mk; L.xv[lane] = mk; }
-  load_a<NB, NW>(A, DD, aC);
-  store_a<NB, NW, true, false>(L.A0, D, aofs, aC, aC);
-  if (Np > 1) load_a<NB, NW>(A + DD, DD, aN);
+  load_a<NB, NW>(A, AS, aC);
+  store_a<NB, NW, false>(L.A0, AS, aC, aC);
+  if (Np > 1) load_a<NB, NW>(A + DD, AS, aN);
   // offset vectors: b0 = b_k, b1 = b_{k+1}; b_{k+2} is fetched one step ahead (HBM latency off the critical path)
   double b0 = vlane ? bb[lane] : 0.0;
   double b1 = (vlane && Np > 1) ? bb[D + lane] : 0.0;
@@ -455,11 +486,11 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
 #endif
     // operands of this step: A1 <- A_{k+1}, AM <- mid-point; prefetch A_{k+2} for the next step
 #if !defined(VGPA_ABL_NOSTAGE)
-    store_a<NB, NW, true, false>(L.A1, D, aofs, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true, true>(L.AM, D, aofs, aC, aN);
+    store_a<NB, NW, false>(L.A1, AS, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, AS, aC, aN);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
-    if (k + 2 < Np) load_a<NB, NW>(A + (size_t)(k + 2) * DD, DD, aN);
+    if (k + 2 < Np) load_a<NB, NW>(A + (size_t)(k + 2) * DD, AS, aN);
 #endif
     const double b2 = (vlane && k + 2 < Np) ? bb[(size_t)(k + 2) * D + lane] : 0.0;
     double mnew = 0.0;
@@ -560,13 +591,13 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   VGPA_STAMP_DECL;
   Tab<NB, NW> T;
   build_tab<NB, NW>(D, T);
-  int aofs[EPT];
-  build_aofs<NB, NW, false>(D, aofs);
+  AStage<NB, NW> AS;
+  build_astage<NB, NW, false>(D, AS);
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
   double pk[MAXU], gC[MAXU], gN[MAXU], jsc[MAXU], w[MAXU], wt[MAXU], r[MAXU], acc1[MAXU], acc2[MAXU], xn[MAXU];
-  double aC[EPT], aN[EPT];
+  a2_t aC[EPT], aN[EPT];
   double lk = 0.0, vs = 0.0;
   // here "A0" holds A_t (start point of the backward step), "A1" holds A_{t-1}
 #pragma unroll
@@ -579,9 +610,9 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
     if (ok) psi[(size_t)(Np - 1) * DD + T.gofs[s]] = 0.0;
   }
   if (vlane) lam[(size_t)(Np - 1) * D + lane] = 0.0;
-  load_a<NB, NW>(A + (size_t)(Np - 1) * DD, DD, aC);
-  store_a<NB, NW, false, false>(L.A0, D, aofs, aC, aC);
-  if (Np > 1) load_a<NB, NW>(A + (size_t)(Np - 2) * DD, DD, aN);
+  load_a<NB, NW>(A + (size_t)(Np - 1) * DD, AS, aC);
+  store_a<NB, NW, false>(L.A0, AS, aC, aC);
+  if (Np > 1) load_a<NB, NW>(A + (size_t)(Np - 2) * DD, AS, aN);
   // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
   double g0 = vlane ? gm[(size_t)(Np - 1) * D + lane] : 0.0;
   double g1 = (vlane && Np > 1) ? gm[(size_t)(Np - 2) * D + lane] : 0.0;
@@ -602,11 +633,11 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
         if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
       if (vlane) lam[(size_t)t * D + lane] = lk;
     }
-    store_a<NB, NW, false, false>(L.A1, D, aofs, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, false, true>(L.AM, D, aofs, aN, aC);
+    store_a<NB, NW, false>(L.A1, AS, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, AS, aN, aC);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
-    if (t >= 2) load_a<NB, NW>(A + (size_t)(t - 2) * DD, DD, aN);
+    if (t >= 2) load_a<NB, NW>(A + (size_t)(t - 2) * DD, AS, aN);
     const double g2 = (vlane && t >= 2) ? gm[(size_t)(t - 2) * D + lane] : 0.0;   // for the next step
     const int n_obs_next = (!a.js_dense && a.obs_idx && t >= 2) ? a.obs_idx[t - 2] : -1;
     double jm_next = 0.0;
