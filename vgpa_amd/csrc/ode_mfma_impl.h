@@ -155,7 +155,7 @@ struct Geo {
   static constexpr int LDA = 16 * ((2 * P - 8 + 15) / 16) + 8;   // = 8 or 24 (mod 32), >= 2P
   static constexpr int LDW = 32 * ((P + 31) / 32);        // exchange buffer for W^T (swizzled inside 32-column groups, w_off)
   static constexpr int EPT = (P * P / 2 + NT - 1) / NT;   // 16-byte operand units (two A entries) per thread for the HBM -> LDS staging
-  static constexpr int TRASH = NT;                        // one scratch double per thread for lanes without an element
+  static constexpr int TRASH = 2 * NT;                    // one 16-byte scratch slot per thread for lanes without an element
   static constexpr size_t LDS_DOUBLES = (size_t)ROWS * LDX + (size_t)P * LDW + 3 * (size_t)ROWS * LDA +
                                         (size_t)(2 + NW) * P + TRASH + 8;
 };
@@ -391,32 +391,33 @@ __device__ __forceinline__ void build_astage(int D, AStage<NB, NW>& s) {
     const int p = e / D, o = e - p * D;
     const bool ok = p < npair;
     const bool two = ok && (2 * p + 1 < D);
-    s.g0[q] = ok ? (FWD ? o * D + 2 * p : 2 * p * D + o) : -1;
-    s.g1[q] = two ? (FWD ? o * D + 2 * p + 1 : (2 * p + 1) * D + o) : -1;
+    s.g0[q] = ok ? (FWD ? o * D + 2 * p : 2 * p * D + o) : 0;
+    s.g1[q] = two ? (FWD ? o * D + 2 * p + 1 : (2 * p + 1) * D + o) : 0;
     s.lo[q] = ok ? pair_off(2 * p, o, g::LDA) : -1;
   }
 }
 
+// Branch-free: lanes without an item load element 0 (always valid) and store into the workgroup's trash area -- a
+// conditional load / store costs an EXEC-masked branch each, and there are 6 EPT of them per step.
 template <int NB, int NW>
 __device__ __forceinline__ void load_a(const double* __restrict__ A, const AStage<NB, NW>& s, a2_t (&a)[Geo<NB, NW>::EPT]) {
 #pragma unroll
   for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
-    a[q][0] = (s.g0[q] >= 0) ? A[s.g0[q]] : 0.0;
-    a[q][1] = (s.g1[q] >= 0) ? A[s.g1[q]] : 0.0;
+    a[q][0] = A[s.g0[q]];      // (offsets of lanes without an item are clamped to 0 in build_astage; their value is
+    a[q][1] = A[s.g1[q]];      //  never stored, or -- second entry of the last pair when D is odd -- hits a row that only meets zeros)
   }
 }
 
-// registers -> LDS operand buffer (MID: the mid-point 0.5 * (a0 + a1))
+// registers -> LDS operand buffer (MID: the mid-point 0.5 * (a0 + a1)); `trash16` = this thread's 16-byte trash slot
 template <int NB, int NW, bool MID>
-__device__ __forceinline__ void store_a(double* __restrict__ buf, const AStage<NB, NW>& s,
+__device__ __forceinline__ void store_a(double* __restrict__ buf, double* __restrict__ trash16, const AStage<NB, NW>& s,
                                         const a2_t (&a0)[Geo<NB, NW>::EPT], const a2_t (&a1)[Geo<NB, NW>::EPT]) {
 #pragma unroll
   for (int q = 0; q < Geo<NB, NW>::EPT; q++) {
-    if (s.lo[q] >= 0) {
-      a2_t v = a0[q];
-      if (MID) { v[0] = 0.5 * (a0[q][0] + a1[q][0]); v[1] = 0.5 * (a0[q][1] + a1[q][1]); }
-      *reinterpret_cast<a2_t*>(buf + s.lo[q]) = v;
-    }
+    a2_t v = a0[q];
+    if (MID) { v[0] = 0.5 * (a0[q][0] + a1[q][0]); v[1] = 0.5 * (a0[q][1] + a1[q][1]); }
+    double* dst = (s.lo[q] >= 0) ? buf + s.lo[q] : trash16;
+    *reinterpret_cast<a2_t*>(dst) = v;
   }
 }
 
@@ -448,6 +449,7 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
   build_tab<NB, NW>(D, T);
   AStage<NB, NW> AS;
   build_astage<NB, NW, true>(D, AS);
+  double* trash16 = L.trash + 2 * tid;
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
@@ -465,7 +467,7 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
   }
   if (vlane) { mk = a.m0[lane]; mt[lane] = mk; L.xv[lane] = mk; }
   load_a<NB, NW>(A, AS, aC);
-  store_a<NB, NW, false>(L.A0, AS, aC, aC);
+  store_a<NB, NW, false>(L.A0, trash16, AS, aC, aC);
   if (Np > 1) load_a<NB, NW>(A + DD, AS, aN);
   // offset vectors: b0 = b_k, b1 = b_{k+1}; b_{k+2} is fetched one step ahead (HBM latency off the critical path)
   double b0 = vlane ? bb[lane] : 0.0;
@@ -486,8 +488,8 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
 #endif
     // operands of this step: A1 <- A_{k+1}, AM <- mid-point; prefetch A_{k+2} for the next step
 #if !defined(VGPA_ABL_NOSTAGE)
-    store_a<NB, NW, false>(L.A1, AS, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, AS, aC, aN);
+    store_a<NB, NW, false>(L.A1, trash16, AS, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, trash16, AS, aC, aN);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (k + 2 < Np) load_a<NB, NW>(A + (size_t)(k + 2) * DD, AS, aN);
@@ -593,6 +595,7 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   build_tab<NB, NW>(D, T);
   AStage<NB, NW> AS;
   build_astage<NB, NW, false>(D, AS);
+  double* trash16 = L.trash + 2 * tid;
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) lds_base[i] = 0.0;
   __syncthreads();
 
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   }
   if (vlane) lam[(size_t)(Np - 1) * D + lane] = 0.0;
   load_a<NB, NW>(A + (size_t)(Np - 1) * DD, AS, aC);
-  store_a<NB, NW, false>(L.A0, AS, aC, aC);
+  store_a<NB, NW, false>(L.A0, trash16, AS, aC, aC);
   if (Np > 1) load_a<NB, NW>(A + (size_t)(Np - 2) * DD, AS, aN);
   // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
   double g0 = vlane ? gm[(size_t)(Np - 1) * D + lane] : 0.0;
@@ -633,8 +636,8 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
         if ((T.valid >> s) & 1u) po[T.gofs[s]] = pk[s];
       if (vlane) lam[(size_t)t * D + lane] = lk;
     }
-    store_a<NB, NW, false>(L.A1, AS, aN, aN);
-    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, AS, aN, aC);
+    store_a<NB, NW, false>(L.A1, trash16, AS, aN, aN);
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) store_a<NB, NW, true>(L.AM, trash16, AS, aN, aC);
 #pragma unroll
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (t >= 2) load_a<NB, NW>(A + (size_t)(t - 2) * DD, AS, aN);
