@@ -363,6 +363,12 @@ __device__ __forceinline__ void publish(const Lds<NB, NW>& L, int D, const Tab<N
   VGPA_STAMP(8);                       // barrier B
 }
 
+// Values loaded from HBM before the time loop and only read inside it (Sigma, the constant jump, ...): make the compiler
+// wait for them HERE.  Otherwise its wait-count pass, which cannot see across the loop back-edge that they arrived long
+// ago, puts an s_waitcnt vmcnt(0) in front of their first use inside the loop -- and that also waits for every prefetch
+// the step has just issued, i.e. it exposes a full memory latency per step (measured on the backward kernel).
+__device__ __forceinline__ void settle(double& v) { asm volatile("" : "+v"(v)); }
+
 // ---- A(t): HBM -> registers -> LDS operand buffer, in 16-byte operand units ----------------------------------------
 // The k-pair interleaved operand layout keeps rows 2p and 2p+1 of the operand in one 16-byte unit per column.  A staging
 // item is such a unit: (p, o) = rows 2p, 2p+1 of the operand at column o -- forward (operand = A^T) the elements
@@ -472,6 +478,9 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
   // offset vectors: b0 = b_k, b1 = b_{k+1}; b_{k+2} is fetched one step ahead (HBM latency off the critical path)
   double b0 = vlane ? bb[lane] : 0.0;
   double b1 = (vlane && Np > 1) ? bb[D + lane] : 0.0;
+#pragma unroll
+  for (int s = 0; s < MAXU; s++) { settle(sk[s]); settle(sig[s]); }
+  settle(b0); settle(b1); settle(mk);
   __syncthreads();
 
   for (int k = 0; k < Np - 1; k++) {
@@ -570,7 +579,11 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
 }
 
 // =================================================================================================================
-template <int METHOD, int NB, int NW>
+// DENSEJ: the jumps come as dense (Np, D, D) / (Np, D) arrays (operator-level API); otherwise one constant matrix jump
+// applied at the observation indices and sparse vector jumps (the sweep).  A compile-time switch: with both paths in one
+// kernel the dense path's loads and the sparse path's selects share registers, and the wait-count pass then puts an
+// s_waitcnt vmcnt(0) in front of the selects -- behind the prefetches the step has just issued.
+template <int METHOD, int NB, int NW, bool DENSEJ>
 __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB, NW>;
@@ -619,15 +632,29 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
   // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
   double g0 = vlane ? gm[(size_t)(Np - 1) * D + lane] : 0.0;
   double g1 = (vlane && Np > 1) ? gm[(size_t)(Np - 2) * D + lane] : 0.0;
-  int n_obs_cur = (!a.js_dense && a.obs_idx && Np > 1) ? a.obs_idx[Np - 2] : -1;
+  // observation index of grid point t (-1: none): the one of t-1 decides this step's jump, the one of t-2 which vector
+  // jump to prefetch; it is itself fetched a step before it is needed (its load must not be waited for in the step that
+  // issues it: that wait would also cover the prefetches issued just before)
+  const bool sparse = !DENSEJ && a.obs_idx;
+  int n_obs_cur = (sparse && Np > 1) ? a.obs_idx[Np - 2] : -1;
+  int n_obs_next = (sparse && Np > 2) ? a.obs_idx[Np - 3] : -1;
+  // (the in-loop fetch goes through a lane-"dependent" address so that the value stays in a VGPR until the next step
+  // reads it with v_readfirstlane; a visibly uniform load is moved to an SGPR -- i.e. waited for -- on the spot)
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  int n_obs_next2_v = -1;
   double jm = 0.0;
   if (Np > 1) {
-    if (a.js_dense) { if (vlane) jm = a.jm_dense[((size_t)prob * Np + (Np - 2)) * D + lane]; }
+    if (DENSEJ) { if (vlane) jm = a.jm_dense[((size_t)prob * Np + (Np - 2)) * D + lane]; }
     else if (vlane && n_obs_cur >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_cur) * D + lane];
   }
+#pragma unroll
+  for (int s = 0; s < MAXU; s++) { settle(jsc[s]); settle(gC[s]); settle(gN[s]); }
+  settle(g0); settle(g1); settle(jm);
   __syncthreads();
 
   for (int t = Np - 1; t > 0; t--) {
+    if (t < Np - 1) n_obs_next = __builtin_amdgcn_readfirstlane(n_obs_next2_v);   // fetched during the previous step
     // Psi_t, lam_t of the previous iteration go to HBM here (see the forward kernel)
     if (t < Np - 1) {
       double* po = psi + (size_t)t * DD;
@@ -642,15 +669,15 @@ __global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
     for (int q = 0; q < EPT; q++) aC[q] = aN[q];
     if (t >= 2) load_a<NB, NW>(A + (size_t)(t - 2) * DD, AS, aN);
     const double g2 = (vlane && t >= 2) ? gm[(size_t)(t - 2) * D + lane] : 0.0;   // for the next step
-    const int n_obs_next = (!a.js_dense && a.obs_idx && t >= 2) ? a.obs_idx[t - 2] : -1;
+    n_obs_next2_v = (sparse && t >= 3) ? a.obs_idx[t - 3 + vzero] : -1;             // for the next step
     double jm_next = 0.0;
     if (t >= 2) {
-      if (a.js_dense) { if (vlane) jm_next = a.jm_dense[((size_t)prob * Np + (t - 2)) * D + lane]; }
+      if (DENSEJ) { if (vlane) jm_next = a.jm_dense[((size_t)prob * Np + (t - 2)) * D + lane]; }
       else if (vlane && n_obs_next >= 0) jm_next = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_next) * D + lane];
     }
     // matrix jump of index t-1
     double js[MAXU];
-    if (a.js_dense) {
+    if (DENSEJ) {
       const double* jp = a.js_dense + ((size_t)prob * Np + (t - 1)) * DD;
 #pragma unroll
       for (int s = 0; s < MAXU; s++) js[s] = ((T.valid >> s) & 1u) ? jp[T.gofs[s]] : 0.0;
@@ -743,7 +770,7 @@ template <int METHOD, bool FWD, int NB, int NW>
 hipError_t launch_nb_w(const OdeArgs& a, hipStream_t st) {
   constexpr size_t lds = Geo<NB, NW>::LDS_DOUBLES * sizeof(double);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = FWD ? k_fwd_mfma<METHOD, NB, NW> : k_bwd_mfma<METHOD, NB, NW>;
+  auto kern = FWD ? k_fwd_mfma<METHOD, NB, NW> : (a.js_dense ? k_bwd_mfma<METHOD, NB, NW, true> : k_bwd_mfma<METHOD, NB, NW, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(a.batch), dim3(64 * NW), lds, st, a);
