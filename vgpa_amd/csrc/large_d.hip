@@ -195,44 +195,52 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int fi = lane & 15, fk = lane >> 4;
 
-  // per-thread global offsets of the first k-tile and LDS offsets of its pairs
-  size_t ga[AV], gb[2];
+  // per-thread operand pointers (advanced by one k-tile per load_tiles call; dedicated registers -- with addresses
+  // recomputed per tile the register allocator recycles the data registers of the previous tile's loads for them, and
+  // every new load then waits for those loads: vmcnt(0) in front of the prefetch) and LDS offsets of the pairs
+  const double* pA[AV];
+  const double* pA1[AV];
+  const double* pB[2];
   int sa[AV], sb[2];
 #pragma unroll
   for (int q = 0; q < AV; q++) {
+    size_t go;
     if (TRANSA) {
       const int i2 = tid & (BM / 2 - 1), k = tid / (BM / 2) + (NT / (BM / 2)) * q;
-      ga[q] = (size_t)k * g.lda + i0 + 2 * i2;
+      go = (size_t)k * g.lda + i0 + 2 * i2;
       sa[q] = k * LDT + 2 * i2;
     } else {
       const int kp = tid & 7, i = (tid >> 3) + 32 * q;
-      ga[q] = (size_t)(i0 + i) * g.lda + 2 * kp;
+      go = (size_t)(i0 + i) * g.lda + 2 * kp;
       sa[q] = i * LDK + 2 * kp;
     }
+    pA[q] = g.A0 + go;
+    pA1[q] = MID ? g.A1 + go : nullptr;
   }
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int j2 = tid & 31, k = (tid >> 5) + 8 * q;
-    gb[q] = (size_t)k * g.ldb + j0 + 2 * j2;
+    pB[q] = g.B + (size_t)k * g.ldb + j0 + 2 * j2;
     sb[q] = k * LDBS + 2 * j2;
   }
   const size_t astep = TRANSA ? (size_t)BK * g.lda : (size_t)BK, bstep = (size_t)BK * g.ldb;
 
   d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
-  auto load_tiles = [&](int kt, d2 (&ra)[AV], d2 (&rb)[2]) {
+  auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {      // loads the NEXT k-tile (tiles are requested in order)
 #pragma unroll
     for (int q = 0; q < AV; q++) {
-      const size_t idx = ga[q] + (size_t)kt * astep;
-      const d2 v0 = *reinterpret_cast<const d2*>(g.A0 + idx);
+      const d2 v0 = *reinterpret_cast<const d2*>(pA[q]);
+      pA[q] += astep;
       if (MID) {
-        const d2 v1 = *reinterpret_cast<const d2*>(g.A1 + idx);
+        const d2 v1 = *reinterpret_cast<const d2*>(pA1[q]);
+        pA1[q] += astep;
         ra[q] = d2{0.5 * (v0[0] + v1[0]), 0.5 * (v0[1] + v1[1])};
       } else {
         ra[q] = v0;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) rb[q] = *reinterpret_cast<const d2*>(g.B + gb[q] + (size_t)kt * bstep);
+    for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bstep; }
   };
   auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
 #pragma unroll
@@ -266,28 +274,28 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
     }
   };
   if constexpr (BM < 128) {
-    load_tiles(0, ra0, rb0);
+    load_tiles(ra0, rb0);
     store_tiles(0, ra0, rb0);
-    if (nk > 1) load_tiles(1, ra1, rb1);
+    if (nk > 1) load_tiles(ra1, rb1);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+      if (kt + 2 < nk) load_tiles(ra0, rb0);
       compute(0);
       if (kt + 1 < nk) store_tiles(1, ra1, rb1);
       __syncthreads();
       if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+      if (kt + 3 < nk) load_tiles(ra1, rb1);
       compute(1);
       if (kt + 2 < nk) store_tiles(0, ra0, rb0);
       __syncthreads();
     }
   } else {
-    load_tiles(0, ra0, rb0);
+    load_tiles(ra0, rb0);
     store_tiles(0, ra0, rb0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) load_tiles(kt + 1, ra0, rb0);
+      if (kt + 1 < nk) load_tiles(ra0, rb0);
       compute(cur);
       if (kt + 1 < nk) store_tiles(cur ^ 1, ra0, rb0);
       __syncthreads();

@@ -157,33 +157,35 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   const double* B = g.B + (long long)blockIdx.z * g.sB;
   double* C = g.C + (long long)blockIdx.z * g.sC;
   const int fi = lane & 15, fk = lane >> 4;
-  long long ga[AV], gb[2];
+  // persistent operand pointers, advanced by one k-tile per load (see ld::k_gemm_v)
+  const double* pA[AV];
+  const double* pB[2];
   int sa[AV], sb[2];
 #pragma unroll
   for (int q = 0; q < AV; q++) {
     if (TA) {
       const int i2 = tid & (BM / 2 - 1), k = tid / (BM / 2) + (NT / (BM / 2)) * q;
-      ga[q] = (long long)k * g.lda + i0 + 2 * i2;
+      pA[q] = A + (long long)k * g.lda + i0 + 2 * i2;
       sa[q] = k * LDT + 2 * i2;
     } else {
       const int kp = tid & 7, i = (tid >> 3) + 32 * q;
-      ga[q] = (long long)(i0 + i) * g.lda + 2 * kp;
+      pA[q] = A + (long long)(i0 + i) * g.lda + 2 * kp;
       sa[q] = i * LDK + 2 * kp;
     }
   }
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int j2 = tid & 31, k = (tid >> 5) + 8 * q;
-    gb[q] = (long long)k * g.ldb + j0 + 2 * j2;
+    pB[q] = B + (long long)k * g.ldb + j0 + 2 * j2;
     sb[q] = k * LDBS + 2 * j2;
   }
   const long long astep = TA ? (long long)BK * g.lda : (long long)BK, bstep = (long long)BK * g.ldb;
   d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
-  auto load_tiles = [&](int kt, d2 (&ra)[AV], d2 (&rb)[2]) {
+  auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {       // loads the NEXT k-tile
 #pragma unroll
-    for (int q = 0; q < AV; q++) ra[q] = *reinterpret_cast<const d2*>(A + ga[q] + (long long)kt * astep);
+    for (int q = 0; q < AV; q++) { ra[q] = *reinterpret_cast<const d2*>(pA[q]); pA[q] += astep; }
 #pragma unroll
-    for (int q = 0; q < 2; q++) rb[q] = *reinterpret_cast<const d2*>(B + gb[q] + (long long)kt * bstep);
+    for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bstep; }
   };
   auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
 #pragma unroll
@@ -218,19 +220,23 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   if (g.k_tri == 1) kt0 = j0 / BK;
   else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
   if (kt0 > nk) kt0 = nk;
+#pragma unroll
+  for (int q = 0; q < AV; q++) pA[q] += (long long)kt0 * astep;
+#pragma unroll
+  for (int q = 0; q < 2; q++) pB[q] += (long long)kt0 * bstep;
   if (kt0 < nk) {
-    load_tiles(kt0, ra0, rb0);
+    load_tiles(ra0, rb0);
     store_tiles(0, ra0, rb0);
-    if (kt0 + 1 < nk) load_tiles(kt0 + 1, ra1, rb1);
+    if (kt0 + 1 < nk) load_tiles(ra1, rb1);
   }
   __syncthreads();
   for (int kt = kt0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+    if (kt + 2 < nk) load_tiles(ra0, rb0);
     compute(0);
     if (kt + 1 < nk) store_tiles(1, ra1, rb1);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+    if (kt + 3 < nk) load_tiles(ra1, rb1);
     compute(1);
     if (kt + 2 < nk) store_tiles(0, ra0, rb0);
     __syncthreads();
