@@ -667,6 +667,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
 
+  // the two entries of S_t that <f>_i needs at the very end (E96_drift): requested now -- at the end they would cost a
+  // full memory round trip per wave
+  double sxa = 0.0, sxb = 0.0;
+  if (act) {
+    const int ip1 = wrap(l + 1, D), im1 = wrap(l - 1, D), im2 = wrap(l - 2, D);
+    sxa = St[ip1 * D + im1];
+    sxb = St[im2 * D + im1];
+  }
+
   // ---- stage c*S into LDS (coalesced); padding: identity
   if (D < Dp) {
     for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
@@ -977,7 +986,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- <f> and optionally dense <df/dx>
   if (act) {
     const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
-    const double cxx = St[ip1 * D + im1] - St[im2 * D + im1];
+    const double cxx = sxa - sxb;
     a.Ef[o * D + i] = cxx + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
   }
   if (a.Edf) {
