@@ -252,38 +252,49 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
   double* gA = a.g + (size_t)prob * len_x + (size_t)t * DD;
   double* gB = a.g + (size_t)prob * len_x + (size_t)a.Np * DD + (size_t)t * D;
 
-  // all HBM loads of this thread are issued before the first one is consumed
+  // ALL HBM loads of this thread are issued before the first one is consumed -- the matrices, the diagonal of Sigma^-1
+  // for its elements, and (threads < D) the vector entries: one memory round trip per workgroup instead of three
+  // (with six workgroups per CU there is little else to hide a round trip behind)
   constexpr int EPT = (P * P + NT - 1) / NT;
-  double sv[EPT], pv[EPT], av[EPT];
+  const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;   // e / D for e < 4096, 5 <= D <= 64
+  double sv[EPT], pv[EPT], av[EPT], ig[EPT], ev[EPT];
 #pragma unroll
   for (int q = 0; q < EPT; q++) {
     const int e = tid + q * NT;
     const bool in = e < DD;
+    const int i = (int)(((unsigned)(in ? e : 0) * magic) >> 20);
     sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0; av[q] = in ? At[e] : 0.0;
+    ig[q] = in ? a.isig[i * D + i] : 0.0;
+    ev[q] = (in && Edf) ? Edf[e] : 0.0;
   }
-  if (tid < P) { mv[tid] = (tid < D) ? a.m[o * D + tid] : 0.0; uv[tid] = 0.0; }
+  const double s00 = St[0];
+  const bool vt = tid < D;
+  const double v_m = vt ? a.m[o * D + tid] : 0.0;
+  const double v_am = (vt && a.Am) ? a.Am[o * D + tid] : 0.0;
+  const double v_ef = vt ? a.Ef[o * D + tid] : 0.0;
+  const double v_b = vt ? bt[tid] : 0.0;
+  const double v_ig = vt ? a.isig[tid * D + tid] : 0.0;
+  const double v_lam = vt ? a.lam[o * D + tid] : 0.0;
+  if (tid < P) { mv[tid] = v_m; uv[tid] = 0.0; }
   if (D < P) {                                   // zero padding of the operands (rows / columns D..P-1)
     for (int e = tid; e < P * LD; e += NT) { QT[e] = 0.0; Ss[e] = 0.0; }
   }
   __syncthreads();
-  const double s00 = St[0];
-  const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;   // e / D for e < 4096, 5 <= D <= 64
 #pragma unroll
   for (int q = 0; q < EPT; q++) {
     const int e = tid + q * NT;
     if (e < DD) {
       const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
-      const double ed = Edf ? Edf[e] : edf_entry(a.model, a.theta, D, i, j, mv, s00);
+      const double ed = Edf ? ev[q] : edf_entry(a.model, a.theta, D, i, j, mv, s00);
       Ss[i * LD + j] = sv[q];
-      QT[j * LD + i] = a.isig[i * D + i] * (ed + av[q]) - 2.0 * pv[q];
+      QT[j * LD + i] = ig[q] * (ed + av[q]) - 2.0 * pv[q];
     }
   }
-  if (tid < D) {
-    double s = 0.0;
-    if (a.Am) s = a.Am[o * D + tid];
-    else for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s);
-    const double r = -a.Ef[o * D + tid] - s + bt[tid];
-    const double u = a.isig[tid * D + tid] * r + a.lam[o * D + tid];
+  if (vt) {
+    double s = v_am;
+    if (!a.Am) { s = 0.0; for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s); }
+    const double r = -v_ef - s + v_b;
+    const double u = v_ig * r + v_lam;
     uv[tid] = u;
     gB[tid] = a.dt * u;
   }
