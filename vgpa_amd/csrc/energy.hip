@@ -676,27 +676,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sxb = St[im2 * D + im1];
   }
 
-  // ---- stage c*S into LDS (coalesced); padding: identity
+  // ---- stage c*S into LDS (coalesced); padding: identity.  Every HBM load of the wave (the vectors too) is requested
+  //      before the first one is consumed: a lone wave pays each dependent round trip in full.
+  const double v_m = act ? a.m[o * D + l] : 0.0;
+  const double v_b = act ? a.b[(size_t)prob * a.strideB + (size_t)t * D + l] : 0.0;
+  const double v_sg = act ? a.isg[l] : 0.0;
   if (D < Dp) {
     for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
   }
-  if (pad) { S.mv[l] = 0.0; S.bv[l] = 0.0; S.sg[l] = 0.0; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
+  if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.sg[l] = v_sg; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
   wave_sync();
   {
     constexpr int EPL = (Dp * Dp + 63) / 64;
+    constexpr int CH = (NB <= 11) ? EPL : 13;                // loads in flight per round trip (registers)
     const int DD = D * D;
     const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;
 #pragma unroll
-    for (int q0 = 0; q0 < EPL; q0 += 13) {
-      double sv[13];
+    for (int q0 = 0; q0 < EPL; q0 += CH) {
+      double sv[CH];
 #pragma unroll
-      for (int u = 0; u < 13; u++) {
+      for (int u = 0; u < CH; u++) {
         const int e = l + 64 * (q0 + u);
         const bool in = (q0 + u < EPL) && (e < DD);
         sv[u] = in ? St[e] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 13; u++) {
+      for (int u = 0; u < CH; u++) {
         const int e = l + 64 * (q0 + u);
         if ((q0 + u < EPL) && (e < DD)) {
           const int r = (int)(((unsigned)e * magic) >> 20), cc = e - r * D;
@@ -706,7 +711,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
   if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
-  if (act) { S.mv[l] = a.m[o * D + l]; S.bv[l] = a.b[(size_t)prob * a.strideB + (size_t)t * D + l]; S.sg[l] = a.isg[l]; }
   wave_sync();
 
   // ---- 1. Cholesky (identical to k_energy_l96)
