@@ -623,15 +623,15 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 //      done afterwards with lane = column from three parked rows of G), summed over the rows by one ones-MFMA (k = r4)
 //      and four partial rows in LDS (b),
 //    * L^-1 overwrites L in place (block-row I of L is dead once block-row I of the inverse is known).
-//  LDS per grid point at D = 40: 18.9 KB instead of 30.5 KB -> 8 waves per CU instead of 5.
+//  LDS per grid point at D = 40: 17.9 KB instead of 30.5 KB -> 9 waves per CU instead of 5 (168 VGPRs: three per SIMD).
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t l96r_lds_doubles(int D) {
   const size_t dp = l96_dp(D);
-  return dp * l96_ld(D) + 7 * dp + 11 * dp;      // L + vectors + scratch (4 + 4 partial rows, 3 rows of G; later xdiag)
+  return dp * l96_ld(D) + 6 * dp + 9 * dp;       // L + 6 vectors + scratch (4 + 4 partial rows, 1 row of G; later xdiag)
 }
 
 template <int NB>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_energy_l96_r(EnergyArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 10 ? 3 : 2, NB <= 10 ? 3 : 2))) k_energy_l96_r(EnergyArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int D = a.D, M = 2 * D + 1;
   constexpr int Dp = 4 * NB, LD = Dp + 1, NUU = (NB + 3) / 4;
@@ -640,11 +640,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
   const size_t o = (size_t)prob * a.Np + t;
   L96Lds S;
-  S.Lm = smem; S.Gm = nullptr; S.mv = S.Lm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
-  S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
+  // (Sigma^-1's diagonal is kept in registers, not in LDS; rows 0 and 1 of the parked G share the space of dl and qq,
+  //  which are written after the boundary pass: 17.9 KB per grid point at D = 40, nine waves per CU)
+  S.Lm = smem; S.Gm = nullptr; S.mv = S.Lm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = nullptr;
+  S.dl = S.am + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
   double* pv = S.vv;                 // [4][Dp] partial sums (over the rows of block-slot b) of the plus points
   double* pw = pv + 4 * Dp;          // [4][Dp] ... of the minus points
-  double* gb = pw + 4 * Dp;          // [3][Dp] rows 0, 1, D-1 of G
+  double* gb2 = pw + 4 * Dp;         // [Dp] row D-1 of G (rows 0 and 1: S.dl, S.qq)
   double* xdiag = pv;                // phase 4 (the partial sums are dead by then)
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
@@ -681,10 +683,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const double v_m = act ? a.m[o * D + l] : 0.0;
   const double v_b = act ? a.b[(size_t)prob * a.strideB + (size_t)t * D + l] : 0.0;
   const double v_sg = act ? a.isg[l] : 0.0;
+
   if (D < Dp) {
     for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
   }
-  if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.sg[l] = v_sg; S.am[l] = 0.0; S.dl[l] = 0.0; S.qq[l] = 0.0; S.rd[l] = 1.0; }
+  if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.am[l] = 0.0; S.rd[l] = 1.0; }
   wave_sync();
   {
     constexpr int EPL = (Dp * Dp + 63) / 64;
@@ -798,10 +801,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int u = 0; u < NUU; u++) {
     if (u == 0 || (16 * u <= Dp - 1 && 16 * u + 15 >= Dp - 4)) {
       const int i = 16 * u + 4 * b + r4;
-      const int slot = (i == 0) ? 0 : ((i == 1) ? 1 : ((i == D - 1) ? 2 : -1));
-      if (slot >= 0) {
+      double* gdst = (i == 0) ? S.dl : ((i == 1) ? S.qq : ((i == D - 1) ? gb2 : nullptr));
+      if (gdst) {
 #pragma unroll
-        for (int J = 0; J < NB; J++) gb[slot * Dp + 4 * J + c4] = gacc[u][J];
+        for (int J = 0; J < NB; J++) gdst[4 * J + c4] = gacc[u][J];
       }
     }
   }
@@ -814,7 +817,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool ok = (i >= 2) && (i <= D - 2);
     const int ir = ok ? i : 2;                                  // masked lanes read a valid interior row, weight 0
     const double mm2 = S.mv[ir - 2], mm1 = S.mv[ir - 1], m0 = S.mv[ir], m1 = S.mv[ir + 1];
-    const double sgr = S.sg[ir];
+    const double sgr = __shfl(v_sg, ir, 64);                    // Sigma^-1[ir][ir] lives in lane ir's register
     const double bvi = S.bv[ir], sgi = ok ? sgr : 0.0, ami = amr[u];
     const double* lp = S.Lm + (ir - 2) * LD + c4;
 #pragma unroll
@@ -866,23 +869,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const double N0 = chi(pMm, D - 2), N1 = chi(pMm, D - 1), N2 = chi(pM, 0), N3 = chi(pM, 1), N4 = chi(pM, 2);
       const double Q0 = chi(pP, D - 3), Q1 = chi(pP, D - 2), Q2 = chi(pP, D - 1), Q3 = chi(pPp, 0);
       const double R0 = chi(pM, D - 3), R1 = chi(pM, D - 2), R2 = chi(pM, D - 1), R3 = chi(pMp, 0);
-      const double g0 = gb[jc], g1 = gb[Dp + jc], g2 = gb[2 * Dp + jc];
+      const double g0 = S.dl[jc], g1 = S.qq[jc], g2 = gb2[jc];
       {
-        const double ami = S.am[0], bvi = S.bv[0], sgi = S.sg[0];
+        const double ami = S.am[0], bvi = S.bv[0], sgi = lane_value(v_sg, 0);
         const double ra = ((P3 - P0) * P1 - P2 + theta) + (ami + g0) - bvi;
         const double rb = ((N3 - N0) * N1 - N2 + theta) + (ami - g0) - bvi;
         vplus = __builtin_fma(sgi, ra * ra, vplus);
         vminus = __builtin_fma(sgi, rb * rb, vminus);
       }
       {
-        const double ami = S.am[1], bvi = S.bv[1], sgi = S.sg[1];
+        const double ami = S.am[1], bvi = S.bv[1], sgi = lane_value(v_sg, 1);
         const double ra = ((P4 - P1) * P2 - P3 + theta) + (ami + g1) - bvi;
         const double rb = ((N4 - N1) * N2 - N3 + theta) + (ami - g1) - bvi;
         vplus = __builtin_fma(sgi, ra * ra, vplus);
         vminus = __builtin_fma(sgi, rb * rb, vminus);
       }
       {
-        const double ami = S.am[D - 1], bvi = S.bv[D - 1], sgi = S.sg[D - 1];
+        const double ami = S.am[D - 1], bvi = S.bv[D - 1], sgi = lane_value(v_sg, D - 1);
         const double ra = ((Q3 - Q0) * Q1 - Q2 + theta) + (ami + g2) - bvi;
         const double rb = ((R3 - R0) * R1 - R2 + theta) + (ami - g2) - bvi;
         vplus = __builtin_fma(sgi, ra * ra, vplus);
@@ -896,7 +899,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const double xm1 = (i >= 1) ? S.mv[i - 1] : chi(M - 1, D - 1);
       const double x1 = (i + 1 < D) ? S.mv[i + 1] : chi(1, 0);
       const double r0 = ((x1 - xm2) * xm1 - S.mv[i] + theta) + S.am[i] - S.bv[i];
-      v0 = S.sg[i] * (r0 * r0);
+      v0 = v_sg * (r0 * r0);
     }
     v0 = wave_sum(v0);
   }
@@ -904,9 +907,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const double e_part = act ? (vplus + vminus) : 0.0;
   const double e_t = 0.5 * (w0 * v0 + w1 * wave_sum(e_part));
   wave_sync();                                   // every lane has read the partial sums: xdiag may overwrite them
-  if (act) {
-    S.dl[l] = w1 * (vplus - vminus);
-    S.qq[l] = 0.5 * c * (w1 * (vplus + vminus)) - e_t;
+  if (pad) {                                     // (padding entries back to zero: the parked rows of G were here)
+    S.dl[l] = act ? w1 * (vplus - vminus) : 0.0;
+    S.qq[l] = act ? 0.5 * c * (w1 * (vplus + vminus)) - e_t : 0.0;
   }
   if (l == 0) a.e_t[o] = e_t;
   // inverses of the 4x4 diagonal blocks of L (lane I < NB)
