@@ -148,11 +148,14 @@ struct Geo {
   // fetches both -- and the lanes r4 = 0, 1 of a 32-lane store group, which own ADJACENT rows of the stage state, write
   // the two halves of the same units instead of colliding on the same banks (a lone wave per SIMD reaches the LDS rate with b128 reads but only ~1/5 of it with b64 reads,
   // MI355X_MICROARCH.md s.LDS).  LDX = 0 (mod 32) doubles makes the 16-wide B rows conflict-free for the b128 lane
-  // groups; LDA = 8 or 24 (mod 32) doubles spreads the four 4-wide A rows of a fragment over the 64 banks.
+  // groups; LDA: see below (the fragment reads themselves, 16-lane groups inside one operand row, do not depend on it).
   static constexpr int KKE = NB + (NB & 1);               // k-steps rounded up to even (extra rows are zero)
   static constexpr int ROWS = 2 * KKE;                    // (KKE / 2) k-pairs x 4 rows
   static constexpr int LDX = 32 * ((2 * P + 31) / 32);
-  static constexpr int LDA = 16 * ((2 * P - 8 + 15) / 16) + 8;   // = 8 or 24 (mod 32), >= 2P
+  // LDA = 18 (mod 32) doubles, >= 2P: (i) 16 units one operand-row pair apart (the forward staging, which reads A in
+  // whole rows) land on 32 different banks, (ii) so do the 32 rows a lane group of the backward mat-vec reads
+  // (18 rho mod 32 runs over the even residues).  The fragment reads (b128, 16-lane groups inside one row) do not care.
+  static constexpr int LDA = 32 * ((2 * P - 18 + 31) / 32) + 18;
   static constexpr int LDW = 32 * ((P + 31) / 32);        // exchange buffer for W^T (swizzled inside 32-column groups, w_off)
   static constexpr int EPT = (P * P / 2 + NT - 1) / NT;   // 16-byte operand units (two A entries) per thread for the HBM -> LDS staging
   static constexpr int TRASH = 2 * NT;                    // one 16-byte scratch slot per thread for lanes without an element
@@ -394,8 +397,10 @@ __device__ __forceinline__ void build_astage(int D, AStage<NB, NW>& s) {
 #pragma unroll
   for (int q = 0; q < g::EPT; q++) {
     const int e = ltid() + q * g::NT;
-    const int p = e / D, o = e - p * D;
-    const bool ok = p < npair;
+    // backward: column o fastest over the lanes (rows of A are contiguous in o); forward: pair p fastest (the two
+    // entries A[o][2p], A[o][2p+1] of consecutive p are contiguous: whole rows of A per 20 lanes)
+    const int p = FWD ? e % npair : e / D, o = FWD ? e / npair : e - (e / D) * D;
+    const bool ok = FWD ? (o < D) : (p < npair);
     const bool two = ok && (2 * p + 1 < D);
     s.g0[q] = ok ? (FWD ? o * D + 2 * p : 2 * p * D + o) : 0;
     s.g1[q] = two ? (FWD ? o * D + 2 * p + 1 : (2 * p + 1) * D + o) : 0;
