@@ -134,3 +134,58 @@ def test_state_errors():
     c72.free_energy(x72)
     with pytest.raises(NotImplementedError):
         c72.gradient(None)                         # D > 64: the gradient needs a diagonal system noise matrix (for now)
+
+
+@pytest.mark.parametrize("d", [2, 3, 4])
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_lane_per_problem_steppers(d, method):
+    """D <= 4 with >= 512 problems runs one LANE per problem (ode_small.hip).  Operator-level calls with non-symmetric
+    inputs and dense jumps: a few of the 520 problems against the oracle, all of them against the workgroup-per-problem
+    kernels (VGPA_FLAG_FORCE_GENERIC), which evaluate the same expressions in the same order."""
+    rng = np.random.default_rng(100 * d + len(method))
+    nb, n = 520, 24
+    a = 2.0 * np.eye(d) + 0.3 * rng.standard_normal((nb, n, d, d))
+    b = rng.standard_normal((nb, n, d))
+    m0 = rng.standard_normal(d)
+    s0 = 0.2 * np.eye(d) + 0.01 * rng.standard_normal((d, d))
+    sigma = np.eye(d) + 0.1 * rng.standard_normal((d, d))
+    gm = rng.standard_normal((nb, n, d))
+    gs = rng.standard_normal((nb, n, d, d))
+    jm = np.zeros((nb, n, d)); jm[:, 7] = rng.standard_normal((nb, d))
+    js = np.zeros((nb, n, d, d)); js[:, 7] = rng.standard_normal((nb, d, d)); js[:, 0] = rng.standard_normal((nb, d, d))
+    res = []
+    for flags in (0, FLAG_FORCE_GENERIC):
+        ctx = va.Context("NONE", method, d, n, 0.01, sigma=sigma, batch=nb, flags=flags)
+        mt, st = ctx.solve_fwd(a, b, m0, s0, sigma)
+        lam, psi = ctx.solve_bwd(a, gm, gs, jm, js)
+        ctx.close()
+        res.append((mt, st, lam, psi))
+    for got, want in zip(res[0], res[1]):
+        assert rel_err(got, want) < 1e-13
+    for p in (0, 63, 64, 519):
+        mt_o, st_o = vo.solve_fwd(method, 0.01, False, a[p], b[p], m0, s0, sigma)
+        lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a[p], gm[p], gs[p], jm[p], js[p])
+        assert rel_err(res[0][0][p], mt_o) < TOL and rel_err(res[0][1][p], st_o) < TOL
+        assert rel_err(res[0][2][p], lam_o) < TOL and rel_err(res[0][3][p], psi_o) < TOL
+
+
+def test_lane_per_problem_sweep_of_lorenz63():
+    """The fused sweep of 600 Lorenz-63 problems (lane-per-problem steppers, sparse jumps) equals the single-problem
+    contexts (workgroup-per-problem steppers) for a few of them."""
+    from helpers import build_problem
+    p = build_problem("L63", "RK4", 0.6, 0.01, None)
+    v = p["vgp"]
+    x0 = v.initialization()
+    nb = 600
+    xb = np.stack([x0 + 0.05 * np.random.default_rng(i).standard_normal(x0.size) for i in range(nb)])
+    e0 = float(p["kl0"](p["m0"], p["s0"]))
+    kw = dict(sigma=p["model"].sigma, theta=p["model"].theta, m0=p["m0"], s0=p["s0"], obs_t=p["obs_t"], obs_y=p["obs_y"],
+              obs_noise=p["obs_noise"], e0=e0)
+    ctx = va.Context("L63", "rk4", 3, v.dim_n, 0.01, batch=nb, **kw)
+    f, g = ctx.sweep(xb)
+    ctx.close()
+    one = va.Context("L63", "rk4", 3, v.dim_n, 0.01, batch=1, **kw)
+    for i in (0, 1, 64, 599):
+        f1, g1 = one.sweep(xb[i])
+        assert abs(f[i] - f1) <= 1e-12 * abs(f1) and rel_err(g[i], g1) < 1e-12
+    one.close()

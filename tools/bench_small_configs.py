@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0] (OU, Euler) and configs[1] (Lorenz-63, RK4), t in [0, 10], dt = 0.01 (Np = 1001): sweeps/s of the
+fused free-energy + gradient evaluation for one problem and for a batch of independent problems.  One JSON line each."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vgpa_amd as va                      # noqa: E402
+from helpers import build_problem          # noqa: E402
+
+
+def run(model, method, batch, reps=20):
+    p = build_problem(model, method, 10.0, 0.01, None)
+    v = p["vgp"]
+    x0 = v.initialization()
+    d = v.dim_d
+    e0 = float(p["kl0"](p["m0"], p["s0"]))
+    ctx = va.Context(model, method, d, v.dim_n, 0.01, sigma=p["model"].sigma, theta=p["model"].theta, m0=p["m0"],
+                     s0=p["s0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=batch)
+    xb = np.stack([x0 + 0.01 * np.random.default_rng(i).standard_normal(x0.size) for i in range(batch)])
+    xd, gd = ctx.alloc(batch * x0.size), ctx.alloc(batch * x0.size)
+    xd.upload(xb)
+    for _ in range(3):
+        ctx.sweep_enqueue(xd, gd); ctx.fetch_f()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.sweep_enqueue(xd, gd); f = ctx.fetch_f()
+    dt = (time.perf_counter() - t0) / reps
+    pr = ctx.profile_end()
+    ctx.close()
+    return {"model": model, "method": method, "D": d, "Np": int(v.dim_n), "batch": batch, "ms_per_step": 1e3 * dt,
+            "sweeps_per_s": batch / dt, "F0": float(np.atleast_1d(f)[0]),
+            "phase_ms": {k: pr[k] / reps for k in ("fwd_ms", "energy_ms", "bwd_ms", "grad_ms")}}
+
+
+if __name__ == "__main__":
+    for model, method in (("OU", "Euler"), ("L63", "RK4")):
+        for batch in (1, 65536):
+            print(json.dumps(run(model, method, batch)))

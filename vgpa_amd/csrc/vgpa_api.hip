@@ -161,6 +161,13 @@ static void prof_collect(vgpa_ctx* c) {
   c->prof_pending = false;
 }
 
+// D <= 4: one lane per problem (any inputs) -- always at D = 1, from 512 problems at D = 2..4 (below that a problem per
+// workgroup has the shorter latency: Lorenz-63 RK4 Np = 1001 forward 1.2 ms vs 1.6 ms; at 65536 problems 108 ms vs
+// 6 ms).  VGPA_FLAG_FORCE_GENERIC keeps the workgroup-per-problem kernels.
+static bool use_lane(vgpa_ctx* c) {
+  return c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && (c->D == 1 || c->B >= 512);
+}
+
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
   return sym && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && ode_mfma_supported(c->cfg.method, fwd, c->D);
 }
@@ -186,8 +193,9 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
   a.four_waves = (c->cfg.flags & VGPA_FLAG_FOUR_WAVES) ? 1 : 0;
-  hipError_t e = use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
-                                        : launch_ode_generic(c->cfg.method, true, a, c->stream);
+  hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, true, a, c->stream)
+                 : use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
+                                          : launch_ode_generic(c->cfg.method, true, a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "forward sweep launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;
 }
@@ -216,8 +224,9 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   a.four_waves = (c->cfg.flags & VGPA_FLAG_FOUR_WAVES) ? 1 : 0;
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
   else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
-  hipError_t e = use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
-                                         : launch_ode_generic(c->cfg.method, false, a, c->stream);
+  hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, false, a, c->stream)
+                 : use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
+                                           : launch_ode_generic(c->cfg.method, false, a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "backward sweep launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;
 }

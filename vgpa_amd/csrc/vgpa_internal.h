@@ -10,6 +10,7 @@
 namespace vgpa {
 
 constexpr int kMaxSmallD = 64;   // single-workgroup (LDS resident) stepping kernels
+constexpr int kMaxLaneD = 4;     // one-lane-per-problem stepping kernels (ode_small.hip)
 constexpr int kMaxTheta = 4;
 
 // Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
@@ -104,6 +105,7 @@ struct ReduceArgs {
 
 // launchers (each returns hipGetLastError()) -----------------------------------------------------
 hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_t st);
+hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t st);     // D <= kMaxLaneD
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
