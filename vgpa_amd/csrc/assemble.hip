@@ -372,34 +372,53 @@ __global__ void __launch_bounds__(64) k_grad_small(GradArgs a) {
   const double* bt = a.b + (size_t)prob * a.strideB + (size_t)t * D;
   const double* St = a.S + o * DD;
   const double* Pt = a.psi + o * DD;
-  double mv[D], rv[D], uv[D], pa[DD], q[DD];
-  for (int i = 0; i < D; i++) mv[i] = a.m[o * D + i];
+  // every operand of the grid point is requested before the first one is used (one memory round trip per thread)
+  double Av[DD], Sv[DD], Pv[DD], Ev[DD], Iv[DD], mv[D], bv[D], ef[D], lm[D];
+#pragma unroll
+  for (int e = 0; e < DD; e++) {
+    Av[e] = At[e]; Sv[e] = St[e]; Pv[e] = Pt[e]; Iv[e] = a.isig[e];
+    Ev[e] = a.Edf ? a.Edf[o * DD + e] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < D; i++) { mv[i] = a.m[o * D + i]; bv[i] = bt[i]; ef[i] = a.Ef[o * D + i]; lm[i] = a.lam[o * D + i]; }
+  double rv[D], uv[D], pa[DD], q[DD];
+#pragma unroll
   for (int i = 0; i < D; i++) {
     double s = 0.0;
-    for (int k = 0; k < D; k++) s = __builtin_fma(At[i * D + k], mv[k], s);
-    rv[i] = -a.Ef[o * D + i] - s + bt[i];
+#pragma unroll
+    for (int k = 0; k < D; k++) s = __builtin_fma(Av[i * D + k], mv[k], s);
+    rv[i] = -ef[i] - s + bv[i];
   }
+#pragma unroll
   for (int i = 0; i < D; i++)
+#pragma unroll
     for (int j = 0; j < D; j++)
-      pa[i * D + j] = (a.Edf ? a.Edf[o * DD + i * D + j] : edf_entry(a.model, a.theta, D, i, j, mv, St[0])) + At[i * D + j];
+      pa[i * D + j] = (a.Edf ? Ev[i * D + j] : edf_entry(a.model, a.theta, D, i, j, mv, Sv[0])) + Av[i * D + j];
+#pragma unroll
   for (int i = 0; i < D; i++) {
     double deb = 0.0;
-    for (int l = 0; l < D; l++) deb = __builtin_fma(a.isig[i * D + l], rv[l], deb);
-    uv[i] = deb + a.lam[o * D + i];
+#pragma unroll
+    for (int l = 0; l < D; l++) deb = __builtin_fma(Iv[i * D + l], rv[l], deb);
+    uv[i] = deb + lm[i];
+#pragma unroll
     for (int j = 0; j < D; j++) {
       double s = 0.0;
-      for (int l = 0; l < D; l++) s = __builtin_fma(a.isig[i * D + l], pa[l * D + j], s);
-      q[i * D + j] = s - 2.0 * Pt[i * D + j];
+#pragma unroll
+      for (int l = 0; l < D; l++) s = __builtin_fma(Iv[i * D + l], pa[l * D + j], s);
+      q[i * D + j] = s - 2.0 * Pv[i * D + j];
     }
   }
   const size_t len_x = (size_t)a.Np * DD + (size_t)a.Np * D;
   double* gA = a.g + (size_t)prob * len_x + (size_t)t * DD;
   double* gB = a.g + (size_t)prob * len_x + (size_t)a.Np * DD + (size_t)t * D;
+#pragma unroll
   for (int i = 0; i < D; i++) {
     gB[i] = a.dt * uv[i];
+#pragma unroll
     for (int j = 0; j < D; j++) {
       double s = 0.0;
-      for (int k = 0; k < D; k++) s = __builtin_fma(q[i * D + k], St[k * D + j], s);
+#pragma unroll
+      for (int k = 0; k < D; k++) s = __builtin_fma(q[i * D + k], Sv[k * D + j], s);
       gA[i * D + j] = a.dt * (s - uv[i] * mv[j]);
     }
   }
