@@ -138,12 +138,14 @@ def test_state_errors():
 
 @pytest.mark.parametrize("d", [2, 3, 4])
 @pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
-def test_lane_per_problem_steppers(d, method):
-    """D <= 4 with >= 512 problems runs one LANE per problem (ode_small.hip).  Operator-level calls with non-symmetric
-    inputs and dense jumps: a few of the 520 problems against the oracle, all of them against the workgroup-per-problem
-    kernels (VGPA_FLAG_FORCE_GENERIC), which evaluate the same expressions in the same order."""
+@pytest.mark.parametrize("nb", [6, 520])
+def test_lane_per_problem_steppers(d, method, nb):
+    """D <= 4: >= 512 problems run one LANE per problem (ode_small.hip), fewer run 16 lanes per problem with shuffled
+    operands (ode_wave.hip; nb = 6 leaves half of the second wave idle).  Operator-level calls with non-symmetric inputs
+    and dense jumps: a few problems against the oracle, all of them against the workgroup-per-problem kernels
+    (VGPA_FLAG_FORCE_GENERIC), which evaluate the same expressions in the same order."""
     rng = np.random.default_rng(100 * d + len(method))
-    nb, n = 520, 24
+    n = 24
     a = 2.0 * np.eye(d) + 0.3 * rng.standard_normal((nb, n, d, d))
     b = rng.standard_normal((nb, n, d))
     m0 = rng.standard_normal(d)
@@ -162,7 +164,7 @@ def test_lane_per_problem_steppers(d, method):
         res.append((mt, st, lam, psi))
     for got, want in zip(res[0], res[1]):
         assert rel_err(got, want) < 1e-13
-    for p in (0, 63, 64, 519):
+    for p in sorted({0, min(63, nb - 1), min(64, nb - 1), nb - 1}):
         mt_o, st_o = vo.solve_fwd(method, 0.01, False, a[p], b[p], m0, s0, sigma)
         lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a[p], gm[p], gs[p], jm[p], js[p])
         assert rel_err(res[0][0][p], mt_o) < TOL and rel_err(res[0][1][p], st_o) < TOL

@@ -167,6 +167,10 @@ static void prof_collect(vgpa_ctx* c) {
 static bool use_lane(vgpa_ctx* c) {
   return c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && (c->D == 1 || c->B >= 512);
 }
+// D = 2..4 below that: 16 lanes per problem, operands exchanged by ds_bpermute (ode_wave.hip)
+static bool use_wave(vgpa_ctx* c) {
+  return c->D >= 2 && c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && c->B < 512;
+}
 
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
   return sym && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && ode_mfma_supported(c->cfg.method, fwd, c->D);
@@ -194,6 +198,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
   a.four_waves = (c->cfg.flags & VGPA_FLAG_FOUR_WAVES) ? 1 : 0;
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, true, a, c->stream)
+                 : use_wave(c) ? launch_ode_wave(c->cfg.method, true, a, c->stream)
                  : use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
                                           : launch_ode_generic(c->cfg.method, true, a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "forward sweep launch failed: %s", hipGetErrorString(e));
@@ -225,6 +230,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
   else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, false, a, c->stream)
+                 : use_wave(c) ? launch_ode_wave(c->cfg.method, false, a, c->stream)
                  : use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
                                            : launch_ode_generic(c->cfg.method, false, a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "backward sweep launch failed: %s", hipGetErrorString(e));

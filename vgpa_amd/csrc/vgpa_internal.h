@@ -106,6 +106,7 @@ struct ReduceArgs {
 // launchers (each returns hipGetLastError()) -----------------------------------------------------
 hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t st);     // D <= kMaxLaneD
+hipError_t launch_ode_wave(int method, bool fwd, const OdeArgs& a, hipStream_t st);      // 2 <= D <= kMaxLaneD, few problems
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
