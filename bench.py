@@ -182,10 +182,18 @@ def main():
         "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * (4 * d * d + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
                      unit="GB/s"),                                                # read A, S, Psi + vectors ; write gLa, gLb
     }
+    nb_blocks = (d + 3) // 4
+    method_id = {"EULER": 0, "HEUN": 1, "RK2": 2, "RK4": 3}.get(args.method.upper(), 3)
+    # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 44)
+    nw = 8 if nb_blocks >= 8 else 4
+    symbols = {"solve_fwd": f"vgpa::mfma::k_fwd_mfma<{method_id}, {nb_blocks}, {nw}>",
+               "solve_bwd": f"vgpa::mfma::k_bwd_mfma<{method_id}, {nb_blocks}, {nw}, false>",
+               "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():
         ach = k["alg"] / max(k["seconds"], 1e-12) / k["scale"]
-        roof[name] = {"bound": k["bound"], "kernel": name, "achieved": ach, "peak": k["peak"], "unit": k["unit"],
+        roof[name] = {"bound": k["bound"], "kernel": name, "symbol": None if args.generic else symbols[name],
+                      "achieved": ach, "peak": k["peak"], "unit": k["unit"],
                       "frac": ach / k["peak"], "traffic": traffic_of(name), "launch_ms": 1e3 * k["seconds"],
                       ("alg_flop_per_launch" if k["bound"] == "mfma" else "alg_bytes_per_launch"): k["alg"]}
     dom = max(kernels, key=lambda n: kernels[n]["seconds"])
