@@ -55,10 +55,16 @@ __global__ void __launch_bounds__(NT) k_obs(ObsArgs a) {
     const double* y = a.obs_y + (size_t)n * D;
     const double* mt = m + (size_t)tn * D;
     double qrow = 0.0, krow = 0.0;
-    for (int j = 0; j < D; j++) {
-      const double w = y[j] - mt[j];
-      qrow = __builtin_fma(a.Q[i * D + j], w, qrow);
-      krow = __builtin_fma(a.K[i * D + j], w, krow);
+    if (a.diag) {                                  // diagonal R^-1 and H^T R^-1 (the usual case): the other terms are exact zeros
+      const double w = y[i] - mt[i];
+      qrow = __builtin_fma(a.Q[i * D + i], w, qrow);
+      krow = __builtin_fma(a.K[i * D + i], w, krow);
+    } else {
+      for (int j = 0; j < D; j++) {
+        const double w = y[j] - mt[j];
+        qrow = __builtin_fma(a.Q[i * D + j], w, qrow);
+        krow = __builtin_fma(a.K[i * D + j], w, krow);
+      }
     }
     jm[u] = -krow;
     // Q4: the covariance diagonal is taken at index n (observation counter), not at t_n
