@@ -148,6 +148,12 @@ int vgpa_energy_full(vgpa_ctx* ctx, const double* lin_a, const double* off_b, co
 
 /* gradient from the cached state into a DEVICE buffer (df(x) of SCG, src/numerics/optim_scg.py:100,235) */
 int vgpa_gradient_dev(vgpa_ctx* ctx, double* g_dev);
+/* LIFETIME of x_dev: the *_dev entry points consume the caller's x in place (zero copy) and the cached state keeps
+ * referring to it -- vgpa_gradient_dev / vgpa_gradient(NULL) read A_t, b_t from that memory.  The caller keeps x_dev
+ * alive and unchanged until the next evaluation, or calls vgpa_release_x before freeing / overwriting it: the cached
+ * state is then dropped and a gradient request without x fails with VGPA_ERR_STATE instead of reading freed memory.
+ * (vgpa_dev_free of the very pointer does the same by itself.) */
+int vgpa_release_x(vgpa_ctx* ctx);
 
 /* device-resident vector algebra for the SCG driver (src/numerics/optim_scg.py:75-285):
  * x, d and the gradients stay in HBM, only scalars return.  Every vector is the context's batch of `batch` segments of
@@ -169,7 +175,8 @@ int vgpa_set_option(vgpa_ctx* ctx, int option, int64_t value);
 /* 1 if the context runs the time-chunked large-D sweep (VGPA_FLAG_STREAM_LARGE_D or chosen for lack of memory) */
 int vgpa_is_streaming(vgpa_ctx* ctx);
 
-/* raw device memory helpers so that hosts without a HIP binding can own device buffers */
+/* raw device memory helpers so that hosts without a HIP binding can own device buffers; whatever has not been returned
+ * through vgpa_dev_free when the context is destroyed is freed with it */
 int vgpa_dev_alloc(vgpa_ctx* ctx, uint64_t bytes, void** out);
 int vgpa_dev_free(vgpa_ctx* ctx, void* ptr);
 int vgpa_memcpy_h2d(vgpa_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);

@@ -76,25 +76,25 @@ def test_h5py_opens_the_writers_files(tmp_path):
 
 
 @pytest.mark.gpu
-def test_simulation_run_save_load(tmp_path, monkeypatch):
-    """setup -> run -> save -> load with the reference's parameter dictionary layout (sim_params_OU.json)."""
+def test_optimise_save_load(tmp_path, monkeypatch):
+    """optimise -> save_results -> load_results: the reference's result-file key set (simulation.py:290-307)."""
+    from helpers import build_problem
     monkeypatch.chdir(tmp_path)
-    params = {"Model": "OU", "Ode-method": "Euler", "Random-Seed": 31415926535,
-              "Time-window": {"t0": 0.0, "tf": 2.0, "dt": 0.01}, "Noise": {"sys": 0.8, "obs": 0.04},
-              "Observations": {"density": 2, "operator": None}, "Drift": {"theta": 1.0},
-              "Prior": {"mu0": 1.0, "tau0": 0.5}}
     outs = []
     for resident in (False, True):
-        sim = va.Simulation("OU run %d" % resident)
-        sim.setup(params, None)
-        sim.run(options={"max_it": 8, "x_tol": 1e-6, "f_tol": 1e-8, "display": False}, device_resident=resident)
-        sim.save()
-        back = va.load_results("OU_run_%d.h5" % resident)
+        p = build_problem("OU", "Euler", 2.0, 0.01, None)
+        v = p["vgp"]
+        opts = {"max_it": 8, "x_tol": 1e-6, "f_tol": 1e-8, "display": False}
+        opt = v.device_scg(opts) if resident else va.SCG(v.free_energy, v.gradient, opts)
+        x, fx = opt(v.initialization())
+        path, written = va.save_results("OU run %d" % resident, v, x, fx)
+        assert str(path) == "OU_run_%d.h5" % resident
+        back = va.load_results(path)
         assert set(back) == {"at", "bt", "fx", "m0", "s0", "mt", "st", "lamt", "psit", "Efx", "Edf"}
-        for key, val in sim.output.items():
+        for key, val in written.items():
             assert np.array_equal(back[key], np.atleast_1d(val)), key
         outs.append(back)
     assert abs(outs[0]["fx"][0] - outs[1]["fx"][0]) <= 1e-9 * abs(outs[0]["fx"][0])
     assert np.allclose(outs[0]["mt"], outs[1]["mt"], rtol=1e-7, atol=1e-9)
-    with pytest.raises(ValueError):
-        va.Simulation("x").setup(dict(params, Model="nope"), None)
+    with pytest.raises(RuntimeError):
+        va.load_results(None)

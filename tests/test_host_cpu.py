@@ -144,3 +144,128 @@ def test_host_side_gradient_helpers_match_the_reference():
     assert np.allclose([g[0], g[1]], [z["kl1_dm0"], z["kl1_ds0"]], rtol=1e-13, atol=0)
     g = va.PriorKL0(z["kln_mu0"], z["kln_tau0"], False).gradients(z["kln_m0"], z["kln_s0"], z["kln_lam0"], z["kln_psi0"])
     assert np.allclose(g[0], z["kln_dm0"], rtol=1e-12, atol=1e-14) and np.allclose(g[1], z["kln_ds0"], rtol=1e-12, atol=1e-14)
+
+
+def test_host_scg_reproduces_the_references_recorded_optimisation_on_the_oracle_objective():
+    """BASELINE configs[0] (OU, Euler, t in [0, 10]): the reference's complete SCG run (52 iterations, 110 objective
+    evaluations, tests/golden/scg_full_config1.json, written by tools/gen_scg_anchor.py) replayed on the CPU: the lock-step
+    engine with host vectors drives the numpy oracle's objective and must follow the recorded trace."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from helpers import build_problem
+    from oracle import vgpa_oracle as vo
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "scg_full_config1.json")))
+    p = build_problem(ref["model"], ref["method"], ref["tf"], 0.01, None)
+    z = dict(model="OU", method=ref["method"], dt=0.01, theta=1.0, sigma=0.8, m0=p["m0"], s0=p["s0"], mu0=p["mu0"],
+             tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"],
+             time_window=p["model"].time_window)
+    prob = vo.Problem.from_fixture({k: np.asarray(val) for k, val in z.items()})
+    cache = {}
+
+    def f_cpu(x):
+        f, cache["state"] = vo.free_energy(prob, x)
+        return f
+
+    def df_cpu(x, eval_fun=False):
+        if eval_fun:
+            f_cpu(x)
+        return vo.gradient(prob, x, cache["state"])
+
+    opt = va.SCG(f_cpu, df_cpu, {"max_it": ref["max_it"], "x_tol": 1e-6, "f_tol": 1e-8, "display": False})
+    x, fx = opt(p["vgp"].initialization())
+    st = opt.statistics
+    n_it = ref["MaxIt_stat"]
+    assert st["MaxIt"] == n_it and st["f_eval"] == ref["f_eval"]
+    assert np.allclose(st["fx"][:n_it], ref["fx_trace"], rtol=1e-8, atol=0)
+    assert np.allclose(st["beta"][:n_it], ref["beta_trace"], rtol=1e-12, atol=0)
+    assert abs(fx - ref["f_final"]) <= 1e-9 * abs(ref["f_final"])
+    assert abs(np.linalg.norm(x) - ref["x_norm"]) <= 1e-8 * ref["x_norm"]
+
+
+def test_lock_step_engine_freezes_finished_problems():
+    """Two host problems of different difficulty in one lock-step run == the two runs alone."""
+    from vgpa_amd import scg as S
+
+    class Two(S._HostVectors):
+        def __init__(self):
+            super().__init__(None, None)
+            self.B = 2
+            self.scale = np.array([1.0, 50.0])
+
+        def _f(self, x):
+            return np.array([np.sum(self.scale[k] * x[k] ** 2) + np.sum(x[k] ** 4) for k in range(2)])
+
+        def _g(self, x):
+            return np.stack([2.0 * self.scale[k] * x[k] + 4.0 * x[k] ** 3 for k in range(2)])
+
+        def value_and_gradient(self, x, g, st):
+            g[...] = self._g(x)
+            return self._f(x)
+
+        def probe_gradient(self, x, g, st):
+            g[...] = self._g(x)
+
+        def value(self, x, st):
+            return self._f(x)
+
+    x0 = np.random.default_rng(3).standard_normal((2, 6))
+    st = S._new_stats(200, 2)
+    x, f = S._lock_step(Two(), x0, 200, 1e-9, 1e-12, False, st)
+    assert np.all(f < 1e-8) and np.abs(x).max() < 1e-3
+    assert st["MaxIt"][0] != st["MaxIt"][1]               # they stop at different iterations ...
+    for k in range(2):                                    # ... and each equals its own single run
+        def fk(v, k=k):
+            return float(np.sum([1.0, 50.0][k] * v ** 2) + np.sum(v ** 4))
+
+        def gk(v, eval_fun=False, k=k):
+            return 2.0 * [1.0, 50.0][k] * v + 4.0 * v ** 3
+        solo = va.SCG(fk, gk, {"max_it": 200, "x_tol": 1e-9, "f_tol": 1e-12})
+        xs, fs = solo(x0[k])
+        assert solo.statistics["MaxIt"] == st["MaxIt"][k]
+        assert np.allclose(xs, x[k], rtol=0, atol=1e-12)
+
+
+def test_device_contexts_are_rebuilt_when_a_baked_in_input_changes(monkeypatch):
+    """theta / sigma / the observation noise / (m0, s0) are settable on the reference's objects; a context created from
+    older values must not be reused.  No GPU: the Context class is replaced by a recorder."""
+    import vgpa_amd.variational as V
+    import vgpa_amd.likelihood as L
+    from helpers import build_problem
+    made = []
+
+    class Recorder:
+        def __init__(self, *a, **k):
+            self.args, self.kw, self.closed = a, k, False
+            made.append(self)
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(V, "Context", Recorder)
+    monkeypatch.setattr(L, "Context", Recorder)
+    p = build_problem("L96", "RK4", 0.2, 0.01, 12)
+    v = p["vgp"]
+    c0 = v._context()
+    assert v._context() is c0 and len(made) == 1
+    assert c0.kw["obs_h"] is None                          # default operator -> the library's diagonal fast path
+    p["model"].theta = 9.0
+    c1 = v._context()
+    assert c1 is not c0 and c0.closed and c1.kw["theta"][0] == 9.0
+    p["lik"].noise = 2.0 * np.asarray(p["lik"].noise)
+    c2 = v._context()
+    assert c2 is not c1 and c1.closed and np.array_equal(c2.kw["obs_noise"], np.asarray(p["lik"].noise))
+    v.output["m0"] = v.output["m0"] + 1.0
+    assert v._context() is not c2
+    v.invalidate()
+    assert v._ctx is None
+    # the likelihood's own operator-level context follows its noise setter
+    lik = p["lik"]
+    k0 = lik._context(21, 12)
+    assert lik._context(21, 12) is k0
+    lik.noise = 3.0 * np.asarray(lik.noise)
+    assert k0.closed and lik._context(21, 12) is not k0
+    # an explicit operator is passed through
+    h = np.eye(12); h[0, 1] = 0.5
+    lik2 = va.GaussianLikelihood(p["obs_y"], p["obs_t"], p["obs_noise"], h, False)
+    assert np.array_equal(lik2._context(21, 12).kw["obs_h"], h)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The reference's whole workflow at BASELINE configs[2] (sim_params_L40D.json-style parameters, RK4): Simulation.setup ->
-run (SCG, 500 iterations, device-resident vectors) -> save.  Prints one JSON line with the wall time of the optimisation."""
+"""The reference's whole workflow at BASELINE configs[2] (sim_params_L40D.json-style parameters, RK4): seeded inputs ->
+DeviceSCG (500 iterations, device-resident vectors) -> save_results.  Prints one JSON line with the wall time of the optimisation."""
 import io
 import json
 import os
@@ -13,20 +13,22 @@ sys.path.insert(0, ROOT)
 import numpy as np          # noqa: E402
 import vgpa_amd as va       # noqa: E402
 
-params = {"Model": "L96", "Ode-method": "RK4", "Random-Seed": 31415926535,
-          "Time-window": {"t0": 0.0, "tf": 10.0, "dt": 0.01}, "Noise": {"sys": [4.0] * 40, "obs": 1.0},
-          "Observations": {"density": 8, "operator": None}, "Drift": {"theta": 8.0}, "Prior": {"mu0": 1.0, "tau0": 0.5}}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import build_problem   # noqa: E402  (the seeded reference inputs of configs[2])
+
 max_it = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 os.chdir(os.environ.get("TMPDIR", "/tmp"))
-sim = va.Simulation("L40D_rk4")
 with contextlib.redirect_stdout(io.StringIO()):
-    sim.setup(params, None)
+    p = build_problem("L96", "RK4", 10.0, 0.01, 40)
+    v = p["vgp"]
+    opt = v.device_scg({"max_it": max_it, "x_tol": 1.0e-6, "f_tol": 1.0e-8, "display": False})
+    x0 = v.initialization()
     t0 = time.perf_counter()
-    sim.run(options={"max_it": max_it, "x_tol": 1.0e-6, "f_tol": 1.0e-8, "display": False}, device_resident=True)
+    x, fx = opt(x0)
     t_run = time.perf_counter() - t0
-    sim.save()
-out = va.load_results("L40D_rk4.h5")
-print(json.dumps({"workflow": "Simulation.setup -> run(DeviceSCG, max_it=%d) -> save, Lorenz96 D=40 RK4 Np=1001" % max_it,
+    path, _ = va.save_results("L40D_rk4", v, x, fx)
+out = va.load_results(path)
+print(json.dumps({"workflow": "build inputs -> DeviceSCG(max_it=%d) -> save_results, Lorenz96 D=40 RK4 Np=1001" % max_it,
                   "seconds_optimisation": t_run, "F_final": float(out["fx"][0]),
                   "file_keys": sorted(out), "mt_shape": list(out["mt"].shape),
-                  "rmse_mean_vs_true_path": float(np.sqrt(np.mean((out["mt"] - sim.m_data["model"].sample_path) ** 2)))}))
+                  "rmse_mean_vs_true_path": float(np.sqrt(np.mean((out["mt"] - p["model"].sample_path) ** 2)))}))

@@ -11,10 +11,9 @@ from .dynamics import (StochasticProcess, OrnsteinUhlenbeck, DoubleWell,   # noq
 from .likelihood import Likelihood, GaussianLikelihood, PriorKL0           # noqa: F401
 from .variational import VarGP                                             # noqa: F401
 from .scg import SCG, DeviceSCG                                            # noqa: F401
-from .simulation import Simulation, load as load_results                  # noqa: F401
-from .h5io import save_h5, load_h5                                         # noqa: F401
+from .h5io import save_h5, load_h5, result_dict, save_results, load_results   # noqa: F401
 
 __all__ = ["Context", "device_count", "load", "OdeSolver", "Euler", "Heun", "RungeKutta2", "RungeKutta4",
            "num_integration", "FwdOde", "BwdOde", "StochasticProcess", "OrnsteinUhlenbeck", "DoubleWell",
            "Lorenz63", "Lorenz96", "dynamical_systems", "Likelihood", "GaussianLikelihood", "PriorKL0",
-           "VarGP", "SCG", "DeviceSCG", "Simulation", "load_results", "save_h5", "load_h5"]
+           "VarGP", "SCG", "DeviceSCG", "result_dict", "save_results", "load_results", "save_h5", "load_h5"]

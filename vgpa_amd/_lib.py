@@ -30,7 +30,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
            "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming",
-           "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby"]
+           "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x"]
 
 P_DOUBLE = POINTER(c_double)
 
@@ -100,6 +100,7 @@ def load():
                                  c_void_p, c_int]
     lib.vgpa_ld_stage.argtypes = [c_void_p, POINTER(LdStageArgs)]
     lib.vgpa_gradient_dev.argtypes = [c_void_p, c_void_p]
+    lib.vgpa_release_x.argtypes = [c_void_p]
     lib.vgpa_vec_dot.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_absmax.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_asum.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
@@ -157,9 +158,15 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx._h is not None:
             self.ctx._lib.vgpa_dev_free(self.ctx._h, self.ptr)
-            self.ptr = None
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class ExternalBuffer:
@@ -368,6 +375,10 @@ class Context:
 
     def gradient_dev(self, g_buf):
         self._check(self._lib.vgpa_gradient_dev(self._h, g_buf.ptr))
+
+    def release_x(self):
+        """Tells the context that the device x of the last `*_dev` evaluation is about to be freed or overwritten."""
+        self._check(self._lib.vgpa_release_x(self._h))
 
     # ------------------------------------------------------------------ device vector algebra (SCG)
     # Every vector is a DeviceBuffer of B segments; scalars are (B,) arrays, one per problem of the batch.

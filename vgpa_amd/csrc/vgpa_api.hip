@@ -46,6 +46,12 @@ struct vgpa_ctx {
   std::vector<double> h_isig;     // host copy of Sigma^-1 [D][D]
   double* d_vec_scratch = nullptr; // [2B coefficients | B results | B*bps partials] of the vector algebra
   size_t vec_scratch_n = 0;
+  // axpby coefficients travel through a pinned ring (the caller's arrays may be temporaries that die on return)
+  static constexpr int kCoefSlots = 16;
+  double* h_coef = nullptr;        // pinned [kCoefSlots][2B]
+  hipEvent_t ev_coef[kCoefSlots] = {};
+  unsigned coef_next = 0;
+  std::vector<void*> user_allocs;  // vgpa_dev_alloc memory not yet returned through vgpa_dev_free
   int lde_nb = 1;
   double lde_budget = 1.0e9;      // bytes the batched large-D energy workspace may take
   int64_t* d_obs_t = nullptr;
@@ -450,6 +456,9 @@ void vgpa_destroy(vgpa_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) (void)hipFree(p);
+  for (void* p : c->user_allocs) (void)hipFree(p);
+  if (c->h_coef) (void)hipHostFree(c->h_coef);
+  for (auto& e : c->ev_coef) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -581,7 +590,14 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
     } else {
       std::vector<double> Rinv(DD, 0.0), H(DD, 0.0), T(DD);
       double logdet = 0.0;
-      bool r_diag = !cfg->obs_h;               // fast path: diagonal R and H = I (no O(D^3) host work at large D)
+      // fast path: diagonal R and H = I (no O(D^3) host work at large D).  An explicitly passed identity counts as
+      // "no operator" (the reference's Likelihood materialises np.eye(d) when the operator is None, likelihood.py:33-40).
+      bool h_identity = true;
+      if (cfg->obs_h)
+        for (int i = 0; i < D && h_identity; i++)
+          for (int j = 0; j < D; j++)
+            if (cfg->obs_h[(size_t)i * D + j] != (i == j ? 1.0 : 0.0)) { h_identity = false; break; }
+      bool r_diag = h_identity;
       for (int i = 0; i < D && r_diag; i++)
         for (int j = 0; j < D; j++)
           if (i != j && cfg->obs_noise[(size_t)i * D + j] != 0.0) { r_diag = false; break; }
@@ -598,7 +614,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
         c->obs_const = c->M * (D * std::log(2.0 * M_PI) + logdet);
       } else if (!host_spd_inverse(D, cfg->obs_noise, Rinv.data(), &logdet)) { fail(nullptr, VGPA_ERR_NOT_PD, "observation noise matrix is not positive definite"); vgpa_destroy(c); return VGPA_ERR_NOT_PD; }
       if (!r_diag) {
-      if (cfg->obs_h) H.assign(cfg->obs_h, cfg->obs_h + DD); else for (int i = 0; i < D; i++) H[(size_t)i * D + i] = 1.0;
+      if (cfg->obs_h && !h_identity) H.assign(cfg->obs_h, cfg->obs_h + DD); else for (int i = 0; i < D; i++) H[(size_t)i * D + i] = 1.0;
       host_matmul(D, H.data(), Rinv.data(), T.data(), false, false);      // H R^-1
       host_matmul(D, T.data(), H.data(), Q.data(), false, true);          // H R^-1 H^T
       host_matmul(D, H.data(), Rinv.data(), T.data(), true, false);       // H^T R^-1
@@ -642,6 +658,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
 
 int vgpa_synchronize(vgpa_ctx* c) {
   if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VGPA_OK;
 }
@@ -812,6 +829,7 @@ int vgpa_free_energy_dev(vgpa_ctx* c, const double* x_dev, double* f_host) {
 
 int vgpa_fetch_f(vgpa_ctx* c, double* f_host) {
   if (!c || !f_host) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
   if ((rc = download(c, f_host, c->d_f, (size_t)c->B))) return rc;
   return check_status(c);
@@ -865,6 +883,7 @@ int vgpa_sweep(vgpa_ctx* c, const double* x, double* f, double* g) {
 
 int vgpa_sweep_enqueue(vgpa_ctx* c, const double* x_dev, double* g_dev) {
   if (!c || !x_dev || !g_dev) return fail(c, VGPA_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
   if ((rc = ingest_x(c, x_dev, true))) return rc;
   return enqueue_sweep(c, g_dev);
@@ -881,6 +900,7 @@ int vgpa_sweep_dev(vgpa_ctx* c, const double* x_dev, double* f_host, double* g_d
 int vgpa_energy_parts(vgpa_ctx* c, double* e0, double* esde, double* eobs) {
   if (!c) return VGPA_ERR_ARG;
   if (!c->have_state) return fail(c, VGPA_ERR_STATE, "no cached state");
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
   if (e0) for (int p = 0; p < c->B; p++) e0[p] = c->cfg.e0;
   if (esde && (rc = download(c, esde, c->d_esde, (size_t)c->B))) return rc;
@@ -930,6 +950,15 @@ int vgpa_gradient_dev(vgpa_ctx* c, double* g_dev) {
   return check_status(c);
 }
 
+// The *_dev entry points consume the caller's x in place: the cached state refers to that memory until the next
+// evaluation.  A caller about to free or overwrite it says so here; gradient(x, eval_fun=False) then fails loudly
+// instead of reading freed memory.
+int vgpa_release_x(vgpa_ctx* c) {
+  if (!c) return VGPA_ERR_ARG;
+  if (c->xcur != c->d_x) { c->xcur = nullptr; c->have_state = false; }
+  return VGPA_OK;
+}
+
 static int vec_scratch(vgpa_ctx* c, uint64_t seglen) {
   const size_t need = (size_t)c->B * (3 + (size_t)vec_blocks_per_seg((long long)seglen, c->B));
   if (c->vec_scratch_n >= need) return VGPA_OK;
@@ -959,9 +988,22 @@ int vgpa_vec_axpby(vgpa_ctx* c, uint64_t seglen, const double* alpha, const doub
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   int rc;
   if ((rc = vec_scratch(c, seglen))) return rc;
-  // the coefficient upload is stream-ordered behind the previous axpby, so the slots can be reused
-  HIP_TRY(c, hipMemcpyAsync(c->d_vec_scratch, alpha, sizeof(double) * c->B, hipMemcpyHostToDevice, c->stream));
-  if (beta) HIP_TRY(c, hipMemcpyAsync(c->d_vec_scratch + c->B, beta, sizeof(double) * c->B, hipMemcpyHostToDevice, c->stream));
+  // The caller's coefficient arrays may be gone when this returns: copy them into a pinned ring slot first.  A slot is
+  // reused only after the upload that read it has completed (its event); the device-side slots are stream-ordered
+  // behind the previous axpby.
+  const size_t B = (size_t)c->B;
+  if (!c->h_coef) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_coef, sizeof(double) * 2 * B * vgpa_ctx::kCoefSlots, hipHostMallocDefault));
+    for (auto& ev : c->ev_coef) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  const unsigned slot = c->coef_next % vgpa_ctx::kCoefSlots;
+  if (c->coef_next >= (unsigned)vgpa_ctx::kCoefSlots) HIP_TRY(c, hipEventSynchronize(c->ev_coef[slot]));
+  c->coef_next++;
+  double* h = c->h_coef + (size_t)slot * 2 * B;
+  std::memcpy(h, alpha, sizeof(double) * B);
+  if (beta) std::memcpy(h + B, beta, sizeof(double) * B);
+  HIP_TRY(c, hipMemcpyAsync(c->d_vec_scratch, h, sizeof(double) * (beta ? 2 * B : B), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_coef[slot], c->stream));
   hipError_t e = vec_axpby(c->B, (long long)seglen, c->d_vec_scratch, x, c->d_vec_scratch + c->B, y, out, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "axpby failed: %s", hipGetErrorString(e));
   return VGPA_OK;
@@ -986,22 +1028,30 @@ int vgpa_dev_alloc(vgpa_ctx* c, uint64_t bytes, void** out) {
   if (!c || !out) return VGPA_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipMalloc(out, bytes ? bytes : 8));
+  c->user_allocs.push_back(*out);          // whatever the caller does not return is freed with the context
   return VGPA_OK;
 }
 int vgpa_dev_free(vgpa_ctx* c, void* ptr) {
   if (!c) return VGPA_ERR_ARG;
+  if (!ptr) return VGPA_OK;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (ptr == (const void*)c->xcur) { c->xcur = nullptr; c->have_state = false; }
+  for (size_t i = 0; i < c->user_allocs.size(); i++)
+    if (c->user_allocs[i] == ptr) { c->user_allocs[i] = c->user_allocs.back(); c->user_allocs.pop_back(); break; }
   HIP_TRY(c, hipFree(ptr));
   return VGPA_OK;
 }
 int vgpa_memcpy_h2d(vgpa_ctx* c, void* dst, const void* src, uint64_t bytes) {
   if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VGPA_OK;
 }
 int vgpa_memcpy_d2h(vgpa_ctx* c, void* dst, const void* src, uint64_t bytes) {
   if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VGPA_OK;
@@ -1016,6 +1066,7 @@ int vgpa_profile_begin(vgpa_ctx* c) {
 }
 int vgpa_profile_end(vgpa_ctx* c, double* fwd_ms, double* energy_ms, double* bwd_ms, double* grad_ms, int64_t* n_sweeps) {
   if (!c) return VGPA_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   c->prof = false;

@@ -325,3 +325,35 @@ def load_h5(path):
         if arr is not None:
             out[name] = arr
     return out
+
+
+def result_dict(vgp, x, fx):
+    """The dictionary a finished optimisation leaves behind, in the key set of the reference's result files
+    (simulation.py:290-307): the optimal (A_t, b_t) split out of `x`, the minimum `fx`, and `vgp.arg_out`
+    (m0, s0, mt, st, lamt, psit, Efx, Edf) of the state at `x`."""
+    x = np.asarray(x, dtype=float)
+    n, d = vgp.dim_n, vgp.dim_d
+    out = {"fx": fx}
+    if vgp.model.single_dim:
+        out["at"], out["bt"] = x[:n], x[n:]
+    else:
+        out["at"], out["bt"] = x[:n * d * d].reshape(n, d, d), x[n * d * d:].reshape(n, d)
+    vgp.free_energy(x)                       # the state at the returned x, whatever the optimiser evaluated last
+    out.update(vgp.arg_out)
+    return out
+
+
+def save_results(name, vgp, x, fx):
+    """`<name>.h5` (spaces -> underscores) with one dataset per key of `result_dict`; returns (path, dictionary)."""
+    from pathlib import Path
+    out = result_dict(vgp, x, fx)
+    path = Path(str(name).strip().replace(" ", "_") + ".h5")
+    save_h5(path, out)
+    return path, out
+
+
+def load_results(filename):
+    """Every dataset of a result file -- one written here or one written by the reference (simulation.py:314-347)."""
+    if filename is None:
+        raise RuntimeError(" load_results: no input file is given.")
+    return load_h5(filename)

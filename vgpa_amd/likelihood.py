@@ -17,6 +17,7 @@ class Likelihood(object):
         self.obs_t = np.asarray(times)
         self.obs_v = np.asarray(values)
         self.obs_n = np.asarray(noise)
+        self.default_operator = operator is None
         if operator is None:
             y0 = self.obs_v[0]
             self.obs_h = np.asarray(1) if y0.ndim == 0 else np.eye(y0.size)
@@ -38,6 +39,10 @@ class Likelihood(object):
     @noise.setter
     def noise(self, new_value):
         self.obs_n = new_value
+        self._drop_contexts()
+
+    def _drop_contexts(self):
+        """Device contexts bake the noise in; subclasses that hold some close them here."""
 
     @property
     def operator(self):
@@ -55,14 +60,20 @@ class GaussianLikelihood(Likelihood):
         self._ctx = {}
         self.device = 0
 
+    def _drop_contexts(self):
+        for ctx in getattr(self, "_ctx", {}).values():
+            ctx.close()
+        self._ctx = {}
+
     def _context(self, n_pts, dim_d):
         key = (n_pts, dim_d, self.device)
         ctx = self._ctx.get(key)
         if ctx is None:
-            self._ctx.clear()
+            self._drop_contexts()
+            obs_h = None if self.default_operator else np.asarray(self.operator, dtype=float).reshape(dim_d, dim_d)
             ctx = Context("NONE", "euler", dim_d, n_pts, 1.0, sigma=np.eye(dim_d), obs_t=self.times,
                           obs_y=self.values, obs_noise=np.asarray(self.noise, dtype=float).reshape(dim_d, dim_d),
-                          obs_h=np.asarray(self.operator, dtype=float).reshape(dim_d, dim_d), device=self.device)
+                          obs_h=obs_h, device=self.device)
             self._ctx[key] = ctx
         return ctx
 

@@ -1,274 +1,315 @@
 """
-Scaled Conjugate Gradient driver: the caller of the hot path (src/numerics/optim_scg.py:23-285, NETLAB's
-`scg`).  Host Python by design (BASELINE.json north_star); it calls `f(x)`, `df(x)` and
-`df(x_plus, eval_fun=True)` in the same order as the reference so that an optimisation trace is comparable
-evaluation by evaluation.
+Scaled conjugate gradients: the caller of the hot path (the reference drives `VarGP.free_energy / gradient` with
+NETLAB's `scg`, src/numerics/optim_scg.py:75-285).
+
+One engine, `_lock_step`, advances B independent minimisations together: every per-problem scalar of the method
+(mu, kappa, theta, delta, alpha, beta, gamma, f) is a (B,) array, every decision of the method is a boolean mask, and
+the vectors (x, d, two gradients, two trial vectors) live wherever the *backend* keeps them:
+
+  * `_DeviceVectors` -- segments of DeviceBuffers in HBM, algebra by vecops.hip, objective by the `*_dev` entry points
+    (x never crosses PCIe; only the (B,) scalars do).  `DeviceSCG` is this backend: the shipped optimiser.
+  * `_HostVectors` -- numpy rows and a user-supplied pair `f(x)`, `df(x, eval_fun=False)`.  `SCG(f, df, options)` is
+    this backend with B = 1; it exists so that code written against the reference's optimiser interface (and the
+    reference's recorded optimisation traces, tests/golden/scg_*.json) runs unchanged against the GPU objective.
+
+A problem that has met its stopping rule gets zero coefficients from then on (its vectors are frozen) while the rest of
+the batch continues.  The order in which the objective is evaluated -- f and g at x0, g at x + sigma d, f at x + alpha d,
+g at an accepted point -- is the method's; the host backend additionally repeats `f(x)` at an accepted point because the
+reference does (optim_scg.py:232-235) and its evaluation counts are part of the recorded traces, whereas the device
+backend assembles that gradient from the state `f(x + alpha d)` left in HBM (one sweep less, same numbers).
 """
 import numpy as np
 
+_SIGMA0 = 1.0e-3                       # finite-difference scale of the curvature probe
+_BETA_MIN, _BETA_MAX = 1.0e-15, 1.0e+100
 
-class SCG(object):
 
-    def __init__(self, f, df, *args) -> None:
-        opts = args[0] if args else {}
-        self.f, self.df = f, df
-        self.nit = opts.get("max_it", 150)
-        self.x_tol = opts.get("x_tol", 1.0e-6)
-        self.f_tol = opts.get("f_tol", 1.0e-8)
-        self.display = opts.get("display", False)
-        self.stats = {"MaxIt": self.nit, "fx": np.zeros(self.nit), "dfx": np.zeros(self.nit),
-                      "f_eval": 0.0, "df_eval": 0.0, "beta": np.zeros(self.nit)}
+def _options(args):
+    opts = dict(args[0]) if args else {}
+    return (int(opts.get("max_it", 150)), float(opts.get("x_tol", 1.0e-6)), float(opts.get("f_tol", 1.0e-8)),
+            bool(opts.get("display", False)))
 
-    @property
-    def statistics(self) -> dict:
-        return self.stats
 
-    def __call__(self, x0: np.ndarray, *args):
-        st = self.stats
-        x = x0.flatten()
-        n_par = x.size
-        sigma0 = 1.0e-3
-        beta, beta_lo, beta_hi = 1.0, 1.0e-15, 1.0e+100
-        eps = np.finfo(float).eps
+def _new_stats(nit, nb):
+    return {"MaxIt": np.full(nb, nit), "fx": np.zeros((nit, nb)), "dfx": np.zeros((nit, nb)),
+            "f_eval": 0.0, "df_eval": 0.0, "beta": np.zeros((nit, nb))}
 
-        f_now = self.f(x, *args)
-        g_new = self.df(x, *args)
+
+class _HostVectors:
+    """numpy rows + callables.  Vectors are (B, n) arrays; B = 1 unless `f`/`df` are themselves batched."""
+
+    def __init__(self, f, df, extra=()):
+        self.f, self.df, self.extra, self.B = f, df, tuple(extra), 1
+
+    def vectors(self, x0, count):
+        x0 = np.asarray(x0, dtype=float).reshape(self.B, -1)
+        return [x0.copy()] + [np.zeros_like(x0) for _ in range(count - 1)]
+
+    def release(self, vecs):
+        pass
+
+    def _each(self, fn, x, *a, **k):
+        return np.stack([np.asarray(fn(row, *a, **k), dtype=float) for row in x])
+
+    def value_and_gradient(self, x, g, st):
+        f = self._each(self.f, x, *self.extra).reshape(self.B)
+        g[...] = self._each(self.df, x, *self.extra)
         st["f_eval"] += 1
         st["df_eval"] += 1
-        f_old, g_old = f_now, np.copy(g_new)
-        d = -g_new
-        ok, n_ok = True, 0
-        kappa = theta = mu = 0.0
+        return f
 
-        for j in range(self.nit):
-            if ok:
-                # directional derivative and curvature along d
-                mu = d.T.dot(g_new)
-                if mu >= 0.0:
-                    d = -g_new
-                    mu = d.T.dot(g_new)
-                kappa = d.T.dot(d)
-                if kappa < eps:
-                    st["MaxIt"] = j + 1
-                    return x, f_now
-                sigma = sigma0 / np.sqrt(kappa)
-                g_plus = self.df(x + (sigma * d), eval_fun=True)
-                st["f_eval"] += 1
-                st["df_eval"] += 1
-                theta = (d.T.dot(g_plus - g_new)) / sigma
+    def probe_gradient(self, x, g, st):
+        g[...] = self._each(self.df, x, eval_fun=True)
+        st["f_eval"] += 1
+        st["df_eval"] += 1
 
-            delta = theta + (beta * kappa)
-            if delta <= 0.0:
-                delta = beta * kappa
-                beta = beta - (theta / kappa)
-            alpha = -(mu / delta)
+    def value(self, x, st):
+        st["f_eval"] += 1
+        return self._each(self.f, x, *self.extra).reshape(self.B)
 
-            x_new = x + (alpha * d)
-            f_new = self.f(x_new, *args)
-            st["f_eval"] += 1
-            delta = 2.0 * (f_new - f_old) / (alpha * mu)     # comparison ratio
-            if delta >= 0.0:
-                ok = True
-                n_ok += 1
-                x, f_now, g_now = np.copy(x_new), np.copy(f_new), np.copy(g_new)
-            else:
-                ok = False
-                f_now, g_now = f_old, np.copy(g_old)
+    def gradient_at_accepted(self, x, g, st):
+        self.value_and_gradient(x, g, st)
 
-            total_grad = np.sum(np.abs(g_now))
-            st["fx"][j], st["beta"][j], st["dfx"][j] = f_now, beta, total_grad
-            if self.display and (np.mod(j, 10) == 0):
-                print(" {0}: fx={1:.3f}\tsum(gx)={2:.3f}".format(j, f_now, total_grad))
+    def dot(self, a, b):
+        return np.array([ra.dot(rb) for ra, rb in zip(a, b)])
 
-            if ok:
-                if (np.abs(alpha * d).max() <= self.x_tol) and (np.abs(f_new - f_old) <= self.f_tol):
-                    st["MaxIt"] = j + 1
-                    return x, f_new
-                f_old, g_old = f_new, np.copy(g_new)
-                f_now = self.f(x, *args)
-                g_new = self.df(x, *args)
-                st["f_eval"] += 1
-                st["df_eval"] += 1
-                if np.isclose(g_new.T.dot(g_new), 0.0):
-                    st["MaxIt"] = j + 1
-                    return x, f_now
+    def absmax(self, a):
+        return np.abs(a).max(axis=1)
 
-            if delta < 0.25:
-                beta = np.minimum(4.0 * beta, beta_hi)
-            if delta > 0.75:
-                beta = np.maximum(0.5 * beta, beta_lo)
+    def asum(self, a):
+        return np.abs(a).sum(axis=1)
 
-            if n_ok == n_par:
-                d = -g_new
-                n_ok = 0
-            elif ok:
-                gamma = np.maximum(g_new.T.dot(g_old - g_new) / mu, 0.0)
-                d = (gamma * d) - g_new
+    def axpby(self, al, a, be, b, out):
+        al = np.broadcast_to(np.asarray(al, dtype=float), (self.B,))[:, None]
+        if b is None:
+            out[...] = al * a
+        else:
+            be = np.broadcast_to(np.asarray(be, dtype=float), (self.B,))[:, None]
+            # a zero coefficient must not touch its operand (an evaluated trial point may hold inf / nan)
+            out[...] = np.where(al != 0.0, al * a, 0.0) + np.where(be != 0.0, be * b, 0.0)
 
-        print(" SGC: Maximum number of iterations has been reached.")
-        return x, f_old
+    def fetch(self, x):
+        return np.array(x)
+
+
+class _DeviceVectors:
+    """B segments per DeviceBuffer on the context's GPU; see vgpa_amd/csrc/vecops.hip."""
+
+    def __init__(self, ctx):
+        self.ctx, self.B = ctx, ctx.B
+
+    def vectors(self, x0, count):
+        from ._lib import DeviceBuffer
+        x0 = np.ascontiguousarray(np.asarray(x0, dtype=float)).reshape(self.B, -1)
+        vecs = [DeviceBuffer(self.ctx, x0.size) for _ in range(count)]
+        vecs[0].upload(x0)
+        return vecs
+
+    def release(self, vecs):
+        self.ctx.synchronize()
+        self.ctx.release_x()          # the context must not keep pointing into a trial vector that is about to go
+        for v in vecs:
+            v.free()
+
+    def value_and_gradient(self, x, g, st):
+        st["f_eval"] += 1
+        st["df_eval"] += 1
+        return np.atleast_1d(self.ctx.sweep_dev(x, g)).astype(float)
+
+    def probe_gradient(self, x, g, st):
+        self.value_and_gradient(x, g, st)
+
+    def value(self, x, st):
+        st["f_eval"] += 1
+        return np.atleast_1d(self.ctx.free_energy_dev(x)).astype(float)
+
+    def gradient_at_accepted(self, x, g, st):
+        st["df_eval"] += 1
+        self.ctx.gradient_dev(g)       # from the state value(x) left resident
+
+    def dot(self, a, b):
+        return self.ctx.vdot(a, b)
+
+    def absmax(self, a):
+        return self.ctx.vabsmax(a)
+
+    def asum(self, a):
+        return self.ctx.vasum(a)
+
+    def axpby(self, al, a, be, b, out):
+        self.ctx.vaxpby(al, a, be, b, out)
+
+    def fetch(self, x):
+        return x.download().reshape(self.B, -1)
+
+
+def _lock_step(vs, x0, nit, x_tol, f_tol, display, st):
+    """Runs the method on backend `vs`; returns (x (B, n), f (B,))."""
+    vecs = vs.vectors(x0, 6)
+    try:
+        return _iterate(vs, vecs, nit, x_tol, f_tol, display, st)
+    finally:
+        vs.release(vecs)
+
+
+def _iterate(vs, vecs, nit, x_tol, f_tol, display, st):
+    x, x_try, d, g_new, g_old, g_tmp = vecs
+    nb = vs.B
+    eps = np.finfo(float).eps
+    ones, zeros = np.ones(nb), np.zeros(nb)
+    pick = lambda mask: np.where(mask, 1.0, 0.0)         # noqa: E731  coefficient 1 where the mask holds
+    keep = lambda mask: np.where(mask, 0.0, 1.0)         # noqa: E731  ... and its complement
+
+    f_now = vs.value_and_gradient(x, g_new, st)
+    f_old = f_now.copy()
+    vs.axpby(ones, g_new, None, None, g_old)
+    vs.axpby(-ones, g_new, None, None, d)
+    n_par = _segment_length(vs, x)
+    ok = np.ones(nb, dtype=bool)                 # last trial step was accepted
+    done = np.zeros(nb, dtype=bool)
+    n_ok = np.zeros(nb, dtype=int)               # accepted steps since the last restart of the direction
+    beta = np.ones(nb)                           # trust-region scale
+    kappa, theta, mu = np.zeros(nb), np.zeros(nb), np.zeros(nb)
+    f_ret = f_now.copy()
+
+    def stop(mask, value, j):
+        nonlocal done
+        mask = mask & ~done
+        f_ret[mask] = value[mask]
+        st["MaxIt"][mask] = j + 1
+        done = done | mask
+
+    for j in range(nit):
+        act = ok & ~done
+        if act.any():                            # second-order information along d (only after an accepted step)
+            mu_c = vs.dot(d, g_new)
+            uphill = act & (mu_c >= 0.0)
+            if uphill.any():
+                vs.axpby(-pick(uphill), g_new, keep(uphill), d, d)
+                mu_c = vs.dot(d, g_new)
+            mu = np.where(act, mu_c, mu)
+            kappa = np.where(act, vs.dot(d, d), kappa)
+            stop(act & (kappa < eps), f_now, j)
+            act = ok & ~done
+            if done.all():
+                break
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sigma = np.where(act, _SIGMA0 / np.sqrt(kappa), 0.0)
+            vs.axpby(ones, x, sigma, d, x_try)
+            vs.probe_gradient(x_try, g_tmp, st)
+            vs.axpby(ones, g_tmp, -ones, g_new, g_tmp)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                theta = np.where(act, vs.dot(d, g_tmp) / sigma, theta)
+
+        live = ~done
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = theta + beta * kappa
+            indefinite = live & (delta <= 0.0)
+            delta = np.where(indefinite, beta * kappa, delta)
+            beta = np.where(indefinite, beta - theta / kappa, beta)
+            alpha = np.where(live, -(mu / delta), 0.0)
+
+        vs.axpby(ones, x, alpha, d, x_try)
+        f_new = vs.value(x_try, st)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = 2.0 * (f_new - f_old) / (alpha * mu)          # actual vs predicted decrease
+        succ = live & (delta >= 0.0)
+        fail = live & ~succ
+        # the recorded gradient norm is the one in force *before* the refresh below (g_now of optim_scg.py:208,213)
+        total_grad = np.where(succ, vs.asum(g_new), vs.asum(g_old))
+        n_ok = n_ok + succ
+        ok = np.where(live, succ, ok)
+        f_now = np.where(succ, f_new, np.where(fail, f_old, f_now))
+        st["fx"][j], st["beta"][j], st["dfx"][j] = f_now, beta, total_grad
+        if display and j % 10 == 0:
+            print(" {0}: fx={1:.3f}\tsum(gx)={2:.3f}".format(j, f_now.sum(), total_grad.sum()))
+
+        if succ.any():
+            vs.axpby(pick(succ), x_try, keep(succ), x, x)          # x <- x_try where accepted
+            step = np.abs(alpha) * vs.absmax(d)
+            stop(succ & (step <= x_tol) & (np.abs(f_new - f_old) <= f_tol), f_new, j)
+            go = succ & ~done
+            if go.any():
+                f_old = np.where(go, f_new, f_old)
+                vs.axpby(pick(go), g_new, keep(go), g_old, g_old)
+                vs.gradient_at_accepted(x, g_tmp, st)
+                vs.axpby(pick(go), g_tmp, keep(go), g_new, g_new)
+                stop(go & np.isclose(vs.dot(g_new, g_new), 0.0), f_now, j)
+        if done.all():
+            break
+
+        live = ~done
+        beta = np.where(live & (delta < 0.25), np.minimum(4.0 * beta, _BETA_MAX), beta)
+        beta = np.where(live & (delta > 0.75), np.maximum(0.5 * beta, _BETA_MIN), beta)
+
+        restart = live & (n_ok == n_par)
+        conj = live & ~restart & ok
+        if restart.any() or conj.any():
+            gamma = zeros
+            if conj.any():
+                vs.axpby(ones, g_old, -ones, g_new, g_tmp)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    gamma = np.maximum(vs.dot(g_new, g_tmp) / mu, 0.0)
+            vs.axpby(np.where(conj, gamma, keep(restart)), d, -pick(conj | restart), g_new, d)
+            n_ok = np.where(restart, 0, n_ok)
+
+    if not done.all():
+        print(" SCG: iteration limit reached before the stopping rule was met.")
+        f_ret[~done] = f_old[~done]
+    return vs.fetch(x), f_ret
+
+
+def _segment_length(vs, x):
+    if isinstance(x, np.ndarray):
+        return x.shape[1]
+    return x.count // vs.B
 
 
 class DeviceSCG(object):
-    """
-    The same SCG iteration (src/numerics/optim_scg.py:75-285) with every vector resident in HBM
-    and advanced in lock step for the `B` independent problems of a batched `Context`:
-
-      * x, d, g_new, g_old and the two trial vectors are DeviceBuffers; the host sees only the per-problem scalars
-        (mu, kappa, theta, delta, alpha, gamma, f) that drive the unchanged control flow, here vectorised over the
-        batch with masks.  A problem that has converged gets zero coefficients and is frozen.
-      * the objective / gradient calls are the context's `*_dev` entry points, so x never crosses PCIe;
-      * the reference re-evaluates `f(x)` right after accepting `x = x_new` (optim_scg.py:232-235) although the state
-        of `f(x_new)` is still cached; here the gradient is assembled from that cached state (one forward-backward
-        sweep less per successful iteration, identical numbers).
-
-    `stats["f_eval"]`/`["df_eval"]` count device evaluations of the whole batch.
-    """
+    """SCG over a batched `Context` with every vector resident in HBM (`VarGP.device_scg`).  `statistics` holds
+    (max_it, B) traces; `f_eval` / `df_eval` count device evaluations of the whole batch."""
 
     def __init__(self, ctx, *args) -> None:
-        opts = args[0] if args else {}
         self.ctx = ctx
-        self.nit = opts.get("max_it", 150)
-        self.x_tol = opts.get("x_tol", 1.0e-6)
-        self.f_tol = opts.get("f_tol", 1.0e-8)
-        self.display = opts.get("display", False)
-        b = ctx.B
-        self.stats = {"MaxIt": np.full(b, self.nit), "fx": np.zeros((self.nit, b)), "dfx": np.zeros((self.nit, b)),
-                      "f_eval": 0.0, "df_eval": 0.0, "beta": np.zeros((self.nit, b))}
+        self.nit, self.x_tol, self.f_tol, self.display = _options(args)
+        self.stats = _new_stats(self.nit, ctx.B)
 
     @property
     def statistics(self) -> dict:
         return self.stats
 
     def __call__(self, x0):
-        from ._lib import DeviceBuffer
-        ctx, st = self.ctx, self.stats
-        nb = ctx.B
-        x0 = np.ascontiguousarray(np.asarray(x0, dtype=float)).reshape(nb, -1)
-        n_par = x0.shape[1]
-        bufs = [DeviceBuffer(ctx, nb * n_par) for _ in range(6)]
+        x, f = _lock_step(_DeviceVectors(self.ctx), x0, self.nit, self.x_tol, self.f_tol, self.display, self.stats)
+        if self.ctx.B == 1:
+            return x[0], float(f[0])
+        return x, f
+
+
+class SCG(object):
+    """`SCG(f, df, options)(x0, *args) -> (x, fx)`: the optimiser interface the reference's driver uses
+    (optim_scg.py:23-73), served by the lock-step engine with host vectors and one problem."""
+
+    def __init__(self, f, df, *args) -> None:
+        self.f, self.df = f, df
+        self.nit, self.x_tol, self.f_tol, self.display = _options(args)
+        self.stats = _new_stats(self.nit, 1)
+        self._squeeze()
+
+    def _squeeze(self):
+        st = self.stats
+        for key in ("fx", "dfx", "beta"):
+            st[key] = np.asarray(st[key]).reshape(self.nit)
+        st["MaxIt"] = int(np.asarray(st["MaxIt"]).ravel()[0])
+
+    @property
+    def statistics(self) -> dict:
+        return self.stats
+
+    def __call__(self, x0, *args):
+        self.stats = _new_stats(self.nit, 1)
         try:
-            return self._run(x0, n_par, *bufs)
+            x, f = _lock_step(_HostVectors(self.f, self.df, args), np.asarray(x0, dtype=float).ravel(), self.nit,
+                              self.x_tol, self.f_tol, self.display, self.stats)
         finally:
-            ctx.synchronize()
-            for buf in bufs:
-                buf.free()
-
-    def _run(self, x0, n_par, x, x_try, d, g_new, g_old, g_tmp):
-        ctx, st = self.ctx, self.stats
-        nb = ctx.B
-        sigma0 = 1.0e-3
-        beta = np.ones(nb)
-        beta_lo, beta_hi = 1.0e-15, 1.0e+100
-        eps = np.finfo(float).eps
-        ones, zeros = np.ones(nb), np.zeros(nb)
-
-        x.upload(x0)
-        f_now = np.atleast_1d(ctx.sweep_dev(x, g_new)).astype(float)
-        st["f_eval"] += 1
-        st["df_eval"] += 1
-        f_old = f_now.copy()
-        ctx.vaxpby(ones, g_new, None, None, g_old)
-        ctx.vaxpby(-ones, g_new, None, None, d)
-        ok = np.ones(nb, dtype=bool)
-        done = np.zeros(nb, dtype=bool)
-        n_ok = np.zeros(nb, dtype=int)
-        kappa, theta, mu = np.zeros(nb), np.zeros(nb), np.zeros(nb)
-        f_ret = f_now.copy()
-
-        def finish(mask, value, j):
-            nonlocal done
-            mask = mask & ~done
-            f_ret[mask] = value[mask]
-            st["MaxIt"][mask] = j + 1
-            done = done | mask
-
-        for j in range(self.nit):
-            act = ok & ~done
-            if act.any():
-                mu_c = ctx.vdot(d, g_new)
-                reset = act & (mu_c >= 0.0)
-                if reset.any():
-                    ctx.vaxpby(np.where(reset, -1.0, 0.0), g_new, np.where(reset, 0.0, 1.0), d, d)
-                    mu_c = ctx.vdot(d, g_new)
-                mu = np.where(act, mu_c, mu)
-                kappa = np.where(act, ctx.vdot(d, d), kappa)
-                finish(act & (kappa < eps), f_now, j)
-                act = ok & ~done
-                if done.all():
-                    break
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    sigma = np.where(act, sigma0 / np.sqrt(kappa), 0.0)
-                ctx.vaxpby(ones, x, sigma, d, x_try)
-                ctx.sweep_dev(x_try, g_tmp)
-                st["f_eval"] += 1
-                st["df_eval"] += 1
-                ctx.vaxpby(ones, g_tmp, -ones, g_new, g_tmp)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    theta = np.where(act, ctx.vdot(d, g_tmp) / sigma, theta)
-
-            live = ~done
-            with np.errstate(divide="ignore", invalid="ignore"):
-                delta = theta + beta * kappa
-                fix = live & (delta <= 0.0)
-                delta = np.where(fix, beta * kappa, delta)
-                beta = np.where(fix, beta - theta / kappa, beta)
-                alpha = np.where(live, -(mu / delta), 0.0)
-
-            ctx.vaxpby(ones, x, alpha, d, x_try)
-            f_new = np.atleast_1d(ctx.free_energy_dev(x_try)).astype(float)
-            st["f_eval"] += 1
-            with np.errstate(divide="ignore", invalid="ignore"):
-                delta = 2.0 * (f_new - f_old) / (alpha * mu)
-            succ = live & (delta >= 0.0)
-            fail = live & ~succ
-            # statistics use the gradient *before* it is refreshed (g_now of optim_scg.py:208,213)
-            total_grad = np.where(succ, ctx.vasum(g_new), ctx.vasum(g_old))
-            n_ok = n_ok + succ
-            ok = np.where(live, succ, ok)
-            f_now = np.where(succ, f_new, np.where(fail, f_old, f_now))
-            st["fx"][j], st["beta"][j], st["dfx"][j] = f_now, beta, total_grad
-            if self.display and (np.mod(j, 10) == 0):
-                print(" {0}: fx={1:.3f}\tsum(gx)={2:.3f}".format(j, f_now.sum(), total_grad.sum()))
-
-            if succ.any():
-                # x <- x_new where accepted.  The state cached by free_energy(x_try) is the state at the new x.
-                ctx.vaxpby(np.where(succ, 1.0, 0.0), x_try, np.where(succ, 0.0, 1.0), x, x)
-                step = np.abs(alpha) * ctx.vabsmax(d)
-                finish(succ & (step <= self.x_tol) & (np.abs(f_new - f_old) <= self.f_tol), f_new, j)
-                go = succ & ~done
-                if go.any():
-                    f_old = np.where(go, f_new, f_old)
-                    ctx.vaxpby(np.where(go, 1.0, 0.0), g_new, np.where(go, 0.0, 1.0), g_old, g_old)
-                    ctx.gradient_dev(g_tmp)
-                    st["df_eval"] += 1
-                    ctx.vaxpby(np.where(go, 1.0, 0.0), g_tmp, np.where(go, 0.0, 1.0), g_new, g_new)
-                    gg = ctx.vdot(g_new, g_new)
-                    finish(go & np.isclose(gg, 0.0), f_now, j)
-            if done.all():
-                break
-
-            live = ~done
-            beta = np.where(live & (delta < 0.25), np.minimum(4.0 * beta, beta_hi), beta)
-            beta = np.where(live & (delta > 0.75), np.maximum(0.5 * beta, beta_lo), beta)
-
-            restart = live & (n_ok == n_par)
-            conj = live & ~restart & ok
-            if restart.any() or conj.any():
-                gamma = zeros
-                if conj.any():
-                    ctx.vaxpby(ones, g_old, -ones, g_new, g_tmp)
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        gamma = np.maximum(ctx.vdot(g_new, g_tmp) / mu, 0.0)
-                a_d = np.where(conj, gamma, np.where(restart, 0.0, 1.0))
-                a_g = np.where(conj | restart, -1.0, 0.0)
-                ctx.vaxpby(a_d, d, a_g, g_new, d)
-                n_ok = np.where(restart, 0, n_ok)
-
-        if not done.all():
-            print(" SGC: Maximum number of iterations has been reached.")
-            f_ret[~done] = f_old[~done]
-        x_out = x.download().reshape(nb, n_par)
-        if nb == 1:
-            return x_out[0], float(f_ret[0])
-        return x_out, f_ret
+            self._squeeze()
+        return x[0], float(f[0])

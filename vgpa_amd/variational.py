@@ -31,6 +31,7 @@ class VarGP(object):
         self.output = {"m0": m0, "s0": s0}
         self.device, self.flags, self.batch = device, flags, int(batch)
         self._ctx = None
+        self._ctx_key = None
         self._stale = set()
         method_f = str(getattr(fwd_ode, "method", "")).lower()
         method_b = str(getattr(bwd_ode, "method", "")).lower()
@@ -40,23 +41,54 @@ class VarGP(object):
         self._method = method_f
 
     # ------------------------------------------------------------------------------------------
+    def _inputs(self):
+        """Everything the device context bakes in at creation, read from the objects NOW."""
+        single, d = self.model.single_dim, self.dim_d
+        m0, s0 = self.output["m0"], self.output["s0"]
+        lik = self.likelihood
+        sigma = np.array([[self.model.sigma]], dtype=float) if single else np.asarray(self.model.sigma, dtype=float)
+        op = getattr(lik, "operator", None)
+        return dict(sigma=sigma, theta=np.atleast_1d(np.asarray(self.model.theta, dtype=float)),
+                    m0=np.atleast_1d(np.asarray(m0, dtype=float)), s0=np.asarray(s0, dtype=float).reshape(d, d),
+                    obs_t=np.asarray(lik.times, dtype=np.int64), obs_y=np.asarray(lik.values, dtype=float),
+                    obs_noise=np.asarray(lik.noise, dtype=float).reshape(d, d),
+                    # the default operator is the identity: passing None keeps libvgpa_hip on its diagonal path
+                    obs_h=None if getattr(lik, "default_operator", False) else np.asarray(op, dtype=float).reshape(d, d))
+
+    @staticmethod
+    def _fingerprint(inputs):
+        """Cheap identity of the baked-in inputs: exact bytes for small arrays, (shape, sum, trace-like probes) beyond."""
+        key = []
+        for name in sorted(inputs):
+            a = inputs[name]
+            if a is None:
+                key.append((name, None))
+            elif a.size <= 1 << 16:
+                key.append((name, a.shape, a.tobytes()))
+            else:
+                flat = a.reshape(-1)
+                key.append((name, a.shape, float(flat.sum()), float(flat[0]), float(flat[-1]), float(flat[flat.size // 2])))
+        return tuple(key)
+
+    def invalidate(self):
+        """Drops the device context (and the state cached in it); the next call rebuilds it from the current
+        model / likelihood / prior values."""
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx, self._ctx_key, self._stale = None, None, set()
+
     def _context(self):
+        # theta, sigma, the observation noise and (m0, s0) are settable on the reference's objects
+        # (stochastic_process.py / likelihood.py setters): a context built from older values must not be reused.
+        inputs = self._inputs()
+        key = self._fingerprint(inputs)
+        if self._ctx is not None and key != self._ctx_key:
+            self.invalidate()
         if self._ctx is None:
-            single = self.model.single_dim
-            d = self.dim_d
-            m0, s0 = self.output["m0"], self.output["s0"]
-            lik = self.likelihood
-            e0 = float(np.asarray(self.kl0(m0, s0)))
-            sigma = np.array([[self.model.sigma]], dtype=float) if single else np.asarray(self.model.sigma, dtype=float)
-            self._ctx = Context(self.model._model_id, self._method, d, self.dim_n, float(self.fwd_ode.dt),
-                                sigma=sigma, theta=np.atleast_1d(np.asarray(self.model.theta, dtype=float)),
-                                m0=np.atleast_1d(np.asarray(m0, dtype=float)),
-                                s0=np.asarray(s0, dtype=float).reshape(d, d),
-                                obs_t=np.asarray(lik.times, dtype=np.int64),
-                                obs_y=np.asarray(lik.values, dtype=float),
-                                obs_noise=np.asarray(lik.noise, dtype=float).reshape(d, d),
-                                obs_h=np.asarray(lik.operator, dtype=float).reshape(d, d),
-                                e0=e0, device=self.device, flags=self.flags, batch=self.batch)
+            e0 = float(np.asarray(self.kl0(self.output["m0"], self.output["s0"])))
+            self._ctx = Context(self.model._model_id, self._method, self.dim_d, self.dim_n, float(self.fwd_ode.dt),
+                                e0=e0, device=self.device, flags=self.flags, batch=self.batch, **inputs)
+            self._ctx_key = key
         return self._ctx
 
     def initialization(self):
