@@ -5,6 +5,7 @@
 // row-sharded output) stays hand-written.
 #include <dlfcn.h>
 
+#include <map>
 #include <mutex>
 
 #include "vgpa_internal.h"
@@ -21,7 +22,8 @@ constexpr int kOpNone = 111, kOpTrans = 112;      // rocblas_operation_none / ro
 
 struct Api {
   void* so = nullptr;
-  void* handle = nullptr;
+  create_handle_t create = nullptr;
+  std::map<int, void*> handles;      // one rocBLAS handle per device (a handle is bound to the device current at creation)
   set_stream_t set_stream = nullptr;
   dgemm_t dgemm = nullptr;
   bool tried = false;
@@ -31,7 +33,7 @@ std::mutex g_mu;
 
 bool load_api() {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (g_api.tried) return g_api.handle != nullptr;
+  if (g_api.tried) return g_api.create != nullptr;
   g_api.tried = true;
   const char* names[] = {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"};
   for (const char* n : names) {
@@ -47,8 +49,21 @@ bool load_api() {
   g_api.set_stream = (set_stream_t)dlsym(g_api.so, "rocblas_set_stream");
   g_api.dgemm = (dgemm_t)dlsym(g_api.so, "rocblas_dgemm");
   if (!create || !g_api.set_stream || !g_api.dgemm) return false;
-  if (create(&g_api.handle) != 0) { g_api.handle = nullptr; return false; }
+  g_api.create = create;
   return true;
+}
+
+// the handle of the device that is current now (the entry points select the context's device before they get here)
+void* device_handle() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_api.handles.find(dev);
+  if (it != g_api.handles.end()) return it->second;
+  void* h = nullptr;
+  if (g_api.create(&h) != 0) h = nullptr;
+  g_api.handles[dev] = h;
+  return h;
 }
 
 }  // namespace
@@ -60,9 +75,11 @@ bool library_gemm_available() { return load_api(); }
 hipError_t library_gemm(bool transa, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
                         hipStream_t st) {
   if (!load_api()) return hipErrorNotSupported;
-  if (g_api.set_stream(g_api.handle, st) != 0) return hipErrorUnknown;
+  void* handle = device_handle();
+  if (!handle) return hipErrorNotSupported;
+  if (g_api.set_stream(handle, st) != 0) return hipErrorUnknown;
   const double one = 1.0, zero = 0.0;
-  const int rc = g_api.dgemm(g_api.handle, kOpNone, transa ? kOpTrans : kOpNone, N, M, K, &one, B, ldb, A, lda, &zero, C, ldc);
+  const int rc = g_api.dgemm(handle, kOpNone, transa ? kOpTrans : kOpNone, N, M, K, &one, B, ldb, A, lda, &zero, C, ldc);
   return rc == 0 ? hipSuccess : hipErrorUnknown;
 }
 

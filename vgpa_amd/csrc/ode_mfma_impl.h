@@ -57,6 +57,11 @@ __device__ long long g_clk[4];   // s_memtime / s_memrealtime at kernel start an
 #define VGPA_STAMP_ARG
 #define VGPA_STAMP_PASS
 #endif
+#ifdef VGPA_WPE            // ubench only: force the register budget of VGPA_WPE waves per SIMD
+#define VGPA_OCC __attribute__((amdgpu_waves_per_eu(VGPA_WPE, VGPA_WPE)))
+#else
+#define VGPA_OCC
+#endif
 constexpr int kMaxNB = 11;   // D <= 44: beyond that the backward kernel spills registers (generic path instead)
 
 // ---- dealing units to (wave, slot) -------------------------------------------------------------------------
@@ -434,7 +439,7 @@ __device__ __forceinline__ void store_a(double* __restrict__ buf, double* __rest
 
 // =================================================================================================================
 template <int METHOD, int NB, int NW>
-__global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
+__global__ void __launch_bounds__(64 * NW) VGPA_OCC k_fwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB, NW>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(64 * NW) k_fwd_mfma(OdeArgs a) {
 // kernel the dense path's loads and the sparse path's selects share registers, and the wait-count pass then puts an
 // s_waitcnt vmcnt(0) in front of the selects -- behind the prefetches the step has just issued.
 template <int METHOD, int NB, int NW, bool DENSEJ>
-__global__ void __launch_bounds__(64 * NW) k_bwd_mfma(OdeArgs a) {
+__global__ void __launch_bounds__(64 * NW) VGPA_OCC k_bwd_mfma(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB, NW>;
   constexpr int MAXU = g::MAXU, EPT = g::EPT;
