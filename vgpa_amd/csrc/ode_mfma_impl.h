@@ -36,73 +36,100 @@ namespace mfma {
 constexpr int kMaxNB = 11;       // D <= 44
 constexpr int kMaxPairNB = 10;   // two problems per workgroup fit the 160 KB of LDS up to D = 40
 constexpr int kNPW = 4;          // P waves (one per SIMD)
-constexpr int kNE = 256;         // E threads per problem (4 waves, one per SIMD)
+constexpr int kNE = 256;         // E threads of a single-problem workgroup (4 waves, one per SIMD); a paired workgroup gives
+                                 // each problem 128 (2 waves): 8 waves per workgroup either way = 256 VGPRs per wave
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Per-lane HBM accesses go through a wave-uniform base pointer + an UNSIGNED 32-bit byte offset: the instruction then
+// takes the base from SGPRs and the offset from one VGPR.  With 64-bit per-lane indices the compiler precomputes every
+// (item, row, array) address as a VGPR pair outside the time loop -- 30-60 registers that decide whether the kernel spills.
+__device__ __forceinline__ double ldg(const double* base, unsigned off8) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off8);
+}
+__device__ __forceinline__ void stg(double* base, unsigned off8, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off8) = v;
+}
+
+// Diagnostic build only (tools/ubench/ode_pe_stamp.hip): per-segment cycle sums of one P wave and one E wave of workgroup 0.
+// Never defined in the product build, so no stamp executes there.
+#ifdef VGPA_STAMPS
+__device__ long long g_stamp[4][8];
+#define VGPA_STAMP(role, i)                                                                   \
+  do {                                                                                        \
+    const long long t_ = clock64();                                                           \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamp[role][i] += t_ - stamp_prev_;     \
+    stamp_prev_ = t_;                                                                         \
+  } while (0)
+#define VGPA_STAMP_DECL long long stamp_prev_ = clock64()
+#else
+#define VGPA_STAMP(role, i) do {} while (0)
+#define VGPA_STAMP_DECL do {} while (0)
+#endif
 
 // ---- dealing MFMA units to (P wave, slot) -----------------------------------------------------------------------
 // A "unit" is one MFMA accumulator = four 4x4 output blocks: (I, J = 4q..4q+3) for the full 16-column groups, and the
 // left-over column blocks of several block-rows packed together (D = 40: 100 blocks = 25 units = 250 MFMAs per product).
 // Units are numbered group-major: NQ full column groups of NB units each, then NLEFT left-over units.  All units of a
 // group share one B fragment.  Every wave loads TWO B fragments per k-step and slot s uses the first one when s < S1 and
-// the second one otherwise -- a compile-time choice.  The greedy below gives each wave units of at most two groups.
+// the second one otherwise -- a compile-time choice, the same for all waves; every wave issues all MAXU slots (slots
+// without a unit multiply garbage into a trash word), so the product takes MAXU x KKE MFMAs on every SIMD and the deal
+// only has to minimise MAXU.  Per wave: the rest of the current group if it fits one of the two slot ranges (the smaller
+// one that takes it), the other range from the next group; else both ranges from the current group.
 struct WaveDeal { int uA, nA, gA, uB, nB, gB; };   // first unit / count / group of the A-range and of the B-range
 
 __host__ __device__ constexpr int deal_group_size(int nb, int nq, int nleft, int g) { return g < nq ? nb : (g == nq ? nleft : 0); }
 
-__host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int maxu, int nw, int want, bool* done) {
+__host__ __device__ constexpr WaveDeal deal_units(int nb, int nq, int nleft, int maxu, int s1, int nw, int want, bool* done) {
   const int ngroups = nq + (nleft ? 1 : 0);
-  const int s1 = maxu / 2, s2 = maxu - s1;
+  const int s2 = maxu - s1;
   int g = 0, off = 0;
-  int left = nb * nq + nleft;
   WaveDeal res{0, 0, 0, 0, 0, 0};
   for (int w = 0; w < nw; w++) {
-    WaveDeal d{0, 0, 0, 0, 0, 0};
-    int quota = (left + (nw - w) - 1) / (nw - w);
-    quota = quota < maxu ? quota : maxu;
     while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
-    if (g < ngroups && quota > 0) {
+    WaveDeal d{0, 0, 0, 0, 0, 0};
+    if (g < ngroups) {
       const int rem = deal_group_size(nb, nq, nleft, g) - off;
-      const int a = rem < quota ? rem : quota;
-      if (a <= s1 || a <= s2) {
-        const bool first_in_a = a <= s1;
+      if (rem > s1 && rem > s2) {               // both ranges from this group
+        const int na = rem < s1 ? rem : s1;
+        const int nbb = (rem - na) < s2 ? (rem - na) : s2;
+        d = WaveDeal{g * nb + off, na, g, g * nb + off + na, nbb, g};
+        off += na + nbb;
+      } else {                                  // the rest of the group in one range, the next group in the other
+        const bool in_a = (rem <= s1) && (s1 <= s2 || rem > s2);
         const int u_first = g * nb + off, g_first = g;
-        off += a;
+        off += rem;
         while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
-        int b = 0, u_second = 0, g_second = g_first;
-        if (g < ngroups && a < quota) {
-          int cap = first_in_a ? s2 : s1;
-          cap = cap < quota - a ? cap : quota - a;
+        int n2 = 0, u2 = 0, g2 = g_first;
+        if (g < ngroups) {
+          const int cap = in_a ? s2 : s1;
           const int rem2 = deal_group_size(nb, nq, nleft, g) - off;
-          b = rem2 < cap ? rem2 : cap;
-          u_second = g * nb + off; g_second = g;
-          off += b;
+          n2 = rem2 < cap ? rem2 : cap;
+          u2 = g * nb + off; g2 = g;
+          off += n2;
         }
-        if (first_in_a) d = WaveDeal{u_first, a, g_first, u_second, b, g_second};
-        else d = WaveDeal{u_second, b, g_second, u_first, a, g_first};
-      } else {
-        const int na = a < s1 ? a : s1;
-        d = WaveDeal{g * nb + off, na, g, g * nb + off + na, a - na, g};
-        off += a;
+        d = in_a ? WaveDeal{u_first, rem, g_first, u2, n2, g2} : WaveDeal{u2, n2, g2, u_first, rem, g_first};
       }
     }
-    left -= d.nA + d.nB;
     if (w == want) res = d;
   }
-  if (done) *done = (left == 0);
+  while (g < ngroups && off >= deal_group_size(nb, nq, nleft, g)) { g++; off = 0; }
+  if (done) *done = (g >= ngroups);
   return res;
 }
 
-__host__ __device__ constexpr bool deal_fits(int nb, int nq, int nleft, int maxu, int nw) {
+__host__ __device__ constexpr bool deal_fits(int nb, int nq, int nleft, int maxu, int s1, int nw) {
   bool ok = false;
-  (void)deal_units(nb, nq, nleft, maxu, nw, 0, &ok);
+  (void)deal_units(nb, nq, nleft, maxu, s1, nw, 0, &ok);
   return ok;
 }
 
-__host__ __device__ constexpr int deal_min_slots(int nb, int nq, int nleft, int nu, int nw) {
-  int m = (nu + nw - 1) / nw;
-  while (!deal_fits(nb, nq, nleft, m, nw)) m++;
-  return m;
+// smallest MAXU (and, for it, the most even split S1) for which the deal covers every unit; want_s1 selects the result
+__host__ __device__ constexpr int deal_pick(int nb, int nq, int nleft, int nu, int nw, bool want_s1) {
+  for (int m = (nu + nw - 1) / nw; m <= nu; m++)
+    for (int s1 = m / 2; s1 >= 0; s1--)
+      if (deal_fits(nb, nq, nleft, m, s1, nw)) return want_s1 ? s1 : m;
+  return want_s1 ? 0 : nu;
 }
 
 __host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
@@ -118,8 +145,8 @@ struct Geo {
   static constexpr int G = REM ? 4 / REM : 0;             // block-rows packed into one left-over unit
   static constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
   static constexpr int NU = NB * NQ + NLEFT;              // units (MFMA accumulators) per product
-  static constexpr int MAXU = deal_min_slots(NB, NQ, NLEFT, NU, kNPW);   // unit slots per P wave
-  static constexpr int S1 = MAXU / 2;                     // slots [0,S1) use B fragment 0, slots [S1,MAXU) fragment 1
+  static constexpr int MAXU = deal_pick(NB, NQ, NLEFT, NU, kNPW, false);   // unit slots per P wave
+  static constexpr int S1 = deal_pick(NB, NQ, NLEFT, NU, kNPW, true);      // slots [0,S1): B fragment 0, [S1,MAXU): fragment 1
   static constexpr int P = 4 * NB;                        // padded dimension
   // LDS operand layout ("k-pair interleaved"): element (k, c) of an operand matrix sits at (k >> 1) * LD + 2 c + (k & 1):
   // rows 2p and 2p+1 share a 16-byte unit.  Four consecutive row pairs feed TWO k-steps of the 4x4x4 instruction (lane
@@ -135,22 +162,30 @@ struct Geo {
   // W[r][c] row-major with LDW = 2 (mod 4) doubles: the transposed 16-byte read (W[c][2p], W[c][2p+1]) of consecutive c
   // touches all 64 banks once per 16 lanes; rows are 16-byte aligned.
   static constexpr int LDW = P + 2;
-  static constexpr int NIT = cdiv((P / 2) * P, kNE);      // row-pair items per E thread
-  // mat-vec partial sums on the E threads: forward lane = (column i, part of the row pairs), backward lane = (row pair,
-  // part of the columns)
-  static constexpr int NPARTF = cmin(kNE / P, RP);
-  static constexpr int RPP = cdiv(RP, NPARTF);
-  static constexpr int NPARTB = cmin(kNE / (P / 2), P);
-  static constexpr int KPP = cdiv(P, NPARTB);
+  static constexpr int NIT = cdiv((P / 2) * P, 64 * kNPW);   // 16-byte operand units per P lane (staging)
   // per-problem LDS regions (doubles)
   static constexpr int XS = RP * LDX;
   static constexpr int AS = RP * LDA;
-  static constexpr int WS = P * LDW + 64 * kNPW;          // + one trash double per P lane
+  static constexpr int WS = P * LDW + 64 * kNPW + 2 * kNE;   // + one trash double per P lane + one 16-byte unit per E thread
   static constexpr int XV = 4 * KKE + 4;                  // stage vector, padded like the operand rows
-  static constexpr int PV = cmax(NPARTF, NPARTB) * P;
+  static constexpr int PV = cmax(cmin(kNE / P, RP), cmin(kNE / (P / 2), P)) * P;   // partial mat-vec sums, sized for 256 E threads
   static constexpr int PROB = XS + 2 * AS + WS + XV + PV;
   static constexpr int SIGS = P * P;                      // Sigma / constant matrix jump in item layout
   static constexpr size_t lds_doubles(int nprob) { return (size_t)nprob * PROB + SIGS + 2 * kNE; }
+};
+
+// what depends on the number NE of E threads of a problem
+template <int NB, int NE>
+struct EGeo {
+  using g = Geo<NB>;
+  static constexpr int NIT = cdiv((g::P / 2) * g::P, NE);   // row-pair items per E thread
+  // mat-vec partial sums on the E threads: forward lane = (column i, part of the row pairs), backward lane = (row pair,
+  // part of the columns)
+  static constexpr int NPARTF = cmin(NE / g::P, g::RP);
+  static constexpr int RPP = cdiv(g::RP, NPARTF);
+  static constexpr int NPARTB = cmin(NE / (g::P / 2), g::P);
+  static constexpr int KPP = cdiv(g::P, NPARTB);
+  static_assert(NPARTF >= 1 && NPARTB >= 1, "too few E threads for this D");
 };
 
 template <int NB>
@@ -180,7 +215,7 @@ template <int NB>
 __device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
   using g = Geo<NB>;
   const int b = (lane >> 2) & 3, r4 = lane >> 4, c4 = lane & 3;
-  const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, kNPW, pw, nullptr);
+  const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, g::S1, kNPW, pw, nullptr);
   constexpr int rem = g::REM ? g::REM : 1;
   auto group_col = [&](int grp) { return (grp < g::NQ) ? (16 * grp + (lane & 15)) : (4 * (4 * g::NQ + b % rem) + c4); };
   T.colB0 = 2 * group_col(deal.gA);
@@ -213,7 +248,9 @@ __device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
 
 // One D^3 product on the matrix cores, W = Aop^T-layout x X, written row-major to the LDS buffer Wb.
 // LDAOP = leading dimension of the A-operand matrix (LDA, or LDX when the stage state itself is the operand).
-// Straight-line code: NKP k-pairs, fragments of pair kp+1 are loaded while the MFMAs of pair kp issue.
+// Straight-line code: NKP k-pairs, fragments of pair kp+1 are loaded while the MFMAs of pair kp issue.  (A hand-pinned
+// variant -- three buffers, all reads of pair kp+2 in one block in front of the MFMAs of pair kp -- was 10 % slower: nine
+// back-to-back ds_read_b128 keep the wave from issuing MFMAs for ~70 cycles; the compiler's interleaving is kept.)
 template <int NB, int LDAOP>
 __device__ __forceinline__ void product(const double* __restrict__ Aop, const double* __restrict__ X, double* __restrict__ Wb,
                                         const PTab<NB>& T, int lane) {
@@ -250,44 +287,156 @@ __device__ __forceinline__ void product(const double* __restrict__ Aop, const do
   for (int s = 0; s < MAXU; s++) Wb[T.offW[s]] = w[s];
 }
 
-// which LDS buffer a stage's matrix product / mat-vec reads its A operand from
+// Which LDS buffer a stage's matrix product / mat-vec reads its A operand from.  Two buffers per problem: R holds the
+// operand of the step's first stage.  While the P waves are in THAT product the E waves fill M -- the mid-point
+// 0.5 (A_k + A_{k+1}) (RK2, RK4) or A_{k+1} itself (Heun) -- and one product later, when nothing reads R any more, they
+// overwrite R with A_{k+1} for the step's last stage and the next step's first one.  Euler has one stage per step: its
+// operand alternates between R (even steps) and M (odd steps).  All of that happens beside a product, never between two.
 enum : int { OP_R = 0, OP_M = 1, OP_X = 2 };
 template <int METHOD, bool FWD>
-__host__ __device__ constexpr int stage_op(int j, bool matrix) {
+__host__ __device__ constexpr int stage_op(int j, bool matrix, int step) {
+  if (METHOD == VGPA_ODE_EULER) return (step & 1) ? OP_M : OP_R;
+  if (METHOD == VGPA_ODE_HEUN) return j == 0 ? OP_R : OP_M;
   if (METHOD == VGPA_ODE_RK2) return j == 0 ? ((FWD && matrix) ? OP_X : OP_R) : OP_M;   // Q2: S_k stands in for A_k
-  if (METHOD == VGPA_ODE_RK4) return (j == 1 || j == 2) ? OP_M : OP_R;
-  return OP_R;                                                                          // Euler, Heun
+  return (j == 1 || j == 2) ? OP_M : OP_R;                                              // RK4
 }
 template <int METHOD>
 __host__ __device__ constexpr int n_stages() { return METHOD == VGPA_ODE_EULER ? 1 : (METHOD == VGPA_ODE_RK4 ? 4 : 2); }
 
 template <int METHOD, bool FWD, int NB>
-__device__ __forceinline__ void p_product_stage(int j, const Lds<NB>& L, const PTab<NB>& T, int lane) {
+__device__ __forceinline__ void p_product_stage(int j, int step, const Lds<NB>& L, const PTab<NB>& T, int lane) {
   using g = Geo<NB>;
-  const int op = stage_op<METHOD, FWD>(j, true);
+  const int op = stage_op<METHOD, FWD>(j, true, step);
   if (op == OP_X) product<NB, g::LDX>(L.X, L.X, L.W, T, lane);
   else product<NB, g::LDA>(op == OP_M ? L.M : L.R, L.X, L.W, T, lane);
 }
 
-// The P role: products for problem A and problem B in alternating phases, one workgroup barrier per phase.
-template <int METHOD, bool FWD, int NB, int NPROB>
-__device__ __forceinline__ void p_role(int n_steps, bool has_b, const Lds<NB>& LA, const Lds<NB>& LB, int pw, int lane) {
+// ---- A(t): HBM -> registers -> LDS operand buffers, by the P waves -------------------------------------------------------
+// The k-pair interleaved operand layout keeps rows 2p and 2p+1 of the operand in one 16-byte unit per column.  A staging
+// item is such a unit: (sp, so) = rows 2sp, 2sp+1 of the operand at column so -- forward (operand = A^T) the entries
+// A[so][2sp], A[so][2sp+1] with the pair fastest over the 256 P lanes (whole rows of A per npair lanes: contiguous HBM
+// reads), backward (operand = A) A[2sp][so], A[2sp+1][so] with the column fastest.  Either way a 16-lane group stores 16
+// units with one conflict-free ds_write_b128.  The P waves own no Runge-Kutta state, so they have the registers to keep
+// A of the next grid point in flight for a whole step (per problem), and their matrix-core stream has the issue slots.
+template <int NB>
+struct STab {
+  static constexpr int NIT = Geo<NB>::NIT;
+  int lo[NIT];              // LDS offset of the unit inside R / M (lanes without an item: their trash unit behind W)
+  unsigned ga0[NIT], ga1[NIT];   // global BYTE offsets of its two entries
+};
+
+template <int NB, bool FWD>
+__device__ __forceinline__ void build_stab(int D, int tp, STab<NB>& T) {
+  using g = Geo<NB>;
+  const int npair = (D + 1) / 2;
+  // (lanes without an item use the trash unit of the E thread of the same index: garbage either way)
+#pragma unroll
+  for (int q = 0; q < g::NIT; q++) {
+    const int e = tp + q * 64 * kNPW;
+    const bool ok = e < npair * D;
+    const int sp = ok ? (FWD ? e % npair : e / D) : 0, so = ok ? (FWD ? e / npair : e - (e / D) * D) : 0;
+    T.lo[q] = ok ? sp * g::LDA + 2 * so : -1;
+    T.ga0[q] = 8u * (unsigned)(FWD ? so * D + 2 * sp : 2 * sp * D + so);
+    const bool two = ok && (2 * sp + 1 < D);
+    T.ga1[q] = two ? (FWD ? T.ga0[q] + 8u : T.ga0[q] + 8u * (unsigned)D) : T.ga0[q];
+  }
+}
+
+// A(t) for one step, HBM -> registers.  Nothing may depend on the loaded values here: they are consumed a step later, and a
+// select behind the load would put an s_waitcnt vmcnt in front of it -- the full HBM latency, inside a phase.  Lanes
+// without an item load element 0 (always valid; never stored).  When D is odd the second entry of the last pair repeats
+// the first one: it lands in operand row D, which only ever meets the zero rows / entries beyond D of the stage state.
+template <int NB>
+__device__ __forceinline__ void load_a(const double* __restrict__ A, const STab<NB>& T, d2_t (&a)[Geo<NB>::NIT]) {
+#pragma unroll
+  for (int q = 0; q < Geo<NB>::NIT; q++) {
+    a[q][0] = ldg(A, T.ga0[q]);
+    a[q][1] = ldg(A, T.ga1[q]);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void store_a(double* __restrict__ buf, double* __restrict__ trash, const STab<NB>& T,
+                                        const d2_t (&v)[Geo<NB>::NIT]) {
+#pragma unroll
+  for (int q = 0; q < Geo<NB>::NIT; q++) *reinterpret_cast<d2_t*>(T.lo[q] >= 0 ? buf + T.lo[q] : trash) = v[q];
+}
+
+// What follows the product of stage j of step `step` for one problem, done in the NEXT phase (beside the product of the
+// other problem, or while the single problem is in its element-wise phase): see stage_op.  `an` = A at the step's end point.
+template <int METHOD, bool FWD, int NB>
+__device__ __forceinline__ void p_stage_after(int j, int step, int n_steps, const double* __restrict__ A, int DD, int Np,
+                                              const Lds<NB>& L, const STab<NB>& T, d2_t (&an)[Geo<NB>::NIT], int tp) {
+  using g = Geo<NB>;
   constexpr int NS = n_stages<METHOD>();
+  constexpr int JSEC = NS > 1 ? 1 : 0;
+  double* trash = L.W + g::P * g::LDW + 64 * kNPW + 2 * tp;
+  if (j == 0) {
+    double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? L.R : L.M;     // Euler: the buffer the next step reads
+    if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) {
+      // R still holds what this lane stored a step ago: the start-point operand comes back from LDS
+      d2_t mid[g::NIT];
+#pragma unroll
+      for (int q = 0; q < g::NIT; q++) mid[q] = *reinterpret_cast<const d2_t*>(T.lo[q] >= 0 ? L.R + T.lo[q] : trash);
+#pragma unroll
+      for (int q = 0; q < g::NIT; q++) { mid[q][0] = 0.5 * (mid[q][0] + an[q][0]); mid[q][1] = 0.5 * (mid[q][1] + an[q][1]); }
+      store_a<NB>(dst, trash, T, mid);
+    } else {
+      store_a<NB>(dst, trash, T, an);
+    }
+  }
+  if (j == JSEC) {
+    if (NS > 1) store_a<NB>(L.R, trash, T, an);
+    if (step + 2 <= n_steps) load_a<NB>(A + (size_t)(FWD ? step + 2 : Np - 1 - (step + 2)) * DD, T, an);
+  }
+}
+
+// The P role: products for problem A and problem B in alternating phases, one workgroup barrier per phase; the operand
+// staging of one problem rides beside the product of the other.
+template <int METHOD, bool FWD, int NB, int NPROB>
+__device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b, const Lds<NB>& LA, const Lds<NB>& LB, int pw,
+                                       int lane) {
+  constexpr int NS = n_stages<METHOD>();
+  using g = Geo<NB>;
+  const int Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
+  const int tp = 64 * pw + lane;
   PTab<NB> T;
   build_ptab<NB>(pw, lane, T);
+  STab<NB> S;
+  build_stab<NB, FWD>(a.D, tp, S);
+  const double* Aa = a.A + (size_t)prob_a * a.strideA;
+  const double* Ab = Aa + (has_b ? a.strideA : 0);
+  d2_t ana[g::NIT], anb[g::NIT];
   __syncthreads();                       // LDS zero-filled
-  __syncthreads();                       // E prologue (X, R, xv, Sigma) published
+  {  // operands of the first step: R <- A at the first grid point of the sweep; A at the second one stays in flight
+    const size_t t0 = FWD ? 0 : (size_t)(Np - 1), t1 = FWD ? 1 : (size_t)(Np - 2);
+    load_a<NB>(Aa + t0 * DD, S, ana);
+    if (NPROB == 2 && has_b) load_a<NB>(Ab + t0 * DD, S, anb);
+    store_a<NB>(LA.R, LA.W + g::P * g::LDW + 64 * kNPW + 2 * tp, S, ana);
+    if (NPROB == 2 && has_b) store_a<NB>(LB.R, LB.W + g::P * g::LDW + 64 * kNPW + 2 * tp, S, anb);
+    if (n_steps >= 1) {
+      load_a<NB>(Aa + t1 * DD, S, ana);
+      if (NPROB == 2 && has_b) load_a<NB>(Ab + t1 * DD, S, anb);
+    }
+  }
+  __syncthreads();                       // prologue (X, R, xv, Sigma) published
+  VGPA_STAMP_DECL;
   for (int k = 0; k < n_steps; k++) {
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-      p_product_stage<METHOD, FWD, NB>(j, LA, T, lane);
-      __syncthreads();
-      if (NPROB == 2) {
-        if (has_b) p_product_stage<METHOD, FWD, NB>(j, LB, T, lane);
-        __syncthreads();
-      } else {
-        __syncthreads();                 // the E phase of the single problem
+      if (NPROB == 2 && has_b) {         // B's chores for its previous product
+        if (j > 0) p_stage_after<METHOD, FWD, NB>(j - 1, k, n_steps, Ab, DD, Np, LB, S, anb, tp);
+        else if (k > 0) p_stage_after<METHOD, FWD, NB>(NS - 1, k - 1, n_steps, Ab, DD, Np, LB, S, anb, tp);
       }
+      p_product_stage<METHOD, FWD, NB>(j, k, LA, T, lane);
+      VGPA_STAMP(pw == 0 ? 0 : 3, 0);    // product A
+      __syncthreads();
+      VGPA_STAMP(pw == 0 ? 0 : 3, 1);    // barrier
+      p_stage_after<METHOD, FWD, NB>(j, k, n_steps, Aa, DD, Np, LA, S, ana, tp);
+      if (NPROB == 2 && has_b) p_product_stage<METHOD, FWD, NB>(j, k, LB, T, lane);
+      VGPA_STAMP(pw == 0 ? 0 : 3, 2);    // product B (or the idle phase of a single problem)
+      __syncthreads();
+      VGPA_STAMP(pw == 0 ? 0 : 3, 3);    // barrier
     }
   }
   if (NPROB == 2) __syncthreads();       // problem B's last element-wise phase
@@ -303,153 +452,137 @@ __device__ __forceinline__ void settle(d2_t& v) { asm volatile("" : "+v"(v)); }
 // A row-pair item (p, c) = elements (2p, c) and (2p+1, c) of the D x D state; items are dealt with c fastest over the
 // E threads, so a 16-lane group publishes 16 consecutive 16-byte units with one conflict-free ds_write_b128 and its W
 // reads are 16 consecutive doubles of one row.
-template <int NB>
+template <int NB, int NE>
 struct ETab {
-  static constexpr int NIT = Geo<NB>::NIT;
+  static constexpr int NIT = EGeo<NB, NE>::NIT;
   int offX[NIT];    // p * LDX + 2 c
   int offW[NIT];    // (2p) * LDW + c           (row 2p+1: + LDW)
   int offWt[NIT];   // c * LDW + 2p             (16-byte unit W[c][2p], W[c][2p+1])
-  int gofs[NIT];    // (2p) * D + c             (row 2p+1: + D)
-  int lo[NIT];      // staging: LDS offset of the 16-byte operand unit inside R / M
-  int ga0[NIT], ga1[NIT];   // staging: global offsets of its two entries
-  unsigned mask;    // bit q: item q exists; bit 8+q: its second row exists; bit 16+q: staging item; bit 24+q: its second entry
+  unsigned gofs[NIT];   // 8 ((2p) * D + c): BYTE offset inside a D x D matrix (row 2p+1: + 8 D)
+  unsigned mask;    // bit q: item q exists; bit 8+q: its second row exists
 };
 
-template <int NB, bool FWD>
-__device__ __forceinline__ void build_etab(int D, int te, ETab<NB>& T) {
+template <int NB, int NE>
+__device__ __forceinline__ void build_etab(int D, int te, ETab<NB, NE>& T) {
   using g = Geo<NB>;
-  static_assert(g::NIT <= 8, "mask layout");
+  constexpr int NIT = EGeo<NB, NE>::NIT;
+  static_assert(NIT <= 8, "mask layout");
   const int npair = (D + 1) / 2;
+  // LDS offsets of threads without an item point at the thread's private 16-byte trash unit behind W (offsets relative
+  // to X for offX, to W for offW / offWt, to R / M for lo), so the element-wise stage and the staging need no branches.
+  const int trashW = g::P * g::LDW + 64 * kNPW + 2 * te;
+  const int trashX = g::XS + 2 * g::AS + trashW;           // X + trashX == W + trashW
   T.mask = 0u;
 #pragma unroll
-  for (int q = 0; q < g::NIT; q++) {
-    const int e = te + q * kNE;
+  for (int q = 0; q < NIT; q++) {
+    const int e = te + q * NE;
     const bool ok = e < npair * D;
     const int p = ok ? e / D : 0, c = ok ? e - p * D : 0;
-    T.offX[q] = p * g::LDX + 2 * c;
+    T.offX[q] = ok ? p * g::LDX + 2 * c : trashX;
     T.offW[q] = 2 * p * g::LDW + c;
     T.offWt[q] = c * g::LDW + 2 * p;
-    T.gofs[q] = 2 * p * D + c;
+    T.gofs[q] = 8u * (unsigned)(2 * p * D + c);
     if (ok) T.mask |= 1u << q;
     if (ok && 2 * p + 1 < D) T.mask |= 1u << (8 + q);
-    // staging item (sp, so) = rows 2sp, 2sp+1 of the operand at column so: forward (operand = A^T) the entries
-    // A[so][2sp], A[so][2sp+1] with the pair fastest over the lanes (whole rows of A per npair lanes), backward
-    // (operand = A) A[2sp][so], A[2sp+1][so] with the column fastest -- the same decomposition as the state items.
-    const int sp = FWD ? (ok ? e % npair : 0) : p, so = FWD ? (ok ? e / npair : 0) : c;
-    T.lo[q] = sp * g::LDA + 2 * so;
-    T.ga0[q] = FWD ? so * D + 2 * sp : 2 * sp * D + so;
-    const bool two = ok && (2 * sp + 1 < D);
-    T.ga1[q] = two ? (FWD ? T.ga0[q] + 1 : T.ga0[q] + D) : T.ga0[q];
-    if (ok) T.mask |= 1u << (16 + q);
-    if (two) T.mask |= 1u << (24 + q);
   }
 }
 
-template <int NB>
-__device__ __forceinline__ void load_a(const double* __restrict__ A, const ETab<NB>& T, d2_t (&a)[Geo<NB>::NIT]) {
-#pragma unroll
-  for (int q = 0; q < Geo<NB>::NIT; q++) {
-    // (offsets of lanes without an item are 0: always valid; their value is never stored.  The second entry of the last
-    //  pair when D is odd is a zero: that operand row only meets zeros.)
-    a[q][0] = A[T.ga0[q]];
-    const double second = A[T.ga1[q]];
-    a[q][1] = ((T.mask >> (24 + q)) & 1u) ? second : 0.0;
-  }
-}
-
-// After the product of a step's first stage: M <- mid-point of (R, next), R <- next.  R still holds what this thread
-// stored a step ago, so the previous operand comes back from LDS instead of living in registers for a whole step.
-template <int METHOD, int NB>
-__device__ __forceinline__ void stage_operands(const Lds<NB>& L, const ETab<NB>& T, const d2_t (&an)[Geo<NB>::NIT]) {
-#pragma unroll
-  for (int q = 0; q < Geo<NB>::NIT; q++) {
-    if ((T.mask >> (16 + q)) & 1u) {
-      if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) {
-        const d2_t prev = *reinterpret_cast<const d2_t*>(L.R + T.lo[q]);
-        d2_t mid;
-        mid[0] = 0.5 * (prev[0] + an[q][0]); mid[1] = 0.5 * (prev[1] + an[q][1]);
-        *reinterpret_cast<d2_t*>(L.M + T.lo[q]) = mid;
-      }
-      *reinterpret_cast<d2_t*>(L.R + T.lo[q]) = an[q];
-    }
-  }
-}
-
-// partial mat-vec sums of this problem's stage vector, on the E threads while the P waves are in the product
-template <int NB, bool FWD>
+// partial mat-vec sums of this problem's stage vector, on the E threads while the P waves are in the product.
+// Branch-free and with affine addresses (one base register + immediate offsets): threads beyond the last part redo part
+// 0 and drop the result into their trash unit; a part that runs past the last row pair / column reads whatever follows in
+// LDS (the next operand rows: finite numbers) against the zero entries of the stage vector beyond D.
+template <int NB, int NE, bool FWD>
 __device__ __forceinline__ void matvec_partials(const double* __restrict__ Aop, const Lds<NB>& L, int te) {
   using g = Geo<NB>;
+  using eg = EGeo<NB, NE>;
+  double* trash = L.W + g::P * g::LDW + 64 * kNPW + 2 * te;
   if (FWD) {          // sum_k Aop[k][i] v[k]: lane = (i, part of the row pairs)
-    const int part = te / g::P, i = te - part * g::P;
-    if (part < g::NPARTF) {
-      double s = 0.0;
+    constexpr int NP = cmin(eg::NPARTF, cdiv(g::RP, eg::RPP));
+    static_assert(2 * NP * eg::RPP <= g::XV, "stage vector padding");
+    const int part0 = te / g::P, i = te - part0 * g::P;
+    const bool act = part0 < NP;
+    const int part = act ? part0 : 0;
+    const double* pa = Aop + part * eg::RPP * g::LDA + 2 * i;
+    const double* pv = L.xv + 2 * part * eg::RPP;
+    d2_t av[eg::RPP], xk[eg::RPP];
 #pragma unroll
-      for (int r = 0; r < g::RPP; r++) {
-        const int rp = part * g::RPP + r;
-        if (rp < g::RP) {
-          const d2_t av = *reinterpret_cast<const d2_t*>(Aop + rp * g::LDA + 2 * i);
-          const d2_t xk = *reinterpret_cast<const d2_t*>(L.xv + 2 * rp);
-          s = __builtin_fma(av[0], xk[0], s);
-          s = __builtin_fma(av[1], xk[1], s);
-        }
-      }
-      L.pv[part * g::P + i] = s;
+    for (int r = 0; r < eg::RPP; r++) {
+      av[r] = *reinterpret_cast<const d2_t*>(pa + r * g::LDA);
+      xk[r] = *reinterpret_cast<const d2_t*>(pv + 2 * r);
     }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < eg::RPP; r++) {
+      s = __builtin_fma(av[r][0], xk[r][0], s);
+      s = __builtin_fma(av[r][1], xk[r][1], s);
+    }
+    *(act ? L.pv + part * g::P + i : trash) = s;
   } else {            // sum_k Aop[i][k] v[k]: lane = (row pair, part of the columns); one read feeds both rows
     constexpr int HP = g::P / 2;
-    const int part = te / HP, ip = te - part * HP;
-    if (part < g::NPARTB) {
-      double s0 = 0.0, s1 = 0.0;
+    constexpr int NP = cmin(eg::NPARTB, cdiv(g::P, eg::KPP));
+    static_assert(NP * eg::KPP <= g::XV, "stage vector padding");
+    const int part0 = te / HP, ip = te - part0 * HP;
+    const bool act = part0 < NP;
+    const int part = act ? part0 : 0;
+    const double* pa = Aop + ip * g::LDA + 2 * part * eg::KPP;
+    const double* pv = L.xv + part * eg::KPP;
+    d2_t av[eg::KPP];
+    double xk[eg::KPP];
 #pragma unroll
-      for (int kk = 0; kk < g::KPP; kk++) {
-        const int k = part * g::KPP + kk;
-        if (k < g::P) {
-          const d2_t av = *reinterpret_cast<const d2_t*>(Aop + ip * g::LDA + 2 * k);
-          const double xk = L.xv[k];
-          s0 = __builtin_fma(av[0], xk, s0);
-          s1 = __builtin_fma(av[1], xk, s1);
-        }
-      }
-      d2_t o; o[0] = s0; o[1] = s1;
-      *reinterpret_cast<d2_t*>(L.pv + part * g::P + 2 * ip) = o;
+    for (int kk = 0; kk < eg::KPP; kk++) {
+      av[kk] = *reinterpret_cast<const d2_t*>(pa + 2 * kk);
+      xk[kk] = pv[kk];
     }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < eg::KPP; kk++) {
+      s0 = __builtin_fma(av[kk][0], xk[kk], s0);
+      s1 = __builtin_fma(av[kk][1], xk[kk], s1);
+    }
+    d2_t o; o[0] = s0; o[1] = s1;
+    *reinterpret_cast<d2_t*>(act ? L.pv + part * g::P + 2 * ip : trash) = o;
   }
 }
 
-template <int NB, bool FWD>
+template <int NB, int NE, bool FWD>
 __device__ __forceinline__ double matvec_sum(const Lds<NB>& L, int i) {
   using g = Geo<NB>;
-  constexpr int NP = FWD ? cmin(g::NPARTF, cdiv(g::RP, g::RPP)) : cmin(g::NPARTB, cdiv(g::P, g::KPP));   // parts holding a sum
+  using eg = EGeo<NB, NE>;
+  constexpr int NP = FWD ? cmin(eg::NPARTF, cdiv(g::RP, eg::RPP)) : cmin(eg::NPARTB, cdiv(g::P, eg::KPP));   // parts holding a sum
   double s = L.pv[i];
 #pragma unroll
   for (int q = 1; q < NP; q++) s += L.pv[q * g::P + i];
   return s;
 }
 
-// Everything one E group (256 threads) needs to integrate one problem.  has == false: the group only keeps the barrier
+// Everything one E group (NE threads) needs to integrate one problem.  has == false: the group only keeps the barrier
 // count (odd batch: the last workgroup of a paired launch carries one problem).
-template <int METHOD, bool FWD, int NB, bool DENSEJ>
+template <int METHOD, bool FWD, int NB, int NE, bool DENSEJ>
 __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, bool leads, bool trails, const Lds<NB>& L,
                                        double* __restrict__ SIG, bool writes_sig, int te) {
   using g = Geo<NB>;
-  constexpr int NIT = g::NIT, NS = n_stages<METHOD>();
+  constexpr int NIT = EGeo<NB, NE>::NIT, NS = n_stages<METHOD>();
   const int D = a.D, DD = D * D, Np = a.Np;
   const double dt = a.dt, h = 0.5 * a.dt;
   const int n_steps = Np - 1;
+  const unsigned D8 = 8u * (unsigned)D, te8 = 8u * (unsigned)te;
   if (!has) {
     const int nbar = 2 + 2 * NS * n_steps + 1;
     for (int i = 0; i < nbar; i++) __syncthreads();
     return;
   }
-  ETab<NB> T;
-  build_etab<NB, FWD>(D, te, T);
+  // The E waves issue few instructions, all on the critical path of their problem; the P wave of the same SIMD always has
+  // an MFMA ready.  Without priority the E waves' fp64 VALU work waits for the matrix pipe until the product is over.
+  __builtin_amdgcn_s_setprio(3);
+  ETab<NB, NE> T;
+  build_etab<NB, NE>(D, te, T);
   const bool vl = te < D;                                  // this thread carries entry `te` of the vector recursion
-  const double* A = a.A + (size_t)prob * a.strideA;
   auto item = [&](int q) { return ((T.mask >> q) & 1u) != 0u; };
   auto row2 = [&](int q) { return ((T.mask >> (8 + q)) & 1u) != 0u; };
   auto opbuf = [&](int op) -> const double* { return op == OP_M ? L.M : L.R; };
+  constexpr double sixth = 1.0 / 6.0;
 
-  d2_t xk[NIT], acc1[NIT], acc2[NIT], an[NIT];
+  d2_t xk[NIT], acc1[NIT], acc2[NIT];
   double vk = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;           // vector entry and its RK slopes
 #pragma unroll
   for (int q = 0; q < NIT; q++) { xk[q] = d2_t{0.0, 0.0}; acc1[q] = acc2[q] = d2_t{0.0, 0.0}; }
@@ -463,67 +596,95 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
       if (item(q)) {
-        xk[q][0] = a.S0[T.gofs[q]];
-        xk[q][1] = row2(q) ? a.S0[T.gofs[q] + D] : 0.0;
-        st[T.gofs[q]] = xk[q][0];
-        if (row2(q)) st[T.gofs[q] + D] = xk[q][1];
+        xk[q][0] = ldg(a.S0, T.gofs[q]);
+        xk[q][1] = row2(q) ? ldg(a.S0, T.gofs[q] + D8) : 0.0;
+        stg(st, T.gofs[q], xk[q][0]);
+        if (row2(q)) stg(st, T.gofs[q] + D8, xk[q][1]);
         *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xk[q];
         if (writes_sig) {
           d2_t sg;
-          sg[0] = a.Sigma[T.gofs[q]]; sg[1] = row2(q) ? a.Sigma[T.gofs[q] + D] : 0.0;
-          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * kNE)) = sg;
+          sg[0] = ldg(a.Sigma, T.gofs[q]); sg[1] = row2(q) ? ldg(a.Sigma, T.gofs[q] + D8) : 0.0;
+          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = sg;
         }
       }
     }
-    if (vl) { vk = a.m0[te]; mt[te] = vk; L.xv[te] = vk; }
-    load_a<NB>(A, T, an);
-#pragma unroll
-    for (int q = 0; q < NIT; q++)
-      if ((T.mask >> (16 + q)) & 1u) *reinterpret_cast<d2_t*>(L.R + T.lo[q]) = an[q];
-    if (Np > 1) load_a<NB>(A + DD, T, an);
-    double b0 = vl ? bb[te] : 0.0;
-    double b1 = (vl && Np > 1) ? bb[D + te] : 0.0;
+    if (vl) { vk = ldg(a.m0, te8); stg(mt, te8, vk); L.xv[te] = vk; }
+    double b0 = vl ? ldg(bb, te8) : 0.0;
+    double b1 = (vl && Np > 1) ? ldg(bb + D, te8) : 0.0;
 #pragma unroll
     for (int q = 0; q < NIT; q++) settle(xk[q]);
     settle(b0); settle(b1); settle(vk);
     __syncthreads();                                       // prologue published
     if (leads) __syncthreads();
 
+    VGPA_STAMP_DECL;
+    const int srole = (te < 64) ? (leads ? 2 : 1) : 3;
+    (void)srole;
     for (int k = 0; k < n_steps; k++) {
-      const double b2 = (vl && k + 2 < Np) ? bb[(size_t)(k + 2) * D + te] : 0.0;     // for the next step
+      const double b2 = (vl && k + 2 < Np) ? ldg(bb + (size_t)(k + 2) * D, te8) : 0.0;     // for the next step
       const double bmid = 0.5 * (b0 + b1);
 #pragma unroll
       for (int j = 0; j < NS; j++) {
-        matvec_partials<NB, true>(opbuf(stage_op<METHOD, true>(j, false)), L, te);
-        __syncthreads();
-        // ---- element-wise stage j (the P waves are busy with the other problem)
-        const bool last = (j == NS - 1);
-        double vs = 0.0;
-        if (vl) vs = matvec_sum<NB, true>(L, te);
+        matvec_partials<NB, NE, true>(opbuf(stage_op<METHOD, true>(j, false, k)), L, te);
+        // chores beside the product of this problem: HBM stores of the previous step, operands of the coming stages
+        if (j == 0) {
+          if (k > 0) {       // S_k, m_k -> HBM
+            double* so = st + (size_t)k * DD;
 #pragma unroll
-        for (int q = 0; q < NIT; q++) {
-          if (item(q)) {
-            const double w0 = L.W[T.offW[q]], w1 = L.W[T.offW[q] + g::LDW];
-            const d2_t wt = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
-            const d2_t sg = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * kNE));
-            d2_t f, xn;
-            f[0] = (-w0 - wt[0]) + sg[0]; f[1] = (-w1 - wt[1]) + sg[1];
-            if (METHOD == VGPA_ODE_EULER) {
-              xk[q] = xk[q] + f * dt; xn = xk[q];
-            } else if (METHOD == VGPA_ODE_HEUN) {
-              if (j == 0) { acc1[q] = f; xn = xk[q] + f * dt; }
-              else { xk[q] = xk[q] + h * (acc1[q] + f); xn = xk[q]; }
-            } else if (METHOD == VGPA_ODE_RK2) {
-              if (j == 0) xn = xk[q] + h * f;
-              else { xk[q] = xk[q] + dt * f; xn = xk[q]; }
-            } else {
-              if (j == 0) { acc1[q] = f; xn = xk[q] + h * f; }
-              else if (j == 1) { acc2[q] = f; xn = xk[q] + h * f; }
-              else if (j == 2) { acc2[q] = acc2[q] + f; xn = xk[q] + dt * f; }
-              else { xk[q] = xk[q] + dt * (acc1[q] + 2.0 * acc2[q] + f) / 6.0; xn = xk[q]; }
+            for (int q = 0; q < NIT; q++) {
+              if (item(q)) {
+                stg(so, T.gofs[q], xk[q][0]);
+                if (row2(q)) stg(so, T.gofs[q] + D8, xk[q][1]);
+              }
             }
-            *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
+            if (vl) stg(mt + (size_t)k * D, te8, vk);
           }
+        }
+        VGPA_STAMP(srole, 0);            // mat-vec + chores
+        __syncthreads();
+        VGPA_STAMP(srole, 1);            // barrier (the product of this problem)
+        // ---- element-wise stage j (the P waves are busy with the other problem)
+        double vs = 0.0;
+        if (vl) vs = matvec_sum<NB, NE, true>(L, te);
+        // In batches of up to four items: every LDS read of the batch first, then the arithmetic, then the publish.  No
+        // branches (threads without an item read element (0, 0) and publish into their trash unit); one LDS round trip
+        // per batch; the scheduling barrier keeps the reads of the next batch (and their registers) behind this one.
+#pragma unroll
+        for (int q0 = 0; q0 < NIT; q0 += 4) {
+          d2_t wv[4], wt[4], sg[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < NIT) {
+              wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
+              wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
+              sg[u] = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * NE));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < NIT) {
+              d2_t xn;
+              const d2_t f = (-wv[u] - wt[u]) + sg[u];
+              if (METHOD == VGPA_ODE_EULER) {
+                xk[q] = xk[q] + f * dt; xn = xk[q];
+              } else if (METHOD == VGPA_ODE_HEUN) {
+                if (j == 0) { acc1[q] = f; xn = xk[q] + f * dt; }
+                else { xk[q] = xk[q] + h * (acc1[q] + f); xn = xk[q]; }
+              } else if (METHOD == VGPA_ODE_RK2) {
+                if (j == 0) xn = xk[q] + h * f;
+                else { xk[q] = xk[q] + dt * f; xn = xk[q]; }
+              } else {
+                if (j == 0) { acc1[q] = f; xn = xk[q] + h * f; }
+                else if (j == 1) { acc2[q] = f; xn = xk[q] + h * f; }
+                else if (j == 2) { acc2[q] = acc2[q] + f; xn = xk[q] + dt * f; }
+                else { xk[q] = xk[q] + (dt * (acc1[q] + 2.0 * acc2[q] + f)) * sixth; xn = xk[q]; }
+              }
+              *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
+            }
+          }
+          if (q0 + 4 < NIT) __builtin_amdgcn_sched_barrier(0);
         }
         if (vl) {
           double vn;
@@ -538,28 +699,26 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
             if (j == 0) { v1 = -vs + b0; vn = vk + h * v1; }
             else if (j == 1) { v2 = -vs + bmid; vn = vk + h * v2; }
             else if (j == 2) { v3 = -vs + bmid; vn = vk + dt * v3; }
-            else { vk = vk + dt * (v1 + 2.0 * (v2 + v3) + (-vs + b1)) / 6.0; vn = vk; }
+            else { vk = vk + (dt * (v1 + 2.0 * (v2 + v3) + (-vs + b1))) * sixth; vn = vk; }
           }
           L.xv[te] = vn;
         }
-        if (j == 0) {        // R is free once the first product of the step is over: stage the operands of the rest
-          stage_operands<METHOD, NB>(L, T, an);
-          if (k + 2 < Np) load_a<NB>(A + (size_t)(k + 2) * DD, T, an);
-        }
-        if (last) {          // S_{k+1}, m_{k+1} -> HBM
-          double* so = st + (size_t)(k + 1) * DD;
-#pragma unroll
-          for (int q = 0; q < NIT; q++) {
-            if (item(q)) {
-              so[T.gofs[q]] = xk[q][0];
-              if (row2(q)) so[T.gofs[q] + D] = xk[q][1];
-            }
-          }
-          if (vl) mt[(size_t)(k + 1) * D + te] = vk;
-        }
+        VGPA_STAMP(srole, 2);            // element-wise stage
         __syncthreads();
+        VGPA_STAMP(srole, 4);            // barrier
       }
       b0 = b1; b1 = b2;
+    }
+    if (n_steps > 0) {       // S, m of the last grid point
+      double* so = st + (size_t)n_steps * DD;
+#pragma unroll
+      for (int q = 0; q < NIT; q++) {
+        if (item(q)) {
+          stg(so, T.gofs[q], xk[q][0]);
+          if (row2(q)) stg(so, T.gofs[q] + D8, xk[q][1]);
+        }
+      }
+      if (vl) stg(mt + (size_t)n_steps * D, te8, vk);
     }
   } else {
     // ------------------------------------------------------------------------------------------ backward: (lam, Psi)
@@ -573,32 +732,28 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
     for (int q = 0; q < NIT; q++) {
       gC[q] = gN[q] = d2_t{0.0, 0.0};
       if (item(q)) {
-        const size_t o1 = (size_t)(Np - 1) * DD + T.gofs[q];
-        gC[q][0] = gs[o1]; gC[q][1] = row2(q) ? gs[o1 + D] : 0.0;
-        if (Np > 1) { gN[q][0] = gs[o1 - DD]; gN[q][1] = row2(q) ? gs[o1 - DD + D] : 0.0; }
-        psi[o1] = 0.0;
-        if (row2(q)) psi[o1 + D] = 0.0;
+        const double* g1p = gs + (size_t)(Np - 1) * DD;
+        double* p1p = psi + (size_t)(Np - 1) * DD;
+        gC[q][0] = ldg(g1p, T.gofs[q]); gC[q][1] = row2(q) ? ldg(g1p, T.gofs[q] + D8) : 0.0;
+        if (Np > 1) { gN[q][0] = ldg(g1p - DD, T.gofs[q]); gN[q][1] = row2(q) ? ldg(g1p - DD, T.gofs[q] + D8) : 0.0; }
+        stg(p1p, T.gofs[q], 0.0);
+        if (row2(q)) stg(p1p, T.gofs[q] + D8, 0.0);
         if (writes_sig && !DENSEJ) {
           d2_t js{0.0, 0.0};
-          if (a.js_const) { js[0] = a.js_const[T.gofs[q]]; js[1] = row2(q) ? a.js_const[T.gofs[q] + D] : 0.0; }
-          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * kNE)) = js;
+          if (a.js_const) { js[0] = ldg(a.js_const, T.gofs[q]); js[1] = row2(q) ? ldg(a.js_const, T.gofs[q] + D8) : 0.0; }
+          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = js;
         }
       }
     }
-    if (vl) lam[(size_t)(Np - 1) * D + te] = 0.0;
-    load_a<NB>(A + (size_t)(Np - 1) * DD, T, an);
-#pragma unroll
-    for (int q = 0; q < NIT; q++)
-      if ((T.mask >> (16 + q)) & 1u) *reinterpret_cast<d2_t*>(L.R + T.lo[q]) = an[q];
-    if (Np > 1) load_a<NB>(A + (size_t)(Np - 2) * DD, T, an);
+    if (vl) stg(lam + (size_t)(Np - 1) * D, te8, 0.0);
     // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
-    double g0 = vl ? gm[(size_t)(Np - 1) * D + te] : 0.0;
-    double g1 = (vl && Np > 1) ? gm[(size_t)(Np - 2) * D + te] : 0.0;
+    double g0 = vl ? ldg(gm + (size_t)(Np - 1) * D, te8) : 0.0;
+    double g1 = (vl && Np > 1) ? ldg(gm + (size_t)(Np - 2) * D, te8) : 0.0;
     int n_obs_cur = (sparse && Np > 1) ? a.obs_idx[Np - 2] : -1;
     double jm = 0.0;
     if (Np > 1) {
-      if (DENSEJ) { if (vl) jm = a.jm_dense[((size_t)prob * Np + (Np - 2)) * D + te]; }
-      else if (vl && n_obs_cur >= 0) jm = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_cur) * D + te];
+      if (DENSEJ) { if (vl) jm = ldg(a.jm_dense + ((size_t)prob * Np + (Np - 2)) * D, te8); }
+      else if (vl && n_obs_cur >= 0) jm = ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs_cur) * D, te8);
     }
 #pragma unroll
     for (int q = 0; q < NIT; q++) { settle(gC[q]); settle(gN[q]); }
@@ -607,56 +762,84 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
     if (leads) __syncthreads();
 
     for (int t = Np - 1; t > 0; t--) {
-      const double g2 = (vl && t >= 2) ? gm[(size_t)(t - 2) * D + te] : 0.0;          // for the next step
+      const double g2 = (vl && t >= 2) ? ldg(gm + (size_t)(t - 2) * D, te8) : 0.0;          // for the next step
       const int n_obs_next = (sparse && t >= 2) ? a.obs_idx[t - 2] : -1;
       double jm_next = 0.0;
       if (t >= 2) {
-        if (DENSEJ) { if (vl) jm_next = a.jm_dense[((size_t)prob * Np + (t - 2)) * D + te]; }
-        else if (vl && n_obs_next >= 0) jm_next = a.jm_sparse[((size_t)prob * a.n_obs + n_obs_next) * D + te];
+        if (DENSEJ) { if (vl) jm_next = ldg(a.jm_dense + ((size_t)prob * Np + (t - 2)) * D, te8); }
+        else if (vl && n_obs_next >= 0) jm_next = ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs_next) * D, te8);
       }
       const double gmid = 0.5 * (g1 + g0);
 #pragma unroll
       for (int j = 0; j < NS; j++) {
-        matvec_partials<NB, false>(opbuf(stage_op<METHOD, false>(j, false)), L, te);
+        matvec_partials<NB, NE, false>(opbuf(stage_op<METHOD, false>(j, false, Np - 1 - t)), L, te);
+        if (j == 0) {
+          if (t < Np - 1) {  // Psi_t, lam_t -> HBM; G_{t-1} for the step's end point
+            double* po = psi + (size_t)t * DD;
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+              if (item(q)) {
+                stg(po, T.gofs[q], xk[q][0]);
+                if (row2(q)) stg(po, T.gofs[q] + D8, xk[q][1]);
+              }
+            }
+            if (vl) stg(lam + (size_t)t * D, te8, vk);
+          }
+        }
         __syncthreads();
         const bool last = (j == NS - 1);
         double vs = 0.0;
-        if (vl) vs = matvec_sum<NB, false>(L, te);
+        if (vl) vs = matvec_sum<NB, NE, false>(L, te);
 #pragma unroll
-        for (int q = 0; q < NIT; q++) {
-          if (item(q)) {
-            const double w0 = L.W[T.offW[q]], w1 = L.W[T.offW[q] + g::LDW];
-            const d2_t wt = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
-            d2_t w, xn; w[0] = w0; w[1] = w1;
-            d2_t js{0.0, 0.0};
-            if (last) {      // matrix jump of index t-1, added after the step (euler.py:139-149)
-              if (DENSEJ) {
-                const double* jp = a.js_dense + ((size_t)prob * Np + (t - 1)) * DD;
-                js[0] = jp[T.gofs[q]]; js[1] = row2(q) ? jp[T.gofs[q] + D] : 0.0;
-              } else if (n_obs_cur >= 0) {
-                js = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * kNE));
+        for (int q0 = 0; q0 < NIT; q0 += 4) {
+          d2_t wv[4], wt[4], js[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < NIT) {
+              wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
+              wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
+              js[u] = d2_t{0.0, 0.0};
+              if (last) {      // matrix jump of index t-1, added after the step (euler.py:139-149)
+                if (DENSEJ) {
+                  if (item(q)) {
+                    const double* jp = a.js_dense + ((size_t)prob * Np + (t - 1)) * DD;
+                    js[u][0] = ldg(jp, T.gofs[q]); js[u][1] = row2(q) ? ldg(jp, T.gofs[q] + D8) : 0.0;
+                  }
+                } else if (n_obs_cur >= 0) {
+                  js[u] = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * NE));
+                }
               }
             }
-            const d2_t gmat = 0.5 * (gN[q] + gC[q]);
-            if (METHOD == VGPA_ODE_EULER) {
-              xk[q] = xk[q] - ((-gC[q] + wt) + w) * dt + js; xn = xk[q];
-            } else if (METHOD == VGPA_ODE_HEUN) {
-              if (j == 0) { acc1[q] = (-gC[q] + wt) + w; xn = xk[q] - acc1[q] * dt; }
-              else { xk[q] = xk[q] - h * (acc1[q] + ((-gN[q] + wt) + w)) + js; xn = xk[q]; }
-            } else if (METHOD == VGPA_ODE_RK2) {
-              if (j == 0) xn = xk[q] - h * ((-gC[q] + wt) + w);
-              else { xk[q] = xk[q] - dt * ((-gmat + wt) + w) + js; xn = xk[q]; }
-            } else {
-              if (j == 0) { acc1[q] = (-gC[q] + wt) + w; xn = xk[q] - h * acc1[q]; }
-              else if (j == 1) { acc2[q] = (-gmat + wt) + w; xn = xk[q] - h * acc2[q]; }
-              else if (j == 2) { const d2_t r = (-gmat + wt) + w; acc2[q] = acc2[q] + r; xn = xk[q] - dt * r; }
-              else {
-                const d2_t r = (-gN[q] + wt) + w;
-                xk[q] = xk[q] - dt * (acc1[q] + 2.0 * acc2[q] + r) / 6.0 + js; xn = xk[q];
-              }
-            }
-            *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
           }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u;
+            if (q < NIT) {
+              d2_t xn;
+              const d2_t w = wv[u];
+              const d2_t gmat = 0.5 * (gN[q] + gC[q]);
+              if (METHOD == VGPA_ODE_EULER) {
+                xk[q] = xk[q] - ((-gC[q] + wt[u]) + w) * dt + js[u]; xn = xk[q];
+              } else if (METHOD == VGPA_ODE_HEUN) {
+                if (j == 0) { acc1[q] = (-gC[q] + wt[u]) + w; xn = xk[q] - acc1[q] * dt; }
+                else { xk[q] = xk[q] - h * (acc1[q] + ((-gN[q] + wt[u]) + w)) + js[u]; xn = xk[q]; }
+              } else if (METHOD == VGPA_ODE_RK2) {
+                if (j == 0) xn = xk[q] - h * ((-gC[q] + wt[u]) + w);
+                else { xk[q] = xk[q] - dt * ((-gmat + wt[u]) + w) + js[u]; xn = xk[q]; }
+              } else {
+                if (j == 0) { acc1[q] = (-gC[q] + wt[u]) + w; xn = xk[q] - h * acc1[q]; }
+                else if (j == 1) { acc2[q] = (-gmat + wt[u]) + w; xn = xk[q] - h * acc2[q]; }
+                else if (j == 2) { const d2_t r = (-gmat + wt[u]) + w; acc2[q] = acc2[q] + r; xn = xk[q] - dt * r; }
+                else {
+                  const d2_t r = (-gN[q] + wt[u]) + w;
+                  xk[q] = xk[q] - (dt * (acc1[q] + 2.0 * acc2[q] + r)) * sixth + js[u]; xn = xk[q];
+                }
+              }
+              *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
+            }
+          }
+          if (q0 + 4 < NIT) __builtin_amdgcn_sched_barrier(0);
         }
         if (vl) {
           double vn;
@@ -671,46 +854,49 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
             if (j == 0) { v1 = -g0 + vs; vn = vk - h * v1; }
             else if (j == 1) { v2 = -gmid + vs; vn = vk - h * v2; }
             else if (j == 2) { v3 = -gmid + vs; vn = vk - dt * v3; }
-            else { vk = vk - dt * (v1 + 2.0 * (v2 + v3) + (-g1 + vs)) / 6.0 + jm; vn = vk; }
+            else { vk = vk - (dt * (v1 + 2.0 * (v2 + v3) + (-g1 + vs))) * sixth + jm; vn = vk; }
           }
           L.xv[te] = vn;
         }
-        if (j == 0) {
-          stage_operands<METHOD, NB>(L, T, an);
-          if (t >= 2) load_a<NB>(A + (size_t)(t - 2) * DD, T, an);
-        }
-        if (last) {          // Psi_{t-1}, lam_{t-1} -> HBM; rotate G
-          double* po = psi + (size_t)(t - 1) * DD;
+        if (last) {          // rotate G: G_{t-1} becomes the start point of the next step, G_{t-2} is requested
 #pragma unroll
           for (int q = 0; q < NIT; q++) {
             if (item(q)) {
-              po[T.gofs[q]] = xk[q][0];
-              if (row2(q)) po[T.gofs[q] + D] = xk[q][1];
               gC[q] = gN[q];
               if (t >= 2) {
-                const size_t o2 = (size_t)(t - 2) * DD + T.gofs[q];
-                gN[q][0] = gs[o2]; gN[q][1] = row2(q) ? gs[o2 + D] : 0.0;
+                const double* g2p = gs + (size_t)(t - 2) * DD;
+                gN[q][0] = ldg(g2p, T.gofs[q]); gN[q][1] = row2(q) ? ldg(g2p, T.gofs[q] + D8) : 0.0;
               }
             }
           }
-          if (vl) lam[(size_t)(t - 1) * D + te] = vk;
         }
         __syncthreads();
       }
       g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
+    }
+    if (n_steps > 0) {       // Psi, lam of the first grid point
+#pragma unroll
+      for (int q = 0; q < NIT; q++) {
+        if (item(q)) {
+          stg(psi, T.gofs[q], xk[q][0]);
+          if (row2(q)) stg(psi, T.gofs[q] + D8, xk[q][1]);
+        }
+      }
+      if (vl) stg(lam, te8, vk);
     }
   }
   if (trails) __syncthreads();
 }
 
 // =================================================================================================================
-// Workgroup = 4 P waves + 4 E waves per problem.  Problems of workgroup w: the first `npair` workgroups take two
-// (2w, 2w+1), the others one (npair + w).
+// Workgroup = 8 waves: 4 P waves + 4 E waves -- all four for the one problem of a single-problem workgroup, two per problem
+// in a paired one.  Problems of workgroup w: the first `npair` workgroups take two (2w, 2w+1), the others one (npair + w).
 template <int METHOD, bool FWD, int NB, int NPROB, bool DENSEJ>
-__global__ void __launch_bounds__(64 * (kNPW + 4 * NPROB)) k_ode_pe(OdeArgs a, int npair) {
+__global__ void __launch_bounds__(64 * (kNPW + 4)) k_ode_pe(OdeArgs a, int npair) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB>;
-  constexpr int NT = 64 * (kNPW + 4 * NPROB);
+  constexpr int NT = 64 * (kNPW + 4);
+  constexpr int NE = kNE / NPROB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = (int)blockIdx.x;
   const bool paired = (NPROB == 2) && wg < npair;
@@ -721,13 +907,14 @@ __global__ void __launch_bounds__(64 * (kNPW + 4 * NPROB)) k_ode_pe(OdeArgs a, i
   LB.carve(smem + (NPROB == 2 ? g::PROB : 0));
   double* SIG = smem + (size_t)NPROB * g::PROB;
   for (int i = tid; i < (int)g::lds_doubles(NPROB); i += NT) smem[i] = 0.0;
+  const int te = tid - 64 * kNPW;
   if (wave < kNPW) {
-    p_role<METHOD, FWD, NB, NPROB>(a.Np - 1, paired, LA, LB, wave, lane);
-  } else if (wave < kNPW + 4) {
+    p_role<METHOD, FWD, NB, NPROB>(a, prob_a, paired, LA, LB, wave, lane);
+  } else if (NPROB == 1 || te < NE) {
     // problem A: its element-wise phase is the one in which the P waves work for B (or idle); it waits out B's last phase
-    e_role<METHOD, FWD, NB, DENSEJ>(a, prob_a, true, false, NPROB == 2, LA, SIG, true, tid - 64 * kNPW);
+    e_role<METHOD, FWD, NB, NE, DENSEJ>(a, prob_a, true, false, NPROB == 2, LA, SIG, true, te);
   } else {
-    e_role<METHOD, FWD, NB, DENSEJ>(a, prob_b, paired, true, false, LB, SIG, false, tid - 64 * (kNPW + 4));
+    e_role<METHOD, FWD, NB, NE, DENSEJ>(a, prob_b, paired, true, false, LB, SIG, false, te - NE);
   }
 }
 
@@ -739,7 +926,7 @@ hipError_t launch_nb_p(const OdeArgs& a, int nwg, int npair, hipStream_t st) {
   auto kern = dense ? k_ode_pe<METHOD, FWD, NB, NPROB, true> : k_ode_pe<METHOD, FWD, NB, NPROB, false>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * (kNPW + 4 * NPROB)), lds, st, a, npair);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * (kNPW + 4)), lds, st, a, npair);
   return hipGetLastError();
 }
 
