@@ -11,11 +11,11 @@ __global__ void __launch_bounds__(256) k(long long* out, int iters) {
   using g = Geo<10>;
   Lds<10> L; L.carve(smem);
   for (int i = threadIdx.x; i < g::PROB; i += 256) smem[i] = 1e-3 * (i % 97);
-  PTab<10> T; build_ptab<10>(threadIdx.x >> 6, threadIdx.x & 63, T);
+  PTab<10> T; build_ptab<10>(40, threadIdx.x >> 6, threadIdx.x & 63, T); double w0[Geo<10>::MAXU] = {};
   __syncthreads();
   long long t0 = clock64();
   for (int it = 0; it < iters; it++) {
-    product<10, g::LDA>(L.R, L.X, L.W, T, threadIdx.x & 63);
+    product<10, g::LDA>(L.R, L.X, L.W, T, threadIdx.x & 63, w0, [](){});
     if (MODE == 1) __syncthreads();
     if (MODE == 2) { __syncthreads(); __syncthreads(); }
   }

@@ -202,6 +202,12 @@ struct Lds {
   }
 };
 
+// Values loaded from HBM before the time loop and only read inside it: make the compiler wait for them HERE.  Otherwise
+// its wait-count pass, which cannot see across the loop back-edge that they arrived long ago, puts an s_waitcnt vmcnt(0) in
+// front of their first use inside the loop -- behind the prefetches the step has just issued.
+__device__ __forceinline__ void settle(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void settle(d2_t& v) { asm volatile("" : "+v"(v)); }
+
 // ---- P waves -----------------------------------------------------------------------------------------------------
 template <int NB>
 struct PTab {
@@ -209,10 +215,12 @@ struct PTab {
   int colA[MAXU];   // 2*(4*I_b + (l&3))
   int colB0, colB1; // B-fragment columns of the group feeding slots [0,S1) / slots [S1,MAXU)
   int offW[MAXU];   // row * LDW + col of the element this lane's accumulator holds (trash for lanes without one)
+  unsigned gofs[MAXU];   // 8 (row * D + col): BYTE offset of that element inside a D x D matrix in HBM (0 without one)
+  unsigned own;     // bit s: slot s holds a real matrix element (row, col < D)
 };
 
 template <int NB>
-__device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
+__device__ __forceinline__ void build_ptab(int D, int pw, int lane, PTab<NB>& T) {
   using g = Geo<NB>;
   const int b = (lane >> 2) & 3, r4 = lane >> 4, c4 = lane & 3;
   const WaveDeal deal = deal_units(g::NB, g::NQ, g::NLEFT, g::MAXU, g::S1, kNPW, pw, nullptr);
@@ -220,6 +228,7 @@ __device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
   auto group_col = [&](int grp) { return (grp < g::NQ) ? (16 * grp + (lane & 15)) : (4 * (4 * g::NQ + b % rem) + c4); };
   T.colB0 = 2 * group_col(deal.gA);
   T.colB1 = 2 * group_col(deal.gB);
+  T.own = 0u;
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) {
     const bool in_a = s < g::S1;
@@ -243,6 +252,9 @@ __device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
     const int row = 4 * Ib + r4, col = 4 * Jb + c4;
     T.colA[s] = 2 * (4 * Ib + c4);
     T.offW[s] = ok ? (row * g::LDW + col) : (g::P * g::LDW + 64 * pw + lane);
+    const bool own = ok && row < D && col < D;
+    T.gofs[s] = own ? 8u * (unsigned)(row * D + col) : 0u;
+    if (own) T.own |= 1u << s;
   }
 }
 
@@ -251,9 +263,12 @@ __device__ __forceinline__ void build_ptab(int pw, int lane, PTab<NB>& T) {
 // Straight-line code: NKP k-pairs, fragments of pair kp+1 are loaded while the MFMAs of pair kp issue.  (A hand-pinned
 // variant -- three buffers, all reads of pair kp+2 in one block in front of the MFMAs of pair kp -- was 10 % slower: nine
 // back-to-back ds_read_b128 keep the wave from issuing MFMAs for ~70 cycles; the compiler's interleaving is kept.)
-template <int NB, int LDAOP>
+// The accumulators start from w0 = minus half the stage's symmetric forcing term (Sigma forward, dEsde_dS backward), so
+// that what the E waves read is V = W -+ F/2 and the stage slope is just -(V + V^T) / +(V + V^T): the forcing term never
+// enters the element-wise waves (no LDS read, no registers there).
+template <int NB, int LDAOP, typename Chores>
 __device__ __forceinline__ void product(const double* __restrict__ Aop, const double* __restrict__ X, double* __restrict__ Wb,
-                                        const PTab<NB>& T, int lane) {
+                                        const PTab<NB>& T, int lane, const double (&w0)[Geo<NB>::MAXU], Chores&& chores) {
   using g = Geo<NB>;
   constexpr int MAXU = g::MAXU, NKP = g::NKP;
   const int r4 = lane >> 4;
@@ -261,8 +276,9 @@ __device__ __forceinline__ void product(const double* __restrict__ Aop, const do
   const double* px = X + r4 * g::LDX;
   d2_t af[2][MAXU], bf[2][2];
   double w[MAXU];
+  chores();          // the operand staging of the OTHER problem (tried between the k-pairs instead: 4 % slower)
 #pragma unroll
-  for (int s = 0; s < MAXU; s++) { w[s] = 0.0; af[0][s] = *reinterpret_cast<const d2_t*>(pa + T.colA[s]); }
+  for (int s = 0; s < MAXU; s++) { w[s] = w0[s]; af[0][s] = *reinterpret_cast<const d2_t*>(pa + T.colA[s]); }
   bf[0][0] = *reinterpret_cast<const d2_t*>(px + T.colB0);
   bf[0][1] = *reinterpret_cast<const d2_t*>(px + T.colB1);
 #pragma unroll
@@ -303,12 +319,33 @@ __host__ __device__ constexpr int stage_op(int j, bool matrix, int step) {
 template <int METHOD>
 __host__ __device__ constexpr int n_stages() { return METHOD == VGPA_ODE_EULER ? 1 : (METHOD == VGPA_ODE_RK4 ? 4 : 2); }
 
+// forcing term of one problem in the P lanes: forward the constant Sigma (fc; fn unused), backward G_t (fc) and G_{t-1}
+// (fn) of the current step, element per accumulator slot
 template <int METHOD, bool FWD, int NB>
-__device__ __forceinline__ void p_product_stage(int j, int step, const Lds<NB>& L, const PTab<NB>& T, int lane) {
+__device__ __forceinline__ void stage_w0(int j, const PTab<NB>& T, const double (&fc)[Geo<NB>::MAXU],
+                                         const double (&fn)[Geo<NB>::MAXU], double (&w0)[Geo<NB>::MAXU]) {
+#pragma unroll
+  for (int s = 0; s < Geo<NB>::MAXU; s++) {
+    double f;
+    if (FWD) f = fc[s];
+    else if (METHOD == VGPA_ODE_EULER) f = fc[s];
+    else if (METHOD == VGPA_ODE_HEUN) f = j == 0 ? fc[s] : fn[s];
+    else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
+    else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
+    w0[s] = ((T.own >> s) & 1u) ? -0.5 * f : 0.0;
+  }
+}
+
+template <int METHOD, bool FWD, int NB, typename Chores>
+__device__ __forceinline__ void p_product_stage(int j, int step, const Lds<NB>& L, const PTab<NB>& T, int lane,
+                                                const double (&fc)[Geo<NB>::MAXU], const double (&fn)[Geo<NB>::MAXU],
+                                                Chores&& chores) {
   using g = Geo<NB>;
+  double w0[g::MAXU];
+  stage_w0<METHOD, FWD, NB>(j, T, fc, fn, w0);
   const int op = stage_op<METHOD, FWD>(j, true, step);
-  if (op == OP_X) product<NB, g::LDX>(L.X, L.X, L.W, T, lane);
-  else product<NB, g::LDA>(op == OP_M ? L.M : L.R, L.X, L.W, T, lane);
+  if (op == OP_X) product<NB, g::LDX>(L.X, L.X, L.W, T, lane, w0, chores);
+  else product<NB, g::LDA>(op == OP_M ? L.M : L.R, L.X, L.W, T, lane, w0, chores);
 }
 
 // ---- A(t): HBM -> registers -> LDS operand buffers, by the P waves -------------------------------------------------------
@@ -401,12 +438,24 @@ __device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b,
   const int Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
   const int tp = 64 * pw + lane;
   PTab<NB> T;
-  build_ptab<NB>(pw, lane, T);
+  build_ptab<NB>(a.D, pw, lane, T);
   STab<NB> S;
   build_stab<NB, FWD>(a.D, tp, S);
   const double* Aa = a.A + (size_t)prob_a * a.strideA;
   const double* Ab = Aa + (has_b ? a.strideA : 0);
   d2_t ana[g::NIT], anb[g::NIT];
+  // forcing terms per accumulator slot: forward Sigma (one set for both problems), backward G_t / G_{t-1} per problem,
+  // requested from HBM one step ahead
+  const double* Ga = FWD ? a.Sigma : a.dEs + (size_t)prob_a * Np * DD;
+  const double* Gb = FWD ? a.Sigma : Ga + (has_b ? (size_t)Np * DD : 0);
+  double fca[g::MAXU], fna[g::MAXU], fcb[g::MAXU], fnb[g::MAXU];
+#pragma unroll
+  for (int s = 0; s < g::MAXU; s++) {
+    const size_t last = FWD ? 0 : (size_t)(Np - 1) * DD, prev = FWD ? 0 : (size_t)(Np > 1 ? Np - 2 : 0) * DD;
+    fca[s] = ldg(Ga + last, T.gofs[s]); fna[s] = FWD ? 0.0 : ldg(Ga + prev, T.gofs[s]);
+    fcb[s] = (!FWD && NPROB == 2) ? ldg(Gb + last, T.gofs[s]) : 0.0;
+    fnb[s] = (!FWD && NPROB == 2) ? ldg(Gb + prev, T.gofs[s]) : 0.0;
+  }
   __syncthreads();                       // LDS zero-filled
   {  // operands of the first step: R <- A at the first grid point of the sweep; A at the second one stays in flight
     const size_t t0 = FWD ? 0 : (size_t)(Np - 1), t1 = FWD ? 1 : (size_t)(Np - 2);
@@ -419,21 +468,37 @@ __device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b,
       if (NPROB == 2 && has_b) load_a<NB>(Ab + t1 * DD, S, anb);
     }
   }
-  __syncthreads();                       // prologue (X, R, xv, Sigma) published
+#pragma unroll
+  for (int s = 0; s < g::MAXU; s++) { settle(fca[s]); settle(fna[s]); settle(fcb[s]); settle(fnb[s]); }
+  __syncthreads();                       // prologue (X, R, xv, constant jump) published
   VGPA_STAMP_DECL;
   for (int k = 0; k < n_steps; k++) {
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-      if (NPROB == 2 && has_b) {         // B's chores for its previous product
-        if (j > 0) p_stage_after<METHOD, FWD, NB>(j - 1, k, n_steps, Ab, DD, Np, LB, S, anb, tp);
-        else if (k > 0) p_stage_after<METHOD, FWD, NB>(NS - 1, k - 1, n_steps, Ab, DD, Np, LB, S, anb, tp);
+      auto chores_b = [&]() {            // B's chores for its previous product
+        if (NPROB == 2 && has_b) {
+          if (j > 0) p_stage_after<METHOD, FWD, NB>(j - 1, k, n_steps, Ab, DD, Np, LB, S, anb, tp);
+          else if (k > 0) p_stage_after<METHOD, FWD, NB>(NS - 1, k - 1, n_steps, Ab, DD, Np, LB, S, anb, tp);
+        }
+      };
+      auto chores_a = [&]() { p_stage_after<METHOD, FWD, NB>(j, k, n_steps, Aa, DD, Np, LA, S, ana, tp); };
+      p_product_stage<METHOD, FWD, NB>(j, k, LA, T, lane, fca, fna, chores_b);
+      if (!FWD && j == NS - 1) {         // G of the next step: G_{t-1} becomes the start point, G_{t-2} is requested
+        const size_t nxt = (size_t)(Np - 1 - (k + 2) >= 0 ? Np - 1 - (k + 2) : 0) * DD;
+#pragma unroll
+        for (int s = 0; s < g::MAXU; s++) { fca[s] = fna[s]; fna[s] = ldg(Ga + nxt, T.gofs[s]); }
       }
-      p_product_stage<METHOD, FWD, NB>(j, k, LA, T, lane);
       VGPA_STAMP(pw == 0 ? 0 : 3, 0);    // product A
       __syncthreads();
       VGPA_STAMP(pw == 0 ? 0 : 3, 1);    // barrier
-      p_stage_after<METHOD, FWD, NB>(j, k, n_steps, Aa, DD, Np, LA, S, ana, tp);
-      if (NPROB == 2 && has_b) p_product_stage<METHOD, FWD, NB>(j, k, LB, T, lane);
+      if (NPROB == 2 && has_b) {
+        p_product_stage<METHOD, FWD, NB>(j, k, LB, T, lane, FWD ? fca : fcb, fnb, chores_a);
+        if (!FWD && j == NS - 1) {
+          const size_t nxt = (size_t)(Np - 1 - (k + 2) >= 0 ? Np - 1 - (k + 2) : 0) * DD;
+#pragma unroll
+          for (int s = 0; s < g::MAXU; s++) { fcb[s] = fnb[s]; fnb[s] = ldg(Gb + nxt, T.gofs[s]); }
+        }
+      } else chores_a();                 // (single problem: the P waves stage while the E waves do their stage)
       VGPA_STAMP(pw == 0 ? 0 : 3, 2);    // product B (or the idle phase of a single problem)
       __syncthreads();
       VGPA_STAMP(pw == 0 ? 0 : 3, 3);    // barrier
@@ -443,12 +508,6 @@ __device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b,
 }
 
 // ---- E waves -----------------------------------------------------------------------------------------------------
-// Values loaded from HBM before the time loop and only read inside it: make the compiler wait for them HERE.  Otherwise
-// its wait-count pass, which cannot see across the loop back-edge that they arrived long ago, puts an s_waitcnt vmcnt(0) in
-// front of their first use inside the loop -- behind the prefetches the step has just issued.
-__device__ __forceinline__ void settle(double& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void settle(d2_t& v) { asm volatile("" : "+v"(v)); }
-
 // A row-pair item (p, c) = elements (2p, c) and (2p+1, c) of the D x D state; items are dealt with c fastest over the
 // E threads, so a 16-lane group publishes 16 consecutive 16-byte units with one conflict-free ds_write_b128 and its W
 // reads are 16 consecutive doubles of one row.
@@ -560,6 +619,10 @@ __device__ __forceinline__ double matvec_sum(const Lds<NB>& L, int i) {
 template <int METHOD, bool FWD, int NB, int NE, bool DENSEJ>
 __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, bool leads, bool trails, const Lds<NB>& L,
                                        double* __restrict__ SIG, bool writes_sig, int te) {
+  // The library is built with -ffp-contract=off (the other kernels keep the reference's operation order); the Runge-Kutta
+  // bookkeeping here may fuse a*b+c: every fused operation is one rounding closer to the exact value and one instruction
+  // less on the fp64 pipe these waves share with the matrix cores.  Parity bound of the test-suite: 1e-9 (north star 1e-6).
+#pragma clang fp contract(fast)
   using g = Geo<NB>;
   constexpr int NIT = EGeo<NB, NE>::NIT, NS = n_stages<METHOD>();
   const int D = a.D, DD = D * D, Np = a.Np;
@@ -582,10 +645,10 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
   auto opbuf = [&](int op) -> const double* { return op == OP_M ? L.M : L.R; };
   constexpr double sixth = 1.0 / 6.0;
 
-  d2_t xk[NIT], acc1[NIT], acc2[NIT];
+  d2_t xk[NIT], acc[NIT];
   double vk = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;           // vector entry and its RK slopes
 #pragma unroll
-  for (int q = 0; q < NIT; q++) { xk[q] = d2_t{0.0, 0.0}; acc1[q] = acc2[q] = d2_t{0.0, 0.0}; }
+  for (int q = 0; q < NIT; q++) { xk[q] = d2_t{0.0, 0.0}; acc[q] = d2_t{0.0, 0.0}; }
 
   __syncthreads();                                         // LDS zero-filled
   if (FWD) {
@@ -601,11 +664,6 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
         stg(st, T.gofs[q], xk[q][0]);
         if (row2(q)) stg(st, T.gofs[q] + D8, xk[q][1]);
         *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xk[q];
-        if (writes_sig) {
-          d2_t sg;
-          sg[0] = ldg(a.Sigma, T.gofs[q]); sg[1] = row2(q) ? ldg(a.Sigma, T.gofs[q] + D8) : 0.0;
-          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = sg;
-        }
       }
     }
     if (vl) { vk = ldg(a.m0, te8); stg(mt, te8, vk); L.xv[te] = vk; }
@@ -651,14 +709,13 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
         // per batch; the scheduling barrier keeps the reads of the next batch (and their registers) behind this one.
 #pragma unroll
         for (int q0 = 0; q0 < NIT; q0 += 4) {
-          d2_t wv[4], wt[4], sg[4];
+          d2_t wv[4], wt[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int q = q0 + u;
             if (q < NIT) {
               wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
               wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
-              sg[u] = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * NE));
             }
           }
 #pragma unroll
@@ -666,20 +723,20 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
             const int q = q0 + u;
             if (q < NIT) {
               d2_t xn;
-              const d2_t f = (-wv[u] - wt[u]) + sg[u];
+              const d2_t f = -wv[u] - wt[u];                // = -(W + W^T) + Sigma: the P waves started from -Sigma/2
               if (METHOD == VGPA_ODE_EULER) {
                 xk[q] = xk[q] + f * dt; xn = xk[q];
               } else if (METHOD == VGPA_ODE_HEUN) {
-                if (j == 0) { acc1[q] = f; xn = xk[q] + f * dt; }
-                else { xk[q] = xk[q] + h * (acc1[q] + f); xn = xk[q]; }
+                if (j == 0) { acc[q] = f; xn = xk[q] + f * dt; }
+                else { xk[q] = xk[q] + h * (acc[q] + f); xn = xk[q]; }
               } else if (METHOD == VGPA_ODE_RK2) {
                 if (j == 0) xn = xk[q] + h * f;
                 else { xk[q] = xk[q] + dt * f; xn = xk[q]; }
-              } else {
-                if (j == 0) { acc1[q] = f; xn = xk[q] + h * f; }
-                else if (j == 1) { acc2[q] = f; xn = xk[q] + h * f; }
-                else if (j == 2) { acc2[q] = acc2[q] + f; xn = xk[q] + dt * f; }
-                else { xk[q] = xk[q] + (dt * (acc1[q] + 2.0 * acc2[q] + f)) * sixth; xn = xk[q]; }
+              } else {                                      // acc = k1 + 2 k2 + 2 k3 + k4, summed as the stages come
+                if (j == 0) { acc[q] = f; xn = xk[q] + h * f; }
+                else if (j == 1) { acc[q] = acc[q] + 2.0 * f; xn = xk[q] + h * f; }
+                else if (j == 2) { acc[q] = acc[q] + 2.0 * f; xn = xk[q] + dt * f; }
+                else { xk[q] = xk[q] + (dt * (acc[q] + f)) * sixth; xn = xk[q]; }
               }
               *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
             }
@@ -723,19 +780,13 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
   } else {
     // ------------------------------------------------------------------------------------------ backward: (lam, Psi)
     const double* gm = a.dEm + (size_t)prob * Np * D;
-    const double* gs = a.dEs + (size_t)prob * Np * DD;
     double* lam = a.lam + (size_t)prob * Np * D;
     double* psi = a.psi + (size_t)prob * Np * DD;
-    d2_t gC[NIT], gN[NIT];
     const bool sparse = !DENSEJ && a.obs_idx;
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
-      gC[q] = gN[q] = d2_t{0.0, 0.0};
       if (item(q)) {
-        const double* g1p = gs + (size_t)(Np - 1) * DD;
         double* p1p = psi + (size_t)(Np - 1) * DD;
-        gC[q][0] = ldg(g1p, T.gofs[q]); gC[q][1] = row2(q) ? ldg(g1p, T.gofs[q] + D8) : 0.0;
-        if (Np > 1) { gN[q][0] = ldg(g1p - DD, T.gofs[q]); gN[q][1] = row2(q) ? ldg(g1p - DD, T.gofs[q] + D8) : 0.0; }
         stg(p1p, T.gofs[q], 0.0);
         if (row2(q)) stg(p1p, T.gofs[q] + D8, 0.0);
         if (writes_sig && !DENSEJ) {
@@ -755,8 +806,6 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
       if (DENSEJ) { if (vl) jm = ldg(a.jm_dense + ((size_t)prob * Np + (Np - 2)) * D, te8); }
       else if (vl && n_obs_cur >= 0) jm = ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs_cur) * D, te8);
     }
-#pragma unroll
-    for (int q = 0; q < NIT; q++) { settle(gC[q]); settle(gN[q]); }
     settle(g0); settle(g1); settle(jm);
     __syncthreads();                                       // prologue published
     if (leads) __syncthreads();
@@ -817,24 +866,20 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
             const int q = q0 + u;
             if (q < NIT) {
               d2_t xn;
-              const d2_t w = wv[u];
-              const d2_t gmat = 0.5 * (gN[q] + gC[q]);
+              const d2_t r = wt[u] + wv[u];                 // = -G + W'^T + W': the P waves started from -G/2
               if (METHOD == VGPA_ODE_EULER) {
-                xk[q] = xk[q] - ((-gC[q] + wt[u]) + w) * dt + js[u]; xn = xk[q];
+                xk[q] = xk[q] - r * dt + js[u]; xn = xk[q];
               } else if (METHOD == VGPA_ODE_HEUN) {
-                if (j == 0) { acc1[q] = (-gC[q] + wt[u]) + w; xn = xk[q] - acc1[q] * dt; }
-                else { xk[q] = xk[q] - h * (acc1[q] + ((-gN[q] + wt[u]) + w)) + js[u]; xn = xk[q]; }
+                if (j == 0) { acc[q] = r; xn = xk[q] - r * dt; }
+                else { xk[q] = xk[q] - h * (acc[q] + r) + js[u]; xn = xk[q]; }
               } else if (METHOD == VGPA_ODE_RK2) {
-                if (j == 0) xn = xk[q] - h * ((-gC[q] + wt[u]) + w);
-                else { xk[q] = xk[q] - dt * ((-gmat + wt[u]) + w) + js[u]; xn = xk[q]; }
+                if (j == 0) xn = xk[q] - h * r;
+                else { xk[q] = xk[q] - dt * r + js[u]; xn = xk[q]; }
               } else {
-                if (j == 0) { acc1[q] = (-gC[q] + wt[u]) + w; xn = xk[q] - h * acc1[q]; }
-                else if (j == 1) { acc2[q] = (-gmat + wt[u]) + w; xn = xk[q] - h * acc2[q]; }
-                else if (j == 2) { const d2_t r = (-gmat + wt[u]) + w; acc2[q] = acc2[q] + r; xn = xk[q] - dt * r; }
-                else {
-                  const d2_t r = (-gN[q] + wt[u]) + w;
-                  xk[q] = xk[q] - (dt * (acc1[q] + 2.0 * acc2[q] + r)) * sixth + js[u]; xn = xk[q];
-                }
+                if (j == 0) { acc[q] = r; xn = xk[q] - h * r; }
+                else if (j == 1) { acc[q] = acc[q] + 2.0 * r; xn = xk[q] - h * r; }
+                else if (j == 2) { acc[q] = acc[q] + 2.0 * r; xn = xk[q] - dt * r; }
+                else { xk[q] = xk[q] - (dt * (acc[q] + r)) * sixth + js[u]; xn = xk[q]; }
               }
               *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
             }
@@ -857,18 +902,6 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
             else { vk = vk - (dt * (v1 + 2.0 * (v2 + v3) + (-g1 + vs))) * sixth + jm; vn = vk; }
           }
           L.xv[te] = vn;
-        }
-        if (last) {          // rotate G: G_{t-1} becomes the start point of the next step, G_{t-2} is requested
-#pragma unroll
-          for (int q = 0; q < NIT; q++) {
-            if (item(q)) {
-              gC[q] = gN[q];
-              if (t >= 2) {
-                const double* g2p = gs + (size_t)(t - 2) * DD;
-                gN[q][0] = ldg(g2p, T.gofs[q]); gN[q][1] = row2(q) ? ldg(g2p, T.gofs[q] + D8) : 0.0;
-              }
-            }
-          }
         }
         __syncthreads();
       }
