@@ -67,10 +67,6 @@ enum {
 /* config flags */
 enum {
   VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
-  VGPA_FLAG_SINGLE_PROBLEM_WG = 2, /* MFMA steppers: one problem per workgroup whatever the batch size (default: one per
-                                      workgroup while batch <= #CUs, two per workgroup -- alternating phases -- beyond) */
-  VGPA_FLAG_PAIR_PROBLEMS = 16,    /* MFMA steppers: two problems per workgroup from batch = 2 on (tests: the paired
-                                      kernel at small batches; D <= 40) */
   VGPA_FLAG_LIBRARY_GEMM = 8,  /* D > 64: rocBLAS dgemm (dlopen'ed) for the plain stage products W = A.X / A^T.Psi instead of the
                                   hand-written MFMA GEMM; everything fused stays hand-written.  Off by default. */
   VGPA_FLAG_STREAM_LARGE_D = 4 /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and

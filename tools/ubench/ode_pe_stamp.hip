@@ -6,7 +6,6 @@
 #include <vector>
 #include <random>
 using namespace vgpa;
-namespace vgpa { namespace mfma { int device_cu_count() { return 256; } } }
 int main(int argc, char** argv) {
   const int D = 40, Np = 1001, B = (argc > 1) ? atoi(argv[1]) : 1, pm = (argc > 2) ? atoi(argv[2]) : 0;
   const size_t DD = D * D;
@@ -16,7 +15,7 @@ int main(int argc, char** argv) {
   for (int p = 0; p < B; p++) for (int t = 0; t < Np; t++) for (int i = 0; i < D; i++) A[((size_t)p * Np + t) * DD + i * D + i] += 8.0;
   for (auto& v : b) v = nd(rng);
   for (int i = 0; i < D; i++) { S0[i * D + i] = 0.2; Sg[i * D + i] = 4.0; }
-  OdeArgs a{}; a.pair_mode = pm; a.D = D; a.Np = Np; a.batch = B; a.dt = 0.01;
+  OdeArgs a{}; a.D = D; a.Np = Np; a.batch = B; a.dt = 0.01;
   a.strideA = (size_t)Np * DD; a.strideB = (size_t)Np * D;
   double *dA, *db, *dS0, *dSg, *dm0, *dm, *dS;
   hipMalloc(&dA, A.size() * 8); hipMalloc(&db, b.size() * 8); hipMalloc(&dS0, DD * 8); hipMalloc(&dSg, DD * 8); hipMalloc(&dm0, D * 8);

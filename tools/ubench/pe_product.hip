@@ -4,7 +4,6 @@
 #include <cstdio>
 using namespace vgpa;
 using namespace vgpa::mfma;
-namespace vgpa { namespace mfma { int device_cu_count() { return 256; } } }
 template <int MODE>
 __global__ void __launch_bounds__(256) k(long long* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -18,8 +18,6 @@ MODEL_IDS = {"NONE": -1, "OU": 0, "DW": 1, "L63": 2, "L96": 3}
 METHOD_IDS = {"euler": 0, "heun": 1, "rk2": 2, "rk4": 3}
 FETCH_IDS = {"mt": 0, "st": 1, "lamt": 2, "psit": 3, "Efx": 4, "Edf": 5, "dEsde_dm": 6, "dEsde_ds": 7, "Esde_t": 8}
 FLAG_FORCE_GENERIC = 1
-FLAG_SINGLE_PROBLEM_WG = 2
-FLAG_PAIR_PROBLEMS = 16
 FLAG_STREAM_LARGE_D = 4
 FLAG_LIBRARY_GEMM = 8
 OPT_LD_CHUNK = 1

@@ -3,20 +3,6 @@
 
 namespace vgpa {
 
-namespace mfma {
-int device_cu_count() {
-  static int cached[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cached[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
-  }
-  return cached[dev];
-}
-}  // namespace mfma
-
 bool ode_mfma_supported(int method, bool, int D) {
   if (D < 1) return false;
   const int nb = (D + 3) / 4;

@@ -1,4 +1,4 @@
-// Symmetric fast path of the time-stepping kernels: fp64 matrix cores, role-specialised waves, two problems per workgroup.
+// Symmetric fast path of the time-stepping kernels: fp64 matrix cores, role-specialised waves, one workgroup per problem.
 // (Included by ode_mfma_m{0,1,2,3}.hip, one translation unit per stepper so that they compile in parallel.)
 //
 // Math.  With S (resp. Psi) symmetric the two products of the reference collapse to one:
@@ -20,13 +20,14 @@
 //     stepper, publish the next stage state with one ds_write_b128 per item, do the mean / lambda recursion (mat-vec on
 //     the VALU while the P waves are in the product), stage A(t) HBM -> registers -> LDS one step ahead and stream
 //     S_k / Psi_t back to HBM.
-//   * A workgroup integrates TWO problems: while the P waves multiply for problem A, the E waves of problem B do B's
-//     element-wise stage, and vice versa.  One workgroup barrier per phase = per problem-stage (round 1: two), the matrix
-//     pipe works in every phase, and the latency chain of one problem hides behind the product of the other.  With at
-//     most one problem per CU (batch <= #CUs, e.g. the single problem of an SCG run) a workgroup takes one problem and the
-//     phases alternate P / E.
+//   * One workgroup (4 P + 4 E waves, one of each per SIMD) per problem; the phases alternate product / element-wise
+//     stage with ONE workgroup barrier each.  Two further schedules were built and measured in round 2 and are not kept
+//     (DESIGN.md s.4.1): two problems per workgroup in alternating phases (the matrix pipe works in every phase, but the
+//     product of one problem and the element-wise waves of the other slow each other down: 2.8 k cycles per
+//     problem-stage against 2.8 k for this one), and counters in LDS instead of barriers (the P waves run products back
+//     to back, but polling and the longer hand-off latency cost more than the drained pipeline they avoid).
 // LDS per problem (D = 40): stage state X 15 KB + two A-operand buffers (start/end point R, mid-point M) 26 KB + W 13 KB
-// + vectors; Sigma (or the constant matrix jump) once per workgroup; 131 KB for two problems.
+// + vectors + the constant matrix jump 13 KB: 82 KB.
 #pragma once
 #include "vgpa_internal.h"
 
@@ -34,10 +35,8 @@ namespace vgpa {
 namespace mfma {
 
 constexpr int kMaxNB = 11;       // D <= 44
-constexpr int kMaxPairNB = 10;   // two problems per workgroup fit the 160 KB of LDS up to D = 40
 constexpr int kNPW = 4;          // P waves (one per SIMD)
-constexpr int kNE = 256;         // E threads of a single-problem workgroup (4 waves, one per SIMD); a paired workgroup gives
-                                 // each problem 128 (2 waves): 8 waves per workgroup either way = 256 VGPRs per wave
+constexpr int kNE = 256;         // E threads (4 waves, one per SIMD)
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -171,7 +170,7 @@ struct Geo {
   static constexpr int PV = cmax(cmin(kNE / P, RP), cmin(kNE / (P / 2), P)) * P;   // partial mat-vec sums, sized for 256 E threads
   static constexpr int PROB = XS + 2 * AS + WS + XV + PV;
   static constexpr int SIGS = P * P;                      // Sigma / constant matrix jump in item layout
-  static constexpr size_t lds_doubles(int nprob) { return (size_t)nprob * PROB + SIGS + 2 * kNE; }
+  static constexpr size_t LDS_DOUBLES = (size_t)PROB + SIGS + 2 * kNE;
 };
 
 // what depends on the number NE of E threads of a problem
@@ -266,9 +265,9 @@ __device__ __forceinline__ void build_ptab(int D, int pw, int lane, PTab<NB>& T)
 // The accumulators start from w0 = minus half the stage's symmetric forcing term (Sigma forward, dEsde_dS backward), so
 // that what the E waves read is V = W -+ F/2 and the stage slope is just -(V + V^T) / +(V + V^T): the forcing term never
 // enters the element-wise waves (no LDS read, no registers there).
-template <int NB, int LDAOP, typename Chores>
+template <int NB, int LDAOP>
 __device__ __forceinline__ void product(const double* __restrict__ Aop, const double* __restrict__ X, double* __restrict__ Wb,
-                                        const PTab<NB>& T, int lane, const double (&w0)[Geo<NB>::MAXU], Chores&& chores) {
+                                        const PTab<NB>& T, int lane, const double (&w0)[Geo<NB>::MAXU]) {
   using g = Geo<NB>;
   constexpr int MAXU = g::MAXU, NKP = g::NKP;
   const int r4 = lane >> 4;
@@ -276,7 +275,6 @@ __device__ __forceinline__ void product(const double* __restrict__ Aop, const do
   const double* px = X + r4 * g::LDX;
   d2_t af[2][MAXU], bf[2][2];
   double w[MAXU];
-  chores();          // the operand staging of the OTHER problem (tried between the k-pairs instead: 4 % slower)
 #pragma unroll
   for (int s = 0; s < MAXU; s++) { w[s] = w0[s]; af[0][s] = *reinterpret_cast<const d2_t*>(pa + T.colA[s]); }
   bf[0][0] = *reinterpret_cast<const d2_t*>(px + T.colB0);
@@ -336,16 +334,15 @@ __device__ __forceinline__ void stage_w0(int j, const PTab<NB>& T, const double 
   }
 }
 
-template <int METHOD, bool FWD, int NB, typename Chores>
+template <int METHOD, bool FWD, int NB>
 __device__ __forceinline__ void p_product_stage(int j, int step, const Lds<NB>& L, const PTab<NB>& T, int lane,
-                                                const double (&fc)[Geo<NB>::MAXU], const double (&fn)[Geo<NB>::MAXU],
-                                                Chores&& chores) {
+                                                const double (&fc)[Geo<NB>::MAXU], const double (&fn)[Geo<NB>::MAXU]) {
   using g = Geo<NB>;
   double w0[g::MAXU];
   stage_w0<METHOD, FWD, NB>(j, T, fc, fn, w0);
   const int op = stage_op<METHOD, FWD>(j, true, step);
-  if (op == OP_X) product<NB, g::LDX>(L.X, L.X, L.W, T, lane, w0, chores);
-  else product<NB, g::LDA>(op == OP_M ? L.M : L.R, L.X, L.W, T, lane, w0, chores);
+  if (op == OP_X) product<NB, g::LDX>(L.X, L.X, L.W, T, lane, w0);
+  else product<NB, g::LDA>(op == OP_M ? L.M : L.R, L.X, L.W, T, lane, w0);
 }
 
 // ---- A(t): HBM -> registers -> LDS operand buffers, by the P waves -------------------------------------------------------
@@ -399,8 +396,8 @@ __device__ __forceinline__ void store_a(double* __restrict__ buf, double* __rest
   for (int q = 0; q < Geo<NB>::NIT; q++) *reinterpret_cast<d2_t*>(T.lo[q] >= 0 ? buf + T.lo[q] : trash) = v[q];
 }
 
-// What follows the product of stage j of step `step` for one problem, done in the NEXT phase (beside the product of the
-// other problem, or while the single problem is in its element-wise phase): see stage_op.  `an` = A at the step's end point.
+// What follows the product of stage j of step `step`, done while the E waves are in their element-wise phase: see
+// stage_op.  `an` = A at the step's end point.
 template <int METHOD, bool FWD, int NB>
 __device__ __forceinline__ void p_stage_after(int j, int step, int n_steps, const double* __restrict__ A, int DD, int Np,
                                               const Lds<NB>& L, const STab<NB>& T, d2_t (&an)[Geo<NB>::NIT], int tp) {
@@ -428,11 +425,9 @@ __device__ __forceinline__ void p_stage_after(int j, int step, int n_steps, cons
   }
 }
 
-// The P role: products for problem A and problem B in alternating phases, one workgroup barrier per phase; the operand
-// staging of one problem rides beside the product of the other.
-template <int METHOD, bool FWD, int NB, int NPROB>
-__device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b, const Lds<NB>& LA, const Lds<NB>& LB, int pw,
-                                       int lane) {
+// The P role: one product per stage; the operand staging is done while the E waves are in their element-wise phase.
+template <int METHOD, bool FWD, int NB>
+__device__ __forceinline__ void p_role(const OdeArgs& a, int prob, const Lds<NB>& L, int pw, int lane) {
   constexpr int NS = n_stages<METHOD>();
   using g = Geo<NB>;
   const int Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
@@ -441,70 +436,46 @@ __device__ __forceinline__ void p_role(const OdeArgs& a, int prob_a, bool has_b,
   build_ptab<NB>(a.D, pw, lane, T);
   STab<NB> S;
   build_stab<NB, FWD>(a.D, tp, S);
-  const double* Aa = a.A + (size_t)prob_a * a.strideA;
-  const double* Ab = Aa + (has_b ? a.strideA : 0);
-  d2_t ana[g::NIT], anb[g::NIT];
-  // forcing terms per accumulator slot: forward Sigma (one set for both problems), backward G_t / G_{t-1} per problem,
-  // requested from HBM one step ahead
-  const double* Ga = FWD ? a.Sigma : a.dEs + (size_t)prob_a * Np * DD;
-  const double* Gb = FWD ? a.Sigma : Ga + (has_b ? (size_t)Np * DD : 0);
-  double fca[g::MAXU], fna[g::MAXU], fcb[g::MAXU], fnb[g::MAXU];
+  const double* A = a.A + (size_t)prob * a.strideA;
+  d2_t an[g::NIT];
+  // forcing term per accumulator slot: forward Sigma, backward G_t / G_{t-1}, requested from HBM one step ahead
+  const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
+  double fc[g::MAXU], fn[g::MAXU];
 #pragma unroll
   for (int s = 0; s < g::MAXU; s++) {
     const size_t last = FWD ? 0 : (size_t)(Np - 1) * DD, prev = FWD ? 0 : (size_t)(Np > 1 ? Np - 2 : 0) * DD;
-    fca[s] = ldg(Ga + last, T.gofs[s]); fna[s] = FWD ? 0.0 : ldg(Ga + prev, T.gofs[s]);
-    fcb[s] = (!FWD && NPROB == 2) ? ldg(Gb + last, T.gofs[s]) : 0.0;
-    fnb[s] = (!FWD && NPROB == 2) ? ldg(Gb + prev, T.gofs[s]) : 0.0;
+    fc[s] = ldg(G + last, T.gofs[s]);
+    fn[s] = FWD ? 0.0 : ldg(G + prev, T.gofs[s]);
   }
   __syncthreads();                       // LDS zero-filled
   {  // operands of the first step: R <- A at the first grid point of the sweep; A at the second one stays in flight
     const size_t t0 = FWD ? 0 : (size_t)(Np - 1), t1 = FWD ? 1 : (size_t)(Np - 2);
-    load_a<NB>(Aa + t0 * DD, S, ana);
-    if (NPROB == 2 && has_b) load_a<NB>(Ab + t0 * DD, S, anb);
-    store_a<NB>(LA.R, LA.W + g::P * g::LDW + 64 * kNPW + 2 * tp, S, ana);
-    if (NPROB == 2 && has_b) store_a<NB>(LB.R, LB.W + g::P * g::LDW + 64 * kNPW + 2 * tp, S, anb);
-    if (n_steps >= 1) {
-      load_a<NB>(Aa + t1 * DD, S, ana);
-      if (NPROB == 2 && has_b) load_a<NB>(Ab + t1 * DD, S, anb);
-    }
+    load_a<NB>(A + t0 * DD, S, an);
+    store_a<NB>(L.R, L.W + g::P * g::LDW + 64 * kNPW + 2 * tp, S, an);
+    if (n_steps >= 1) load_a<NB>(A + t1 * DD, S, an);
   }
 #pragma unroll
-  for (int s = 0; s < g::MAXU; s++) { settle(fca[s]); settle(fna[s]); settle(fcb[s]); settle(fnb[s]); }
+  for (int s = 0; s < g::MAXU; s++) { settle(fc[s]); settle(fn[s]); }
   __syncthreads();                       // prologue (X, R, xv, constant jump) published
   VGPA_STAMP_DECL;
   for (int k = 0; k < n_steps; k++) {
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-      auto chores_b = [&]() {            // B's chores for its previous product
-        if (NPROB == 2 && has_b) {
-          if (j > 0) p_stage_after<METHOD, FWD, NB>(j - 1, k, n_steps, Ab, DD, Np, LB, S, anb, tp);
-          else if (k > 0) p_stage_after<METHOD, FWD, NB>(NS - 1, k - 1, n_steps, Ab, DD, Np, LB, S, anb, tp);
-        }
-      };
-      auto chores_a = [&]() { p_stage_after<METHOD, FWD, NB>(j, k, n_steps, Aa, DD, Np, LA, S, ana, tp); };
-      p_product_stage<METHOD, FWD, NB>(j, k, LA, T, lane, fca, fna, chores_b);
+      p_product_stage<METHOD, FWD, NB>(j, k, L, T, lane, fc, fn);
       if (!FWD && j == NS - 1) {         // G of the next step: G_{t-1} becomes the start point, G_{t-2} is requested
         const size_t nxt = (size_t)(Np - 1 - (k + 2) >= 0 ? Np - 1 - (k + 2) : 0) * DD;
 #pragma unroll
-        for (int s = 0; s < g::MAXU; s++) { fca[s] = fna[s]; fna[s] = ldg(Ga + nxt, T.gofs[s]); }
+        for (int s = 0; s < g::MAXU; s++) { fc[s] = fn[s]; fn[s] = ldg(G + nxt, T.gofs[s]); }
       }
-      VGPA_STAMP(pw == 0 ? 0 : 3, 0);    // product A
+      VGPA_STAMP(0, 0);                  // product
       __syncthreads();
-      VGPA_STAMP(pw == 0 ? 0 : 3, 1);    // barrier
-      if (NPROB == 2 && has_b) {
-        p_product_stage<METHOD, FWD, NB>(j, k, LB, T, lane, FWD ? fca : fcb, fnb, chores_a);
-        if (!FWD && j == NS - 1) {
-          const size_t nxt = (size_t)(Np - 1 - (k + 2) >= 0 ? Np - 1 - (k + 2) : 0) * DD;
-#pragma unroll
-          for (int s = 0; s < g::MAXU; s++) { fcb[s] = fnb[s]; fnb[s] = ldg(Gb + nxt, T.gofs[s]); }
-        }
-      } else chores_a();                 // (single problem: the P waves stage while the E waves do their stage)
-      VGPA_STAMP(pw == 0 ? 0 : 3, 2);    // product B (or the idle phase of a single problem)
+      VGPA_STAMP(0, 1);                  // barrier
+      p_stage_after<METHOD, FWD, NB>(j, k, n_steps, A, DD, Np, L, S, an, tp);
+      VGPA_STAMP(0, 2);                  // operand staging
       __syncthreads();
-      VGPA_STAMP(pw == 0 ? 0 : 3, 3);    // barrier
+      VGPA_STAMP(0, 3);                  // barrier (the element-wise phase)
     }
   }
-  if (NPROB == 2) __syncthreads();       // problem B's last element-wise phase
 }
 
 // ---- E waves -----------------------------------------------------------------------------------------------------
@@ -614,11 +585,9 @@ __device__ __forceinline__ double matvec_sum(const Lds<NB>& L, int i) {
   return s;
 }
 
-// Everything one E group (NE threads) needs to integrate one problem.  has == false: the group only keeps the barrier
-// count (odd batch: the last workgroup of a paired launch carries one problem).
+// The E role: the Runge-Kutta state of the problem, the vector recursion, the HBM stores.
 template <int METHOD, bool FWD, int NB, int NE, bool DENSEJ>
-__device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, bool leads, bool trails, const Lds<NB>& L,
-                                       double* __restrict__ SIG, bool writes_sig, int te) {
+__device__ __forceinline__ void e_role(const OdeArgs& a, int prob, const Lds<NB>& L, double* __restrict__ SIG, int te) {
   // The library is built with -ffp-contract=off (the other kernels keep the reference's operation order); the Runge-Kutta
   // bookkeeping here may fuse a*b+c: every fused operation is one rounding closer to the exact value and one instruction
   // less on the fp64 pipe these waves share with the matrix cores.  Parity bound of the test-suite: 1e-9 (north star 1e-6).
@@ -629,11 +598,6 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
   const double dt = a.dt, h = 0.5 * a.dt;
   const int n_steps = Np - 1;
   const unsigned D8 = 8u * (unsigned)D, te8 = 8u * (unsigned)te;
-  if (!has) {
-    const int nbar = 2 + 2 * NS * n_steps + 1;
-    for (int i = 0; i < nbar; i++) __syncthreads();
-    return;
-  }
   // The E waves issue few instructions, all on the critical path of their problem; the P wave of the same SIMD always has
   // an MFMA ready.  Without priority the E waves' fp64 VALU work waits for the matrix pipe until the product is over.
   __builtin_amdgcn_s_setprio(3);
@@ -673,10 +637,9 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
     for (int q = 0; q < NIT; q++) settle(xk[q]);
     settle(b0); settle(b1); settle(vk);
     __syncthreads();                                       // prologue published
-    if (leads) __syncthreads();
 
     VGPA_STAMP_DECL;
-    const int srole = (te < 64) ? (leads ? 2 : 1) : 3;
+    const int srole = (te < 64) ? 1 : 3;
     (void)srole;
     for (int k = 0; k < n_steps; k++) {
       const double b2 = (vl && k + 2 < Np) ? ldg(bb + (size_t)(k + 2) * D, te8) : 0.0;     // for the next step
@@ -789,7 +752,7 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
         double* p1p = psi + (size_t)(Np - 1) * DD;
         stg(p1p, T.gofs[q], 0.0);
         if (row2(q)) stg(p1p, T.gofs[q] + D8, 0.0);
-        if (writes_sig && !DENSEJ) {
+        if (!DENSEJ) {
           d2_t js{0.0, 0.0};
           if (a.js_const) { js[0] = ldg(a.js_const, T.gofs[q]); js[1] = row2(q) ? ldg(a.js_const, T.gofs[q] + D8) : 0.0; }
           *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = js;
@@ -808,7 +771,6 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
     }
     settle(g0); settle(g1); settle(jm);
     __syncthreads();                                       // prologue published
-    if (leads) __syncthreads();
 
     for (int t = Np - 1; t > 0; t--) {
       const double g2 = (vl && t >= 2) ? ldg(gm + (size_t)(t - 2) * D, te8) : 0.0;          // for the next step
@@ -918,68 +880,35 @@ __device__ __forceinline__ void e_role(const OdeArgs& a, int prob, bool has, boo
       if (vl) stg(lam, te8, vk);
     }
   }
-  if (trails) __syncthreads();
 }
 
 // =================================================================================================================
-// Workgroup = 8 waves: 4 P waves + 4 E waves -- all four for the one problem of a single-problem workgroup, two per problem
-// in a paired one.  Problems of workgroup w: the first `npair` workgroups take two (2w, 2w+1), the others one (npair + w).
-template <int METHOD, bool FWD, int NB, int NPROB, bool DENSEJ>
-__global__ void __launch_bounds__(64 * (kNPW + 4)) k_ode_pe(OdeArgs a, int npair) {
+// Workgroup = 8 waves = 4 P waves + 4 E waves, one problem.
+template <int METHOD, bool FWD, int NB, bool DENSEJ>
+__global__ void __launch_bounds__(64 * kNPW + kNE) k_ode_pe(OdeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = Geo<NB>;
-  constexpr int NT = 64 * (kNPW + 4);
-  constexpr int NE = kNE / NPROB;
+  constexpr int NT = 64 * kNPW + kNE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wg = (int)blockIdx.x;
-  const bool paired = (NPROB == 2) && wg < npair;
-  const int prob_a = (NPROB == 2) ? (paired ? 2 * wg : npair + wg) : wg;
-  const int prob_b = prob_a + 1;
-  Lds<NB> LA, LB;
-  LA.carve(smem);
-  LB.carve(smem + (NPROB == 2 ? g::PROB : 0));
-  double* SIG = smem + (size_t)NPROB * g::PROB;
-  for (int i = tid; i < (int)g::lds_doubles(NPROB); i += NT) smem[i] = 0.0;
-  const int te = tid - 64 * kNPW;
-  if (wave < kNPW) {
-    p_role<METHOD, FWD, NB, NPROB>(a, prob_a, paired, LA, LB, wave, lane);
-  } else if (NPROB == 1 || te < NE) {
-    // problem A: its element-wise phase is the one in which the P waves work for B (or idle); it waits out B's last phase
-    e_role<METHOD, FWD, NB, NE, DENSEJ>(a, prob_a, true, false, NPROB == 2, LA, SIG, true, te);
-  } else {
-    e_role<METHOD, FWD, NB, NE, DENSEJ>(a, prob_b, paired, true, false, LB, SIG, false, te - NE);
-  }
+  const int prob = (int)blockIdx.x;
+  Lds<NB> L;
+  L.carve(smem);
+  double* SIG = smem + g::PROB;
+  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
+  if (wave < kNPW) p_role<METHOD, FWD, NB>(a, prob, L, wave, lane);
+  else e_role<METHOD, FWD, NB, kNE, DENSEJ>(a, prob, L, SIG, tid - 64 * kNPW);
 }
 
-template <int METHOD, bool FWD, int NB, int NPROB>
-hipError_t launch_nb_p(const OdeArgs& a, int nwg, int npair, hipStream_t st) {
-  constexpr size_t lds = Geo<NB>::lds_doubles(NPROB) * sizeof(double);
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  const bool dense = !FWD && a.js_dense;
-  auto kern = dense ? k_ode_pe<METHOD, FWD, NB, NPROB, true> : k_ode_pe<METHOD, FWD, NB, NPROB, false>;
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * (kNPW + 4)), lds, st, a, npair);
-  return hipGetLastError();
-}
-
-int device_cu_count();   // ode_mfma.hip
-
-// One problem per workgroup while every problem can have a CU of its own; beyond that, pairs -- as few as needed to fit
-// the batch on the chip in one wave of workgroups, everything paired from two problems per CU on.
 template <int METHOD, bool FWD, int NB>
 hipError_t launch_nb(const OdeArgs& a, hipStream_t st) {
-  const int B = a.batch;
-  if constexpr (NB <= kMaxPairNB) {
-    const int ncu = device_cu_count();
-    const bool pairs = a.pair_mode == 2 ? (B >= 2) : (a.pair_mode == 1 ? false : B > ncu);
-    if (pairs) {
-      int nwg = (B + 1) / 2;
-      if (a.pair_mode != 2 && nwg < ncu) nwg = ncu;
-      return launch_nb_p<METHOD, FWD, NB, 2>(a, nwg, B - nwg, st);
-    }
-  }
-  return launch_nb_p<METHOD, FWD, NB, 1>(a, B, 0, st);
+  constexpr size_t lds = Geo<NB>::LDS_DOUBLES * sizeof(double);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  const bool dense = !FWD && a.js_dense;
+  auto kern = dense ? k_ode_pe<METHOD, FWD, NB, true> : k_ode_pe<METHOD, FWD, NB, false>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(a.batch), dim3(64 * kNPW + kNE), lds, st, a);
+  return hipGetLastError();
 }
 
 }  // namespace mfma

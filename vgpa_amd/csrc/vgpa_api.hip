@@ -202,7 +202,6 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
-  a.pair_mode = (c->cfg.flags & VGPA_FLAG_SINGLE_PROBLEM_WG) ? 1 : ((c->cfg.flags & VGPA_FLAG_PAIR_PROBLEMS) ? 2 : 0);
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, true, a, c->stream)
                  : use_wave(c) ? launch_ode_wave(c->cfg.method, true, a, c->stream)
                  : use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
@@ -232,7 +231,6 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
-  a.pair_mode = (c->cfg.flags & VGPA_FLAG_SINGLE_PROBLEM_WG) ? 1 : ((c->cfg.flags & VGPA_FLAG_PAIR_PROBLEMS) ? 2 : 0);
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
   else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, false, a, c->stream)

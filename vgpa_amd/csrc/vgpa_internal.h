@@ -16,7 +16,6 @@ constexpr int kMaxTheta = 4;
 // Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
 struct OdeArgs {
   int D, Np, batch;
-  int pair_mode;         // MFMA stepping kernels: 0 = by batch size, 1 = one problem per workgroup, 2 = two per workgroup
   size_t strideA, strideB;  // elements between consecutive problems in A / b (x layout: len_x for both)
   double dt;
   // forward
