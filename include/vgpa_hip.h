@@ -217,6 +217,44 @@ int vgpa_ld_gemm(void* stream, int transa, int M, int N, int K, const double* A0
                  const double* B, int ldb, double* C, int cw);
 int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* args);
 
+/* row-sharded recursion for large D on the GPUs of one node (BASELINE configs[4]) ------------------
+ * One vgpa_shard per process / GPU.  Rank p of `world` owns rows [p D/world, (p+1) D/world) of S_t / Psi_t inside every
+ * Runge-Kutta stage and the contiguous slice [t_lo, t_hi) of the TIME grid of the results (vgpa_shard_time_slice): the
+ * whole step / stage loop of src/numerics/{euler,heun,runge_kutta2,runge_kutta4}.py:solve_fwd / solve_bwd runs inside
+ * vgpa_shard_solve_* with two collectives per stage enqueued on the shard's stream between the kernels (an all-to-all of
+ * the packed product blocks, one grouped all-gather of the next stage state's row blocks + vector entries) and no host
+ * synchronisation.  The collectives come through a vgpa_comm table: vgpa_rccl_comm_create fills it from librccl
+ * (dlopen'ed; rank 0 calls vgpa_rccl_unique_id and the host runtime -- MPI, torch.distributed, a file -- hands the 128
+ * bytes to the other ranks), tests inject their own.  All pointers are DEVICE pointers; inputs are replicated on every
+ * rank ([Np][D][D] / [Np][D], same meaning as vgpa_solve_fwd / vgpa_solve_bwd), outputs hold only the rank's own grid
+ * points: m_own [t_hi - t_lo][D], S_own [t_hi - t_lo][D][D].  D must be a multiple of `world`; symmetric S0 / Sigma /
+ * dEsde_dS / jumps as for every D > 64 path.  Calls return when the work is ENQUEUED (vgpa_shard_synchronize waits). */
+typedef struct vgpa_comm {
+  void* user;
+  /* recv[q * count .. (q+1) * count) = send of rank q; send may be recv + rank * count (in place) */
+  int (*all_gather)(void* user, const double* send, double* recv, uint64_t count, void* stream);
+  /* chunk q of send goes to rank q, chunk q of recv comes from rank q; count doubles per chunk */
+  int (*all_to_all)(void* user, const double* send, double* recv, uint64_t count, void* stream);
+  int (*group_begin)(void* user);      /* optional (may be NULL): fuse the calls up to group_end into one launch */
+  int (*group_end)(void* user);
+} vgpa_comm;
+typedef struct vgpa_shard vgpa_shard;
+int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_pts, int rank, int world, int device,
+                      const vgpa_comm* comm_or_null_if_world_1, void* stream_or_null);
+void vgpa_shard_destroy(vgpa_shard* s);
+int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi);
+void* vgpa_shard_stream(vgpa_shard* s);
+int vgpa_shard_synchronize(vgpa_shard* s);
+int vgpa_shard_solve_fwd(vgpa_shard* s, const double* lin_a, const double* off_b, const double* m0, const double* s0,
+                         const double* sigma, double* m_own, double* s_own);
+int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde_dm, const double* desde_ds,
+                         const double* deobs_dm, const double* deobs_ds, double* lam_own, double* psi_own);
+/* RCCL behind the vgpa_comm table: collectives over xGMI; the library is dlopen'ed on first use */
+#define VGPA_RCCL_UNIQUE_ID_BYTES 128
+int vgpa_rccl_unique_id(void* out_128_bytes);
+int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_128_bytes, int rank, int world, int device);
+void vgpa_rccl_comm_destroy(vgpa_comm* comm);
+
 /* timing of the stepping kernel on the context's stream (HIP events), for bench.py's roofline */
 int vgpa_profile_begin(vgpa_ctx* ctx);
 int vgpa_profile_end(vgpa_ctx* ctx, double* fwd_ms, double* energy_ms, double* bwd_ms,

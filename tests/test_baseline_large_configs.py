@@ -132,39 +132,8 @@ def test_config4_fused_sweep_at_d1024():
 
 def test_config5_row_sharded_recursion_at_d4096_eight_ranks():
     """BASELINE configs[4]: D = 4096, RK4, rows sharded over 8 ranks (blocks of 512 rows; 64-row GEMM tiles, packed
-    column-chunk output, all-to-all + all-gather per stage).  Eight virtual ranks share the one GPU of the test box;
-    one forward and one backward RK4 step against the unsharded oracle."""
-    import threading
-    import torch
-    from vgpa_amd.large_d import ShardedRecursion
-    from test_large_d import make_inputs, _ThreadComm
-    d, n, world = 4096, 2, 8
-    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
-    js[0] = 0.5 * np.eye(d)                                     # a jump on the one backward step
-    jm[0] = 1.0
-    mt_o, st_o = vo.solve_fwd("rk4", 0.01, False, a, b, m0, s0, sigma)
-    lam_o, psi_o = vo.solve_bwd("rk4", 0.01, False, a, gm, gs, jm, js)
-    comm = _ThreadComm(world)
-    errs, fails = [None] * world, []
-
-    def run(rank):
-        try:
-            torch.cuda.set_device(0)
-            rec = ShardedRecursion("rk4", 0.01, d, comm=comm.view(rank))
-            assert rec.world == world and rec.Mp == 512 and rec.row0 == 512 * rank
-            mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
-            lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
-            torch.cuda.synchronize()
-            errs[rank] = max(rel_err(mt.cpu().numpy(), mt_o), rel_err(st.cpu().numpy(), st_o),
-                             rel_err(lam.cpu().numpy(), lam_o), rel_err(psi.cpu().numpy(), psi_o))
-        except BaseException as exc:      # noqa: BLE001 - a dead thread would leave the others at the barrier
-            fails.append(exc)
-            comm.barrier.abort()
-
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=600)
-    assert not fails, fails
-    assert all(e is not None and e < TOL for e in errs), errs
+    column-chunk output, all-to-all + grouped all-gather per stage) on the NATIVE driver (vgpa_shard_solve_fwd / _bwd: the
+    step / stage loop and the collectives inside libvgpa_hip.so).  Eight virtual ranks share the one GPU of the test box;
+    one forward and one backward RK4 step; every rank's time slice against the unsharded oracle."""
+    from test_large_d import _run_native_virtual_ranks
+    _run_native_virtual_ranks("rk4", 4096, 2, 8)

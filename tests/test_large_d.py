@@ -360,3 +360,141 @@ def test_library_gemm_backend_of_the_stage_product(method):
         assert abs(f - f_h) <= 1e-12 * abs(f_h) and rel_err(g, g_h) < 1e-11
         ctx.close()
     own.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The native driver: step / stage loop and collectives inside libvgpa_hip.so (vgpa_shard_*).
+class _CallbackComm:
+    """`world` virtual ranks in threads of ONE process sharing one GPU: a vgpa_comm table whose collectives are
+    barrier-ordered device copies (hipMemcpyAsync through ctypes).  Exercises the C++ driver's schedule, pointer
+    arithmetic and in-place gathers; RCCL itself sits behind the same table (tests/test_large_d.py::test_rccl_*)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.send = [None] * world
+        self.hip = ctypes_hip()
+
+    def table(self, rank):
+        import ctypes
+        from vgpa_amd._lib import VgpaComm, COMM_COLLECTIVE, COMM_GROUP
+        hip, world = self.hip, self.world
+
+        def publish(send, stream):
+            hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+            self.send[rank] = send
+            self.barrier.wait()
+
+        def finish(stream):
+            hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+            self.barrier.wait()
+
+        def all_gather(user, send, recv, count, stream):
+            publish(send, stream)
+            for q in range(world):
+                if q != rank or send != recv + rank * count * 8:
+                    hip.hipMemcpyAsync(ctypes.c_void_p(recv + q * count * 8), ctypes.c_void_p(self.send[q]),
+                                       ctypes.c_size_t(count * 8), 3, ctypes.c_void_p(stream))
+            finish(stream)
+            return 0
+
+        def all_to_all(user, send, recv, count, stream):
+            publish(send, stream)
+            for q in range(world):
+                hip.hipMemcpyAsync(ctypes.c_void_p(recv + q * count * 8), ctypes.c_void_p(self.send[q] + rank * count * 8),
+                                   ctypes.c_size_t(count * 8), 3, ctypes.c_void_p(stream))
+            finish(stream)
+            return 0
+
+        t = VgpaComm()
+        t._keep = (COMM_COLLECTIVE(all_gather), COMM_COLLECTIVE(all_to_all))      # keep the thunks alive
+        t.user, t.all_gather, t.all_to_all = None, t._keep[0], t._keep[1]
+        t.group_begin, t.group_end = COMM_GROUP(), COMM_GROUP()
+        return t
+
+
+def ctypes_hip():
+    """ctypes handle of the HIP runtime THIS process already uses (torch bundles its own copy: a second one would not
+    know the streams of the first)."""
+    import ctypes
+    import torch  # noqa: F401
+    import vgpa_amd
+    vgpa_amd.load()
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    if not paths:
+        raise RuntimeError("HIP runtime not loaded")
+    return ctypes.CDLL(paths[0])
+
+
+def _run_native_virtual_ranks(method, d, n, world):
+    import threading
+    import torch
+    from vgpa_amd.large_d import NativeShardedRecursion
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
+    mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
+    lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
+    comm = _CallbackComm(world)
+    errs, fails, slices = [None] * world, [], [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            rec = NativeShardedRecursion(method, 0.01, d, n, rank=rank, world=world, device=0, comm=comm.table(rank))
+            lo, hi = rec.time_slice
+            slices[rank] = (lo, hi)
+            mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
+            lam, psi = rec.solve_bwd(a, gm, gs, jm, js)
+            e = 0.0
+            if hi > lo:
+                e = max(rel_err(mt.cpu().numpy(), mt_o[lo:hi]), rel_err(st.cpu().numpy(), st_o[lo:hi]),
+                        rel_err(lam.cpu().numpy(), lam_o[lo:hi]), rel_err(psi.cpu().numpy(), psi_o[lo:hi]))
+            errs[rank] = e
+            rec.close()
+        except BaseException as exc:      # noqa: BLE001 - a dead thread would leave the others at the barrier
+            fails.append(exc)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not fails, fails
+    assert all(e is not None and e < TOL for e in errs), errs
+    # the owners' slices tile the grid
+    assert slices[0][0] == 0 and slices[-1][1] == n and all(slices[r][1] == slices[r + 1][0] for r in range(world - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+@pytest.mark.parametrize("d,n,world", [(128, 7, 2), (192, 6, 4), (96, 5, 3), (80, 9, 1)])
+def test_native_sharded_driver_with_virtual_ranks(method, d, n, world):
+    """vgpa_shard_solve_fwd / _bwd (C++ step / stage loop + collectives through vgpa_comm): every virtual rank's time slice
+    must equal the unsharded oracle; also with more ranks than some slices have grid points."""
+    _run_native_virtual_ranks(method, d, n, world)
+
+
+@pytest.mark.gpu
+def test_rccl_table_single_rank():
+    """librccl behind vgpa_comm: unique id through the C ABI, communicator of one rank on this GPU, a grouped in-place
+    all-gather and an all-to-all through the table's function pointers."""
+    import ctypes
+    import torch
+    from vgpa_amd._lib import load, VgpaComm
+    lib = load()
+    uid = (ctypes.c_char * 128)()
+    assert lib.vgpa_rccl_unique_id(uid) == 0
+    comm = VgpaComm()
+    assert lib.vgpa_rccl_comm_create(ctypes.byref(comm), uid, 0, 1, 0) == 0
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert comm.group_begin(comm.user) == 0
+    assert comm.all_gather(comm.user, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), 1000, stream) == 0
+    assert comm.group_end(comm.user) == 0
+    assert comm.all_to_all(comm.user, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), 1000, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and float(x[999]) == 999.0
+    lib.vgpa_rccl_comm_destroy(ctypes.byref(comm))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4]: Lorenz-96-sized recursions at D = 4096, RK4, S_t / Psi_t ROW-SHARDED over the GPUs of one node
-with one all-to-all + one all-gather (RCCL over xGMI) per RK stage (vgpa_amd/large_d.py).
+with one all-to-all + one grouped all-gather (RCCL over xGMI) per RK stage, the whole step / stage loop and the
+collectives inside libvgpa_hip.so (vgpa_shard_solve_fwd / _bwd, vgpa_amd/csrc/large_d.hip).
 
     python tools/bench_config5.py [--dim 4096] [--np 11] [--reps 2]                               # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -33,7 +34,7 @@ def main():
     import torch
     import torch.distributed as dist
     from vgpa_amd import parallel as par
-    from vgpa_amd.large_d import ShardedRecursion
+    from vgpa_amd.large_d import NativeShardedRecursion
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -57,7 +58,8 @@ def main():
     for t in range(3, n, 4):
         js[t] = 0.5 * torch.eye(d, **f64)
         jm[t] = torch.randn(d, generator=gen, **f64)
-    rec = ShardedRecursion(args.method, dt, d)
+    rec = NativeShardedRecursion(args.method, dt, d, n, rank=rank, world=world, device=local_rank)
+    t_lo, t_hi = rec.time_slice
 
     def barrier():
         if world > 1:
@@ -76,7 +78,16 @@ def main():
         mt, st, lam, psi = once()
     barrier()
     elapsed = par.max_over_ranks((time.perf_counter() - t0) / args.reps, device="cuda")
-    chk = [float(st[-1].abs().sum()), float(psi[0].abs().sum()), float((st[-1] - st[-1].T).abs().max())]
+    # every rank holds its own time slice: the last grid point of S lives on the last rank, Psi_0 on rank 0
+    chk_t = torch.zeros(3, **f64)
+    if t_lo <= n - 1 < t_hi:
+        chk_t[0] = st[n - 1 - t_lo].abs().sum()
+        chk_t[2] = (st[n - 1 - t_lo] - st[n - 1 - t_lo].T).abs().max()
+    if t_lo == 0 and t_hi > 0:
+        chk_t[1] = psi[0].abs().sum()
+    if world > 1:
+        dist.all_reduce(chk_t)
+    chk = [float(v) for v in chk_t]
     if rank == 0:
         stages = {"euler": 1, "heun": 2, "rk2": 2, "rk4": 4}[args.method.lower()]
         flop = 2 * (n - 1) * stages * 2.0 * d ** 3          # fwd + bwd, one D^3 product per stage (symmetry)
@@ -84,7 +95,7 @@ def main():
                           "n_gpus": world, "D": d, "Np": n, "s_per_fwd_bwd": elapsed, "steps_per_s": 2 * (n - 1) / elapsed,
                           "tflops_aggregate": flop / elapsed / 1e12, "scaling": "strong",
                           "checks": {"sum|S_T|": chk[0], "sum|Psi_0|": chk[1], "asym(S_T)": chk[2]},
-                          "collectives_per_stage": 0 if world == 1 else 2,
+                          "collectives_per_stage": 0 if world == 1 else 2, "driver": "native (vgpa_shard_*)", "history": "time-sharded",
                           "all_gather_bytes_per_rank_per_stage": 0 if world == 1 else 8 * d * d // world}))
     if world > 1:
         dist.barrier()

@@ -29,7 +29,10 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
            "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming",
-           "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x"]
+           "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x",
+           "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
+           "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
+           "vgpa_rccl_comm_destroy"]
 
 P_DOUBLE = POINTER(c_double)
 
@@ -42,6 +45,16 @@ class LdStageArgs(ctypes.Structure):
                 ("base", c_void_p), ("K1", c_void_p), ("K23", c_void_p), ("out", c_void_p), ("A0", c_void_p),
                 ("A1", c_void_p), ("x", c_void_p), ("e0", c_void_p), ("e1", c_void_p), ("jv", c_void_p),
                 ("vbase", c_void_p), ("k1v", c_void_p), ("k23v", c_void_p), ("vout", c_void_p)]
+
+
+COMM_COLLECTIVE = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p)
+COMM_GROUP = ctypes.CFUNCTYPE(c_int, c_void_p)
+
+
+class VgpaComm(ctypes.Structure):
+    """vgpa_comm (include/vgpa_hip.h): the collectives of the row-sharded recursion as a table of function pointers."""
+    _fields_ = [("user", c_void_p), ("all_gather", COMM_COLLECTIVE), ("all_to_all", COMM_COLLECTIVE),
+                ("group_begin", COMM_GROUP), ("group_end", COMM_GROUP)]
 
 
 class VgpaConfig(ctypes.Structure):
@@ -100,6 +113,20 @@ def load():
     lib.vgpa_ld_stage.argtypes = [c_void_p, POINTER(LdStageArgs)]
     lib.vgpa_gradient_dev.argtypes = [c_void_p, c_void_p]
     lib.vgpa_release_x.argtypes = [c_void_p]
+    lib.vgpa_shard_create.argtypes = [POINTER(c_void_p), c_int, c_double, c_int, c_int, c_int, c_int, c_int,
+                                      POINTER(VgpaComm), c_void_p]
+    lib.vgpa_shard_destroy.argtypes = [c_void_p]
+    lib.vgpa_shard_destroy.restype = None
+    lib.vgpa_shard_time_slice.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.vgpa_shard_stream.argtypes = [c_void_p]
+    lib.vgpa_shard_stream.restype = c_void_p
+    lib.vgpa_shard_synchronize.argtypes = [c_void_p]
+    lib.vgpa_shard_solve_fwd.argtypes = [c_void_p] + [c_void_p] * 7
+    lib.vgpa_shard_solve_bwd.argtypes = [c_void_p] + [c_void_p] * 7
+    lib.vgpa_rccl_unique_id.argtypes = [c_void_p]
+    lib.vgpa_rccl_comm_create.argtypes = [POINTER(VgpaComm), c_void_p, c_int, c_int, c_int]
+    lib.vgpa_rccl_comm_destroy.argtypes = [POINTER(VgpaComm)]
+    lib.vgpa_rccl_comm_destroy.restype = None
     lib.vgpa_vec_dot.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_absmax.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_asum.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]

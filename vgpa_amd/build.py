@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvgpa_hip.so")
 SOURCES = ["vgpa_api.hip", "ode_generic.hip", "ode_mfma.hip", "ode_mfma_m0.hip", "ode_mfma_m1.hip", "ode_mfma_m2.hip",
-           "ode_mfma_m3.hip", "ode_small.hip", "ode_wave.hip", "energy.hip", "assemble.hip", "large_d.hip", "large_d_energy.hip", "vecops.hip", "host_linalg.cpp", "lib_gemm.cpp"]
+           "ode_mfma_m3.hip", "ode_small.hip", "ode_wave.hip", "energy.hip", "assemble.hip", "large_d.hip", "large_d_energy.hip", "vecops.hip", "host_linalg.cpp", "lib_gemm.cpp", "sharded_rccl.cpp"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

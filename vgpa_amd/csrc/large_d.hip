@@ -650,6 +650,216 @@ hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, c
   }
   return hipSuccess;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-sharded drivers (BASELINE configs[4]): the whole per-step / per-stage loop of a rank, collectives
+// included, behind one C-ABI call.  Rank p owns rows I_p = [row0, row0 + Mp) of the stage state and of the products:
+//     W[I_p, :]  = A_s[I_p, :] . X  (forward)   |   (A_s^T)[I_p, :] . Psi  (backward)         fp64-MFMA GEMM, packed
+//     Wcol       = all_to_all(W[I_p, :])  = W[:, I_p]                                          (D^2/world^2 per peer)
+//     X'[I_p, :] = stage kernel (R = -(W + Wcol^T) + Sigma ..., RK slots, the vector recursion in the same launch)
+//     X', x'     = all_gather of the row blocks: matrix and vector in ONE group (one RCCL launch)
+// Two collectives per stage, both enqueued on the rank's stream between the kernels: no host synchronisation inside a
+// sweep.  Every rank sees the complete S_{k+1} / Psi_{t-1} after the step's last gather and keeps it only if it owns
+// that grid point: the history is TIME-sharded (contiguous slices of the grid), which is the layout the time-parallel
+// energy / gradient phase wants, at no extra communication.  The collectives come through a small table of function
+// pointers (vgpa_comm): RCCL in production (sharded.cpp: dlopen'ed librccl, unique id through the C ABI), a test
+// double in the virtual-rank tests.
+struct ShardWork {
+  double *Wp, *Wcol, *K1, *K23, *XA, *XB, *cur, *nxt, *mid, *xvA, *xvB, *vcur, *vnxt, *k1v, *k23v;
+};
+
+size_t shard_workspace_doubles(int D, int Mp) {
+  const size_t DD = (size_t)D * D, MD = (size_t)Mp * D;
+  return 5 * MD + 4 * DD + 4 * (size_t)D + 2 * (size_t)Mp + 16;
+}
+
+ShardWork carve_shard(double* ws, int D, int Mp) {
+  const size_t DD = (size_t)D * D, MD = (size_t)Mp * D;
+  ShardWork w;
+  w.Wp = ws; w.Wcol = w.Wp + MD; w.K1 = w.Wcol + MD; w.K23 = w.K1 + MD; w.mid = w.K23 + MD;
+  w.XA = w.mid + MD; w.XB = w.XA + DD; w.cur = w.XB + DD; w.nxt = w.cur + DD;
+  w.xvA = w.nxt + DD; w.xvB = w.xvA + D; w.vcur = w.xvB + D; w.vnxt = w.vcur + D;
+  w.k1v = w.vnxt + D; w.k23v = w.k1v + Mp;
+  return w;
+}
+
+// out[r][c] = 0.5 (a0[r][col0 + c] + a1[r][col0 + c]), r < rows, c < cols: the mid-point of a column block of A
+__global__ void __launch_bounds__(256) k_mid_cols(const double* __restrict__ a0, const double* __restrict__ a1, double* __restrict__ out,
+                                                  int rows, int cols, int ld, int col0) {
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols, c = i - r * cols;
+    out[i] = 0.5 * (a0[r * ld + col0 + c] + a1[r * ld + col0 + c]);
+  }
+}
+
+struct ShardCtx {
+  int method, D, rank, world, row0, Mp;
+  double dt;
+  vgpa_comm comm;
+  hipStream_t st;
+  ShardWork w;
+  const double* mid_a0 = nullptr; const double* mid_a1 = nullptr; bool mid_fwd = false;
+};
+
+#define SH_COMM(expr) do { if ((expr) != 0) return hipErrorUnknown; } while (0)
+
+static hipError_t shard_stage(ShardCtx& c, const StageSpec& s) {
+  const int D = c.D, Mp = c.Mp, row0 = c.row0;
+  const ShardWork& w = c.w;
+  GemmArgs g{};
+  g.M = Mp; g.N = D; g.K = D; g.B = s.X; g.ldb = D; g.C = w.Wp; g.cw = Mp; g.A1 = nullptr;
+  if (s.Am1) {      // mid-point operand of this rank's slab, formed once per step
+    if (c.mid_a0 != s.Am0 || c.mid_a1 != s.Am1 || c.mid_fwd != s.fwd) {
+      const size_t n = (size_t)Mp * D;
+      const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+      if (s.fwd) hipLaunchKernelGGL(k_mid, dim3(blocks), dim3(256), 0, c.st, s.Am0 + (size_t)row0 * D, s.Am1 + (size_t)row0 * D, w.mid, n);
+      else hipLaunchKernelGGL(k_mid_cols, dim3(blocks), dim3(256), 0, c.st, s.Am0, s.Am1, w.mid, D, Mp, D, row0);
+      c.mid_a0 = s.Am0; c.mid_a1 = s.Am1; c.mid_fwd = s.fwd;
+    }
+    g.A0 = w.mid; g.lda = s.fwd ? D : Mp;
+  } else {
+    g.A0 = s.fwd ? s.Am0 + (size_t)row0 * D : s.Am0 + row0;     // rows I_p of A / columns I_p of A (rows of A^T)
+    g.lda = D;
+  }
+  LD_TRY(launch_gemm(!s.fwd, g, c.st));
+  const double* wcol = w.Wp;
+  if (c.world > 1) {
+    SH_COMM(c.comm.all_to_all(c.comm.user, w.Wp, w.Wcol, (uint64_t)Mp * Mp, c.st));
+    wcol = w.Wcol;
+  }
+  StageArgs a{};
+  a.D = D; a.row0 = row0; a.Mp = Mp; a.cw = Mp; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
+  a.W = w.Wp; a.Wcol = wcol;
+  a.E0 = s.E0 + (size_t)row0 * D; a.E1 = s.E1 ? s.E1 + (size_t)row0 * D : nullptr;
+  a.J = s.J ? s.J + (size_t)row0 * D : nullptr;
+  a.base = s.base + (size_t)row0 * D; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out + (size_t)row0 * D;
+  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
+  a.e0 = s.e0 + row0; a.e1 = s.e1 ? s.e1 + row0 : nullptr; a.mid_ev = s.e1 != nullptr;
+  a.jv = s.jv ? s.jv + row0 : nullptr; a.vbase = s.vbase + row0;
+  a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout + row0;
+  LD_TRY(launch_stage(a, c.st));
+  if (c.world > 1) {      // complete the next stage state: row blocks of the matrix and of the vector, one group
+    if (c.comm.group_begin) SH_COMM(c.comm.group_begin(c.comm.user));
+    SH_COMM(c.comm.all_gather(c.comm.user, s.out + (size_t)row0 * D, s.out, (uint64_t)Mp * D, c.st));
+    SH_COMM(c.comm.all_gather(c.comm.user, s.vout + row0, s.vout, (uint64_t)Mp, c.st));
+    if (c.comm.group_end) SH_COMM(c.comm.group_end(c.comm.user));
+  }
+  return hipSuccess;
+}
+
+static void time_slice(int Np, int rank, int world, int* lo, int* hi) {
+  const int base = Np / world, rem = Np % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
+// (m_t, S_t): every rank steps the whole grid, keeps the grid points [t_lo, t_hi) it owns in m_own / S_own.
+hipError_t shard_solve_fwd(ShardCtx& c, int Np, const double* A, const double* b, const double* m0, const double* S0,
+                           const double* Sigma, double* m_own, double* S_own) {
+  const int D = c.D;
+  const size_t DD = (size_t)D * D;
+  const double dt = c.dt, h = 0.5 * dt;
+  ShardWork& w = c.w;
+  int lo, hi;
+  time_slice(Np, c.rank, c.world, &lo, &hi);
+  c.mid_a0 = c.mid_a1 = nullptr;
+  LD_TRY(hipMemcpyAsync(w.cur, S0, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
+  LD_TRY(hipMemcpyAsync(w.vcur, m0, D * sizeof(double), hipMemcpyDeviceToDevice, c.st));
+  auto keep = [&](int t, const double* S, const double* m) -> hipError_t {
+    if (t < lo || t >= hi) return hipSuccess;
+    LD_TRY(hipMemcpyAsync(S_own + (size_t)(t - lo) * DD, S, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
+    return hipMemcpyAsync(m_own + (size_t)(t - lo) * D, m, D * sizeof(double), hipMemcpyDeviceToDevice, c.st);
+  };
+  LD_TRY(keep(0, w.cur, w.vcur));
+  for (int k = 0; k < Np - 1; k++) {
+    const double *Ak = A + k * DD, *Ak1 = Ak + DD, *bk = b + (size_t)k * D, *bk1 = bk + D;
+    const double *Sk = w.cur, *mk = w.vcur;
+    double *Sn = w.nxt, *mn = w.vnxt;
+    StageSpec s{};
+    s.fwd = true; s.E0 = Sigma; s.base = Sk; s.vbase = mk;
+    auto set = [&](const double* am0, const double* am1, const double* av0, const double* av1, const double* X,
+                   const double* xv, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
+                   double cx, double cf) {
+      s.Am0 = am0; s.Am1 = am1; s.Av0 = av0; s.Av1 = av1; s.X = X; s.xv = xv; s.e0 = e0; s.e1 = e1; s.out = out;
+      s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
+    };
+    if (c.method == VGPA_ODE_EULER) {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
+    } else if (c.method == VGPA_ODE_HEUN) {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(shard_stage(c, s));
+    } else if (c.method == VGPA_ODE_RK2) {
+      set(Sk, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
+    } else {
+      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ak, Ak1, Ak, Ak1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(shard_stage(c, s));
+    }
+    LD_TRY(keep(k + 1, Sn, mn));
+    double* t1 = w.cur; w.cur = w.nxt; w.nxt = t1;
+    double* t2 = w.vcur; w.vcur = w.vnxt; w.vnxt = t2;
+  }
+  return hipSuccess;
+}
+
+// (lam_t, Psi_t) with dense jump arrays (operator level); same ownership of the grid.
+hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const double* gm, const double* gs, const double* jm,
+                           const double* js, double* lam_own, double* psi_own) {
+  const int D = c.D;
+  const size_t DD = (size_t)D * D;
+  const double dt = c.dt, h = 0.5 * dt;
+  ShardWork& w = c.w;
+  int lo, hi;
+  time_slice(Np, c.rank, c.world, &lo, &hi);
+  c.mid_a0 = c.mid_a1 = nullptr;
+  LD_TRY(hipMemsetAsync(w.cur, 0, DD * sizeof(double), c.st));
+  LD_TRY(hipMemsetAsync(w.vcur, 0, D * sizeof(double), c.st));
+  auto keep = [&](int t, const double* P, const double* l) -> hipError_t {
+    if (t < lo || t >= hi) return hipSuccess;
+    LD_TRY(hipMemcpyAsync(psi_own + (size_t)(t - lo) * DD, P, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
+    return hipMemcpyAsync(lam_own + (size_t)(t - lo) * D, l, D * sizeof(double), hipMemcpyDeviceToDevice, c.st);
+  };
+  LD_TRY(keep(Np - 1, w.cur, w.vcur));
+  for (int t = Np - 1; t > 0; t--) {
+    const double *At = A + t * DD, *Am = A + (t - 1) * DD, *Gt = gs + t * DD, *Gm = gs + (t - 1) * DD;
+    const double *gt = gm + (size_t)t * D, *gmm = gm + (size_t)(t - 1) * D;
+    const double *Jn = js + (size_t)(t - 1) * DD, *jn = jm + (size_t)(t - 1) * D;
+    const double *Pt = w.cur, *lt = w.vcur;
+    double *Pn = w.nxt, *ln = w.vnxt;
+    StageSpec s{};
+    s.fwd = false; s.base = Pt; s.vbase = lt;
+    auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
+                   const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
+                   double cx, double cf, bool jump) {
+      s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
+      s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
+      s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
+    };
+    if (c.method == VGPA_ODE_EULER) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+    } else if (c.method == VGPA_ODE_HEUN) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(shard_stage(c, s));
+    } else if (c.method == VGPA_ODE_RK2) {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+    } else {
+      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+    }
+    LD_TRY(keep(t - 1, Pn, ln));
+    double* t1 = w.cur; w.cur = w.nxt; w.nxt = t1;
+    double* t2 = w.vcur; w.vcur = w.vnxt; w.vnxt = t2;
+  }
+  return hipSuccess;
+}
+#undef SH_COMM
 #undef LD_TRY
 
 }  // namespace ld
@@ -680,6 +890,77 @@ int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* p) {
   a.e0 = p->e0; a.e1 = p->e1; a.mid_ev = p->e1 != nullptr; a.jv = p->jv; a.vbase = p->vbase;
   a.k1v = p->k1v; a.k23v = p->k23v; a.vout = p->vout;
   return ld::launch_stage(a, (hipStream_t)stream) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+// ---- row-sharded recursion behind the C ABI ------------------------------------------------------------------------
+struct vgpa_shard {
+  ld::ShardCtx c;
+  int Np = 0, device = 0;
+  double* ws = nullptr;
+  bool own_stream = false;
+};
+
+int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_pts, int rank, int world, int device,
+                      const vgpa_comm* comm, void* stream) {
+  if (!out || dim_d < 1 || n_pts < 2 || world < 1 || rank < 0 || rank >= world || !(dt > 0.0)) return VGPA_ERR_ARG;
+  if (method < VGPA_ODE_EULER || method > VGPA_ODE_RK4) return VGPA_ERR_ARG;
+  if (dim_d % world != 0) return VGPA_ERR_ARG;
+  if (world > 1 && (!comm || !comm->all_gather || !comm->all_to_all)) return VGPA_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return VGPA_ERR_DEVICE;
+  vgpa_shard* s = new vgpa_shard();
+  s->Np = n_pts; s->device = device;
+  s->c.method = method; s->c.D = dim_d; s->c.rank = rank; s->c.world = world; s->c.dt = dt;
+  s->c.Mp = dim_d / world; s->c.row0 = rank * s->c.Mp;
+  if (comm) s->c.comm = *comm; else s->c.comm = vgpa_comm{};
+  if (stream) s->c.st = (hipStream_t)stream;
+  else {
+    if (hipStreamCreateWithFlags(&s->c.st, hipStreamNonBlocking) != hipSuccess) { delete s; return VGPA_ERR_DEVICE; }
+    s->own_stream = true;
+  }
+  const size_t n = ld::shard_workspace_doubles(dim_d, s->c.Mp);
+  if (hipMalloc((void**)&s->ws, n * sizeof(double)) != hipSuccess) { if (s->own_stream) (void)hipStreamDestroy(s->c.st); delete s; return VGPA_ERR_DEVICE; }
+  (void)hipMemsetAsync(s->ws, 0, n * sizeof(double), s->c.st);
+  s->c.w = ld::carve_shard(s->ws, dim_d, s->c.Mp);
+  *out = s;
+  return VGPA_OK;
+}
+
+void vgpa_shard_destroy(vgpa_shard* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->c.st);
+  if (s->ws) (void)hipFree(s->ws);
+  if (s->own_stream) (void)hipStreamDestroy(s->c.st);
+  delete s;
+}
+
+int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi) {
+  if (!s || !t_lo || !t_hi) return VGPA_ERR_ARG;
+  ld::time_slice(s->Np, s->c.rank, s->c.world, t_lo, t_hi);
+  return VGPA_OK;
+}
+
+void* vgpa_shard_stream(vgpa_shard* s) { return s ? (void*)s->c.st : nullptr; }
+
+int vgpa_shard_synchronize(vgpa_shard* s) {
+  if (!s) return VGPA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  return hipStreamSynchronize(s->c.st) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+int vgpa_shard_solve_fwd(vgpa_shard* s, const double* lin_a, const double* off_b, const double* m0, const double* s0,
+                         const double* sigma, double* m_own, double* s_own) {
+  if (!s || !lin_a || !off_b || !m0 || !s0 || !sigma || !m_own || !s_own) return VGPA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  return ld::shard_solve_fwd(s->c, s->Np, lin_a, off_b, m0, s0, sigma, m_own, s_own) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde_dm, const double* desde_ds,
+                         const double* deobs_dm, const double* deobs_ds, double* lam_own, double* psi_own) {
+  if (!s || !lin_a || !desde_dm || !desde_ds || !deobs_dm || !deobs_ds || !lam_own || !psi_own) return VGPA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  return ld::shard_solve_bwd(s->c, s->Np, lin_a, desde_dm, desde_ds, deobs_dm, deobs_ds, lam_own, psi_own) == hipSuccess
+             ? VGPA_OK : VGPA_ERR_DEVICE;
 }
 
 }  // extern "C"

@@ -1,0 +1,127 @@
+// RCCL behind the vgpa_comm table of the row-sharded recursion (large_d.hip, include/vgpa_hip.h).
+// librccl is dlopen'ed on first use -- a copy the process already holds (torch's) is reused -- so that libvgpa_hip.so has
+// no link-time dependency on it and single-GPU users never load it.  The unique id travels through the C ABI as 128 bytes.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "vgpa_internal.h"
+
+namespace {
+
+struct UniqueId { char internal[VGPA_RCCL_UNIQUE_ID_BYTES]; };
+typedef int (*get_unique_id_t)(UniqueId*);
+typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
+typedef int (*comm_destroy_t)(void*);
+typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*send_t)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*recv_t)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*group_t)();
+constexpr int kNcclFloat64 = 8;          // ncclDataType_t (rccl.h)
+
+struct Api {
+  void* so = nullptr;
+  get_unique_id_t get_unique_id = nullptr;
+  comm_init_rank_t comm_init_rank = nullptr;
+  comm_destroy_t comm_destroy = nullptr;
+  all_gather_t all_gather = nullptr;
+  send_t send = nullptr;
+  recv_t recv = nullptr;
+  group_t group_start = nullptr, group_end = nullptr;
+  bool tried = false, ok = false;
+};
+Api g_api;
+std::mutex g_mu;
+
+bool load_api() {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_api.tried) return g_api.ok;
+  g_api.tried = true;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    g_api.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (g_api.so) break;
+  }
+  for (const char* n : names) {
+    if (g_api.so) break;
+    g_api.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!g_api.so) return false;
+  g_api.get_unique_id = (get_unique_id_t)dlsym(g_api.so, "ncclGetUniqueId");
+  g_api.comm_init_rank = (comm_init_rank_t)dlsym(g_api.so, "ncclCommInitRank");
+  g_api.comm_destroy = (comm_destroy_t)dlsym(g_api.so, "ncclCommDestroy");
+  g_api.all_gather = (all_gather_t)dlsym(g_api.so, "ncclAllGather");
+  g_api.send = (send_t)dlsym(g_api.so, "ncclSend");
+  g_api.recv = (recv_t)dlsym(g_api.so, "ncclRecv");
+  g_api.group_start = (group_t)dlsym(g_api.so, "ncclGroupStart");
+  g_api.group_end = (group_t)dlsym(g_api.so, "ncclGroupEnd");
+  g_api.ok = g_api.get_unique_id && g_api.comm_init_rank && g_api.comm_destroy && g_api.all_gather && g_api.send && g_api.recv &&
+             g_api.group_start && g_api.group_end;
+  return g_api.ok;
+}
+
+struct RcclComm {
+  void* comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+int rccl_all_gather(void* user, const double* send, double* recv, uint64_t count, void* stream) {
+  RcclComm* c = static_cast<RcclComm*>(user);
+  return g_api.all_gather(send, recv, (size_t)count, kNcclFloat64, c->comm, (hipStream_t)stream);
+}
+
+// chunk q of send -> rank q: grouped point-to-point calls, one xGMI link per peer
+int rccl_all_to_all(void* user, const double* send, double* recv, uint64_t count, void* stream) {
+  RcclComm* c = static_cast<RcclComm*>(user);
+  int rc = g_api.group_start();
+  for (int q = 0; q < c->world && rc == 0; q++) {
+    rc = g_api.send(send + (size_t)q * count, (size_t)count, kNcclFloat64, q, c->comm, (hipStream_t)stream);
+    if (rc == 0) rc = g_api.recv(recv + (size_t)q * count, (size_t)count, kNcclFloat64, q, c->comm, (hipStream_t)stream);
+  }
+  const int rc2 = g_api.group_end();
+  return rc ? rc : rc2;
+}
+
+int rccl_group_begin(void*) { return g_api.group_start(); }
+int rccl_group_end(void*) { return g_api.group_end(); }
+
+}  // namespace
+
+extern "C" {
+
+int vgpa_rccl_unique_id(void* out) {
+  if (!out) return VGPA_ERR_ARG;
+  if (!load_api()) return VGPA_ERR_UNSUPPORTED;
+  UniqueId id;
+  if (g_api.get_unique_id(&id) != 0) return VGPA_ERR_DEVICE;
+  std::memcpy(out, id.internal, VGPA_RCCL_UNIQUE_ID_BYTES);
+  return VGPA_OK;
+}
+
+int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_bytes, int rank, int world, int device) {
+  if (!out || !id_bytes || world < 1 || rank < 0 || rank >= world) return VGPA_ERR_ARG;
+  if (!load_api()) return VGPA_ERR_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return VGPA_ERR_DEVICE;
+  UniqueId id;
+  std::memcpy(id.internal, id_bytes, VGPA_RCCL_UNIQUE_ID_BYTES);
+  RcclComm* c = new RcclComm();
+  c->rank = rank; c->world = world;
+  if (g_api.comm_init_rank(&c->comm, world, id, rank) != 0) { delete c; return VGPA_ERR_DEVICE; }
+  out->user = c;
+  out->all_gather = rccl_all_gather;
+  out->all_to_all = rccl_all_to_all;
+  out->group_begin = rccl_group_begin;
+  out->group_end = rccl_group_end;
+  return VGPA_OK;
+}
+
+void vgpa_rccl_comm_destroy(vgpa_comm* comm) {
+  if (!comm || !comm->user) return;
+  RcclComm* c = static_cast<RcclComm*>(comm->user);
+  if (c->comm) (void)g_api.comm_destroy(c->comm);
+  delete c;
+  comm->user = nullptr;
+}
+
+}  // extern "C"

@@ -251,3 +251,114 @@ class ShardedRecursion:
                 self._stage(False, A, am, None, (A, am, None), XA, xvA, e0_off=am, e1_off=None, ev0=vm, ev1=None,
                             kstore=0, final_mode=3, cx=0.0, cf=dt, **common, **fin)
         return lam.reshape(n, D), psi.reshape(n, D, D)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class NativeShardedRecursion:
+    """
+    The row-sharded recursion with the whole step / stage loop AND its collectives inside libvgpa_hip.so
+    (vgpa_shard_solve_fwd / _bwd, vgpa_amd/csrc/large_d.hip): per RK stage one all-to-all of the packed product blocks and
+    one grouped all-gather (matrix row blocks + vector entries) over RCCL, enqueued on the shard's stream between the
+    kernels; no Python and no host synchronisation inside a sweep.  The results are TIME-sharded: a rank keeps only the
+    grid points [t_lo, t_hi) it owns (`time_slice`), which is the layout the time-parallel energy / gradient phase uses.
+
+    `comm`: a `_lib.VgpaComm` (tests inject one built from Python callbacks); by default RCCL, whose unique id rank 0
+    creates and torch.distributed (any backend, e.g. gloo) broadcasts.  One rank: no communicator at all.
+    `ShardedRecursion` above drives the same two kernels stage by stage from Python; it is kept as the CPU / gloo-testable
+    statement of the schedule.
+    """
+
+    def __init__(self, method, dt, dim_d, n_pts, rank=None, world=None, device=None, comm=None):
+        import torch
+        import torch.distributed as dist
+        from ._lib import VgpaComm, METHOD_IDS
+        method = str(method).lower()
+        if method not in METHODS:
+            raise ValueError(f" Integration method is unknown -> {method}.")
+        if dt <= 0.0:
+            raise ValueError(f" Discrete time step should be strictly positive -> {dt}.")
+        self._lib = load()
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = int(world if world is not None else (dist.get_world_size() if ready else 1))
+        self.rank = int(rank if rank is not None else (dist.get_rank() if ready else 0))
+        self.D, self.Np = int(dim_d), int(n_pts)
+        if self.D % self.world:
+            raise ValueError(f"D={self.D} must be a multiple of the number of ranks ({self.world})")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._comm, self._own_comm = None, False
+        if self.world > 1:
+            if comm is None:
+                comm = VgpaComm()
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    buf = (ctypes.c_char * 128)()
+                    self._check(self._lib.vgpa_rccl_unique_id(buf), "vgpa_rccl_unique_id")
+                    uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                if dist.get_backend() == "nccl":
+                    uid = uid.cuda(self.device)
+                dist.broadcast(uid, src=0)
+                raw = bytes(uid.cpu().numpy().tobytes())
+                self._check(self._lib.vgpa_rccl_comm_create(ctypes.byref(comm), raw, self.rank, self.world, self.device),
+                            "vgpa_rccl_comm_create")
+                self._own_comm = True
+            self._comm = comm
+        h = ctypes.c_void_p()
+        self._check(self._lib.vgpa_shard_create(ctypes.byref(h), METHOD_IDS[method], float(dt), self.D, self.Np, self.rank,
+                                                self.world, self.device,
+                                                ctypes.byref(self._comm) if self._comm is not None else None, None),
+                    "vgpa_shard_create")
+        self._h = h
+        lo, hi = ctypes.c_int(), ctypes.c_int()
+        self._lib.vgpa_shard_time_slice(self._h, ctypes.byref(lo), ctypes.byref(hi))
+        self.time_slice = (lo.value, hi.value)
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            _raise(rc, f"{what} failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vgpa_shard_destroy(self._h)
+            self._h = None
+        if self._own_comm and self._comm is not None:
+            self._lib.vgpa_rccl_comm_destroy(ctypes.byref(self._comm))
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.vgpa_shard_synchronize(self._h), "vgpa_shard_synchronize")
+
+    def _dev(self, a):
+        import torch
+        dev = torch.device("cuda", self.device)
+        if isinstance(a, torch.Tensor):
+            return a.to(device=dev, dtype=torch.float64).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+
+    def _run(self, fn, inputs, what):
+        import torch
+        ins = [self._dev(a) for a in inputs]
+        torch.cuda.synchronize(self.device)                       # uploads (torch's stream) before the shard's stream reads
+        n_own = self.time_slice[1] - self.time_slice[0]
+        dev = torch.device("cuda", self.device)
+        v_own = torch.empty((max(n_own, 1), self.D), dtype=torch.float64, device=dev)
+        m_own = torch.empty((max(n_own, 1), self.D, self.D), dtype=torch.float64, device=dev)
+        ptr = [ctypes.c_void_p(t.data_ptr()) for t in ins]
+        self._check(fn(self._h, *ptr, ctypes.c_void_p(v_own.data_ptr()), ctypes.c_void_p(m_own.data_ptr())), what)
+        self.synchronize()
+        return v_own[:n_own], m_own[:n_own]
+
+    def solve_fwd(self, lin_a, off_b, m0, s0, sigma):
+        """(m_t, S_t) for the grid points of `time_slice`."""
+        return self._run(self._lib.vgpa_shard_solve_fwd, (lin_a, off_b, m0, s0, sigma), "vgpa_shard_solve_fwd")
+
+    def solve_bwd(self, lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds):
+        """(lam_t, Psi_t) for the grid points of `time_slice`."""
+        return self._run(self._lib.vgpa_shard_solve_bwd, (lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds),
+                         "vgpa_shard_solve_bwd")
