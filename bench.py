@@ -47,6 +47,53 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_sweep(job):
+    """One oracle sweep in a worker process (BLAS pinned to one thread): the all-core CPU baseline runs one per core."""
+    prob, x, faithful = job
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    from oracle import vgpa_oracle as vo
+    t0 = time.perf_counter()
+    f, _, _ = vo.sweep(prob, x, faithful=faithful)
+    return time.perf_counter() - t0, float(f)
+
+
+def cpu_baseline(p, x, method, d, n_pts, dt):
+    """The numpy oracle on the host cores, BEFORE this process touches the GPU (the pool forks).  `value`: one sweep on one
+    core in the reference's operation order (faithful mode); `all_cores`: one such sweep per host core, concurrently --
+    independent problems are how the path parallelises on a CPU (a 40 x 40 sweep has nothing for BLAS threads to do)."""
+    import multiprocessing as mp
+    from oracle import vgpa_oracle as vo
+    z = dict(model="L96", method=method, dt=dt, theta=8.0, sigma=p["model"].sigma, m0=p["m0"], s0=p["s0"],
+             mu0=p["mu0"], tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"],
+             time_window=p["model"].time_window)
+    prob = vo.Problem.from_fixture({k: np.asarray(val) for k, val in z.items()})
+    t_faith, f_cpu = _cpu_sweep((prob, x, True))
+    t_lean, _ = _cpu_sweep((prob, x, False))
+    print(f"[bench] cpu baseline: one core {t_faith:.2f} s (faithful), {t_lean:.2f} s (lean)", file=sys.stderr, flush=True)
+    # (a GPU box gives one GPU's job a share of the host: 16 cores; more workers than that only time-slice)
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("VGPA_BENCH_CPU_WORKERS", "16"))))
+    all_cores = None
+    try:
+        with mp.get_context("fork").Pool(cores) as pool:
+            tw = time.perf_counter()
+            res = pool.map_async(_cpu_sweep, [(prob, x, True)] * cores).get(timeout=20.0 * t_faith + 60.0)
+            wall = time.perf_counter() - tw
+        all_cores = {"cores": cores, "value": cores / wall, "unit": "sweeps/s", "seconds": wall,
+                     "how": f"{cores} concurrent single-threaded oracle processes, one faithful sweep each",
+                     "slowest_worker_s": max(r[0] for r in res)}
+    except Exception as exc:                                  # (a box that forbids fork: keep the one-core figure)
+        all_cores = {"cores": cores, "value": None, "error": repr(exc)}
+    return {"value": 1.0 / t_faith, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"1 full sweep of the same workload (L96 D={d} Np={n_pts}), numpy oracle in faithful mode (same "
+                      f"per-step operations as the reference), one core; all_cores: one such sweep per host core",
+            "seconds": t_faith, "lean_value": 1.0 / t_lean, "lean_seconds": t_lean, "host_cores": os.cpu_count(),
+            "all_cores": all_cores, "F_cpu": f_cpu}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -54,6 +101,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # host-side inputs first (numpy only), and with them the CPU baseline: its worker pool forks, which must happen
+    # before this process initialises the GPU
+    from helpers import build_problem
+    d, n_pts, dt = args.dim, args.n_pts, 0.01
+    tf = (n_pts - 1) * dt
+    p = build_problem("L96", args.method, tf, dt, d)          # seed 31415926535: the reference's config-3 inputs
+    x0 = p["vgp"].initialization()
+    x_first = x0 + 0.05 * np.random.default_rng(0).standard_normal(x0.size)     # global problem 0
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(p, x_first, args.method, d, n_pts, dt)
+        print(f"[bench] cpu baseline: all cores {cpu['all_cores']}", file=sys.stderr, flush=True)
 
     # torch is plumbing only (process group, barrier, device sync).  It must be imported BEFORE libvgpa_hip.so
     # is loaded so that both share one HIP runtime (same SONAME, see vgpa_amd/_lib.py).
@@ -72,19 +132,14 @@ def main():
 
     import vgpa_amd as va
     from vgpa_amd._lib import FLAG_FORCE_GENERIC
-    from helpers import build_problem
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    d, n_pts, dt = args.dim, args.n_pts, 0.01
-    tf = (n_pts - 1) * dt
-    p = build_problem("L96", args.method, tf, dt, d)          # seed 31415926535: the reference's config-3 inputs
     v = p["vgp"]
     assert v.dim_n == n_pts, (v.dim_n, n_pts)
-    x0 = v.initialization()
     len_x = x0.size
     B = args.batch
     flags = FLAG_FORCE_GENERIC if args.generic else 0
@@ -185,9 +240,8 @@ def main():
     nb_blocks = (d + 3) // 4
     method_id = {"EULER": 0, "HEUN": 1, "RK2": 2, "RK4": 3}.get(args.method.upper(), 3)
     # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 44)
-    nw = 8 if nb_blocks >= 8 else 4
-    symbols = {"solve_fwd": f"vgpa::mfma::k_fwd_mfma<{method_id}, {nb_blocks}, {nw}>",
-               "solve_bwd": f"vgpa::mfma::k_bwd_mfma<{method_id}, {nb_blocks}, {nw}, false>",
+    symbols = {"solve_fwd": f"vgpa::mfma::k_ode_pe<{method_id}, true, {nb_blocks}, false>",
+               "solve_bwd": f"vgpa::mfma::k_ode_pe<{method_id}, false, {nb_blocks}, false>",
                "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():
@@ -210,8 +264,15 @@ def main():
         "config": {"workload": f"Lorenz96 D={d}, {args.method.upper()}, Np={n_pts} (BASELINE configs[2])",
                    "batch_per_gpu": B, "sharding": "independent problems per GPU, no collective",
                    "kernels": "generic" if args.generic else "mfma"},
-        "roofline": dict(roof[dom], note="kernel with the longest launch of the sweep; energy+obs phase = k_energy_l96_r + k_obs "
-                                         "(0.1 ms); all four kernels under roofline_kernels"),
+        # `value` is BATCH throughput (B independent sweeps per launch); ONE sweep -- what an SCG iteration of the reference's
+        # use case waits for -- is latency-bound on one CU:
+        "single_problem_sweeps_per_s": None if single is None else single["sweeps_per_s"],
+        "whole_sweep_frac_of_hbm": sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+        "roofline": dict(roof[dom], note=f"kernel with the longest launch of the sweep (batched, B={B}); energy+obs phase = "
+                                         f"k_energy_l96_r + k_obs (0.1 ms); all four kernels under roofline_kernels; whole "
+                                         f"sweep = {sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS:.3f} of HBM on SURVEY 8d's "
+                                         f"algorithmic bytes; single problem = "
+                                         f"{(single or {}).get('sweeps_per_s', float('nan')):.1f} sweeps/s"),
         "roofline_kernels": roof,
         "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
@@ -223,31 +284,10 @@ def main():
         "parity_check_rel_err_F": check,
     }
 
-    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
-        from oracle import vgpa_oracle as vo
-        z = dict(model="L96", method=args.method, dt=dt, theta=8.0, sigma=p["model"].sigma, m0=p["m0"], s0=p["s0"],
-                 mu0=p["mu0"], tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"],
-                 time_window=p["model"].time_window)
-        prob = vo.Problem.from_fixture({k: np.asarray(val) for k, val in z.items()})
-        # one BLAS thread: the oracle is a single Python process working on 40 x 40 matrices, `cores` = 1 is then exact
-        try:
-            from threadpoolctl import threadpool_limits
-            limiter, n_cores = threadpool_limits(limits=1), 1
-        except Exception:                                     # no threadpoolctl: report what the process may use
-            limiter, n_cores = None, len(os.sched_getaffinity(0))
-        tc = time.perf_counter()
-        f_cpu, g_cpu, _ = vo.sweep(prob, xb[0], faithful=True)
-        t_faith = time.perf_counter() - tc
-        tc = time.perf_counter()
-        vo.sweep(prob, xb[0], faithful=False)
-        t_lean = time.perf_counter() - tc
-        if limiter is not None:
-            limiter.restore_original_limits()
-        out["cpu_baseline"] = {"value": 1.0 / t_faith, "unit": "sweeps/s", "cores": n_cores, "kind": "port",
-                               "sample": f"1 full sweep of the same workload (L96 D={d} Np={n_pts}), numpy oracle in "
-                                         f"faithful mode (same per-step operations as the reference)",
-                               "seconds": t_faith, "lean_value": 1.0 / t_lean, "lean_seconds": t_lean,
-                               "gpu_vs_cpu_F_rel_err": abs(np.atleast_1d(f_last)[0] - f_cpu) / abs(f_cpu)}
+    if cpu is not None:                              # measured before the GPU work, rank 0 at N = 1 only
+        f_cpu = cpu.pop("F_cpu")
+        cpu["gpu_vs_cpu_F_rel_err"] = abs(np.atleast_1d(f_last)[0] - f_cpu) / abs(f_cpu)
+        out["cpu_baseline"] = cpu
     print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Summaries out of the SQLite files rocprofv3 (ROCm 7.2) writes by default.
+
+    python tools/rocprof_db.py stats  <results.db> <out.csv>                   # per-kernel calls / total / avg / min / max (us)
+    python tools/rocprof_db.py traffic <fetch.db> <write.db> B D Np <out.csv> <pmc_traffic.json>
+
+`traffic`: per-launch HBM bytes of the sweep kernels from two counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE) of
+`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-problem`.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950
+FETCH_SIZE reports 1/2 of streamed read bytes (MI355X_MICROARCH.md, HBM section): hbm_bytes = (2 FETCH + WRITE) * 1024,
+the maximum over the dispatches of a kernel.  The correction is checked on the forward stepping kernel, whose reads are
+exactly A and b."""
+import collections
+import json
+import re
+import sqlite3
+import sys
+
+KEYS = [(r"k_ode_pe<\d+, true", "solve_fwd"), (r"k_ode_pe<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"),
+        (r"k_grad", "grad")]
+
+
+def stats(db_path, out_csv):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                       "group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1.0
+    with open(out_csv, "w") as fh:
+        fh.write("# rocprofv3 --kernel-trace --stats (durations in us)\n")
+        fh.write("Name,Calls,TotalDurationUs,AverageUs,Percentage,MinUs,MaxUs\n")
+        for name, calls, tot, avg, mn, mx in rows:
+            fh.write('"%s",%d,%.3f,%.3f,%.4f,%.3f,%.3f\n' % (name, calls, tot / 1e3, avg / 1e3, 100.0 * tot / total, mn / 1e3, mx / 1e3))
+    for r in rows[:8]:
+        print("%-70s calls %4d  avg %10.3f us" % (r[0][:70], r[1], r[3] / 1e3))
+
+
+def per_dispatch(db_path, counter):
+    cur = sqlite3.connect(db_path).cursor()
+    acc, name, grid = collections.defaultdict(float), {}, {}
+    for did, kname, g, val in cur.execute("select dispatch_id, kernel_name, grid_size, value from counters_collection "
+                                          "where counter_name = ?", (counter,)):
+        acc[did] += float(val)
+        name[did], grid[did] = kname, g
+    out = collections.defaultdict(list)
+    for d, v in acc.items():
+        out[name[d]].append((v, grid[d]))
+    return out
+
+
+def traffic(fetch_db, write_db, B, D, Np, out_csv, out_json):
+    B, D, Np = int(B), int(D), int(Np)
+    f, w = per_dispatch(fetch_db, "FETCH_SIZE"), per_dispatch(write_db, "WRITE_SIZE")
+    rows, res = [], {}
+    for kname, vals in sorted(f.items()):
+        short = next((v for k, v in KEYS if re.search(k, kname)), None)
+        if short is None:
+            continue
+        fv, grid = max(vals)
+        wv = max(w.get(kname, [(0.0, "")]))[0]
+        hbm = (2.0 * fv + wv) * 1024.0
+        rows.append((kname, grid, len(vals), fv, wv, hbm))
+        res[f"{short}_B{B}_D{D}_Np{Np}"] = hbm
+    with open(out_csv, "w") as fh:
+        fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 "
+                 f"--batch {B} --no-cpu-baseline --no-single-problem\n"
+                 "# KB per dispatch (max over dispatches); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
+        exp = B * Np * (D * D + D) * 8.0
+        cal = [r for r in rows if re.search(KEYS[0][0], r[0])]
+        if cal:
+            fh.write(f"# calibration: forward stepping kernel reads A and b = {exp:.4e} B; 2*FETCH_SIZE*1024 = {2.0 * cal[0][3] * 1024.0:.4e} B\n")
+        fh.write("kernel,grid_size,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected\n")
+        for r in rows:
+            fh.write('"%s",%s,%d,%.1f,%.1f,%.0f\n' % r)
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        traffic(*sys.argv[2:9])
