@@ -11,12 +11,8 @@
 //         matrix (quirk Q1) is reproduced exactly.
 #include "vgpa_internal.h"
 
-#ifndef VGPA_L96_NOK
 #define VGPA_L96_NOK 0
-#endif
-#ifndef VGPA_L96_NOPANEL
 #define VGPA_L96_NOPANEL 0
-#endif
 
 namespace vgpa {
 namespace {
@@ -317,11 +313,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
   const size_t o = (size_t)prob * a.Np + t;
   L96Lds S;
-#ifdef VGPA_L96_ALIAS   // diagnostic build only (WRONG results): one matrix in LDS, to measure what the occupancy would buy
-  S.Lm = smem; S.Gm = S.Lm; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
-#else
   S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
-#endif
   S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
   const double* St = a.S + o * D * D;
@@ -419,9 +411,6 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     return;
   }
 
-#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 1
-  return;
-#endif
   // inverses of the 4x4 diagonal blocks of L (lane I < NB), used by the blocked forward substitution of phase 4
   double* xdiag = S.vv + (2 * D + 1) + 7;
   if (l < NB) {
@@ -458,9 +447,6 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   }
   wave_sync();
 
-#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 2
-  return;
-#endif
   // ---- 3. v_p.  Lane j < D evaluates BOTH sigma points of column j (p = 1+j: m + L[:,j] and p = 1+D+j: m - L[:,j]) in
   //         one sequential pass over i -- they share every LDS operand; the mean point p = 0 is evaluated in parallel
   //         over i.  chi(p, i) = m_i + sgn_p L[i][col_p]; the flat np.roll of the reference (quirk Q1) makes the
@@ -535,9 +521,6 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   if (l == 0) a.e_t[o] = e_t;
   wave_sync();
 
-#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 3
-  return;
-#endif
   // ---- 4. X = L^-1 into Gm by blocked forward substitution on the matrix cores: for block-row I and the unit of column
   //         blocks J_b = 4u + b:  T_b = sum_{K < I} L[I][K] . X[K][J_b] accumulates in the MFMA result register, which is
   //         already laid out as the B-operand of the second product X[I][J_b] = -inv(L[I][I]) . T_b.
@@ -567,9 +550,6 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     wave_sync();
   }
 
-#if defined(VGPA_L96_STOP) && VGPA_L96_STOP <= 4
-  return;
-#endif
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
@@ -760,9 +740,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     return;
   }
 
-#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 1
-  return;
-#endif
   // ---- 2. A.m and G = A.L on the matrix cores, results stay in the accumulators (row 16u + 4b + r4, column 4J + c4)
   double amr[NUU], gacc[NUU][NB];
 #pragma unroll
@@ -790,9 +767,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     if (c4 == 0 && i < D) { S.am[i] = amr[u]; if (a.Am) a.Am[o * D + i] = amr[u]; }
   }
 
-#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 2
-  return;
-#endif
   // ---- 3. residuals of the sigma points m +- L[:, j] in accumulator layout, rows 2 .. D-2
   // park rows 0, 1, D-1 of G for the boundary pass first (only the units that can hold them: compile-time test), so
   // that the residual loop below is ONE basic block (with branches in between, the compiler sinks all the arithmetic
@@ -931,9 +905,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   }
   wave_sync();
 
-#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 4
-  return;
-#endif
   // ---- 4. X = L^-1 IN PLACE by blocked forward substitution on the matrix cores (see k_energy_l96): block-row I of X
   //         overwrites block-row I of L, which only step I reads; LDS operations of one wave execute in order.
   const double* l4_a = S.Lm + c4 * LD + r4;
@@ -969,9 +940,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     wave_sync();
   }
 
-#if defined(VGPA_R_STOP) && VGPA_R_STOP <= 5
-  return;
-#endif
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
@@ -999,469 +967,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   if (a.Edf) {
     double* ed = a.Edf + o * D * D;
     for (int e = l; e < D * D; e += 64) {
-      const int k = e / D, j = e - k * D;
-      const int kp1 = wrap(k + 1, D), km1 = wrap(k - 1, D), km2 = wrap(k - 2, D);
-      double v = 0.0;
-      if (j == k) v = -1.0;
-      if (j == kp1) v = S.mv[km1];
-      if (j == km2) v = -S.mv[km1];
-      if (j == km1) v = S.mv[kp1] - S.mv[km2];
-      ed[e] = v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-//  Lorenz-96, FOUR waves per grid point (256-thread workgroups).  Same algebra, same LDS layout and the same two
-//  sequential phases (Cholesky panels, forward substitution for L^-1: wave 0) as k_energy_l96; everything that has
-//  parallelism inside one grid point is spread over the four waves:
-//    staging            all 256 threads, every HBM load in flight at once
-//    G = A.L, SYRK      wave w owns the block-rows w, w+4, ... of the 4x4-blocked result (v_mfma_f64_4x4x4_4b)
-//    residuals          wave w evaluates rows i in [w Q, (w+1) Q) of both sigma points of column `lane`
-//  The task latency drops from ~36 k to ~25 k cycles and the LDS a task occupies is shared by four waves instead of one,
-//  so a CU holds 20 waves (5 tasks) instead of 5.
-// ------------------------------------------------------------------------------------------------
-// X^T diag(q) X for the block-rows W, W+4, ... of one wave (W compile-time: blocks with k < i or k < j are skipped at
-// compile time).  pa: A-operand base (X [k][i], lane offset r4*LD + c4 applied), px: B-operand base (lane offset r4*LD).
-template <int NB, int W>
-__device__ __forceinline__ void l96_syrk_rows(const double* __restrict__ pa, const double* __restrict__ px,
-                                              const double* __restrict__ qr4, int LD, int colq, int coll, int b,
-                                              double (&acc)[(NB / 4 > 0 ? NB / 4 : 1) * ((NB + 3) / 4)],
-                                              double (&accl)[((NB % 4) ? (((NB + (4 / (NB % 4)) - 1) / (4 / (NB % 4))) + 3) / 4 : 1)]) {
-  constexpr int NQ = NB / 4, REM = NB % 4, G = REM ? 4 / REM : 0;
-  constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
-  constexpr int RW = (NB + 3) / 4, LW = (NLEFT + 3) / 4;
-  constexpr int rem = REM ? REM : 1;
-#pragma unroll
-  for (int u = 0; u < (NQ > 0 ? NQ : 1) * RW; u++) acc[u] = 0.0;
-#pragma unroll
-  for (int u = 0; u < (LW > 0 ? LW : 1); u++) accl[u] = 0.0;
-#pragma unroll
-  for (int kk = 0; kk < NB; kk++) {
-    const double qk = qr4[4 * kk];
-    double bq[NQ > 0 ? NQ : 1];
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-      if (kk >= 4 * q) bq[q] = qk * px[kk * 4 * LD + 16 * q + colq];
-    double bl = 0.0;
-    if (NLEFT > 0 && kk >= 4 * NQ) bl = qk * px[kk * 4 * LD + coll];
-#pragma unroll
-    for (int ii = 0; ii < RW; ii++) {
-      constexpr int dummy = 0; (void)dummy;
-      const int I = W + 4 * ii;
-      if (NQ > 0 && I < NB && kk >= I) {
-        const double af = pa[kk * 4 * LD + 4 * I];
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-          if (kk >= 4 * q) acc[q * RW + ii] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * RW + ii], 0, 0, 0);
-      }
-    }
-    if (NLEFT > 0 && kk >= 4 * NQ) {
-#pragma unroll
-      for (int vv = 0; vv < LW; vv++) {
-        const int v = W + 4 * vv;
-        if (v < NLEFT && kk >= v * G) {
-          int ib = v * G + b / rem;
-          ib = ib < NB ? ib : NB - 1;
-          const double af = pa[kk * 4 * LD + 4 * ib];
-          accl[vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bl, accl[vv], 0, 0, 0);
-        }
-      }
-    }
-  }
-}
-
-// two matrices + 7 vectors + vv[1 + Dp] (v_0, r0^2) + vpart[8][Dp] + xdiag[NB][16]: 4089 doubles at D = 40, i.e. five
-// tasks per CU (5 x 32 KB = 160 KB)
-__host__ __device__ inline size_t l96w4_lds_doubles(int D) {
-  const size_t dp = l96_dp(D);
-  return 2 * dp * l96_ld(D) + 7 * dp + (dp + 1) + 8 * dp + 4 * dp;
-}
-
-template <int NB>
-__global__ void __launch_bounds__(NT) k_energy_l96_w4(EnergyArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int s_bad;
-  const int D = a.D, M = 2 * D + 1;
-  constexpr int Dp = 4 * NB, LD = Dp + 1;
-  constexpr int NQ = NB / 4, REM = NB % 4, G = REM ? 4 / REM : 0;
-  constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
-  constexpr int RW = (NB + 3) / 4, LW = (NLEFT + 3) / 4;
-  constexpr int rem = REM ? REM : 1;
-  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
-  const long long wid = blockIdx.x;
-  const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
-  const size_t o = (size_t)prob * a.Np + t;
-  L96Lds S;
-  S.Lm = smem; S.Gm = S.Lm + Dp * LD; S.mv = S.Gm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = S.am + Dp;
-  S.dl = S.sg + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
-  double* vpart = S.vv + (Dp + 1);                 // [2][4][Dp] partial residual sums of the four waves
-  double* xdiag = vpart + 8 * Dp;                  // [NB][4][4] inverses of the diagonal blocks of L
-  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
-  const double* St = a.S + o * D * D;
-  const double theta = a.theta[0];
-  const double kappa = 1.05 * D, c = D + kappa;
-  const bool act = l < D, pad = l < Dp;
-  const int li = pad ? l : Dp - 1;
-  const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
-
-  // ---- 0. stage c*S and A^T into LDS: every HBM load of the workgroup is issued before the first is consumed
-  constexpr int EPT = (Dp * Dp + NT - 1) / NT;
-  {
-    const int DD = D * D;
-    double sv[EPT], av[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; q++) {
-      const int e = tid + q * NT;
-      const bool in = e < DD;
-#if defined(VGPA_W4_NOMEM)   // diagnostic build only: synthetic operands instead of the HBM reads (wrong results)
-      sv[q] = in ? ((e % (D + 1)) == 0 ? 2.0 : 0.001) : 0.0;
-      av[q] = in ? 0.01 * (double)(e & 7) : 0.0;
-#else
-      sv[q] = in ? St[e] : 0.0;
-      av[q] = in ? At[e] : 0.0;
-#endif
-    }
-    if (tid == 0) s_bad = 0;
-    if (D < Dp) {
-      for (int e = tid; e < Dp * LD; e += NT) { S.Lm[e] = 0.0; S.Gm[e] = 0.0; }
-      __syncthreads();
-    }
-    const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;
-#pragma unroll
-    for (int q = 0; q < EPT; q++) {
-      const int e = tid + q * NT;
-      if (e < DD) {
-        const int r = (int)(((unsigned)e * magic) >> 20), cc = e - r * D;
-        S.Lm[r * LD + cc] = c * sv[q];
-        S.Gm[cc * LD + r] = av[q];                 // A^T: operand layout [k][i] of the MFMA product
-      }
-    }
-    if (tid < Dp) {
-      const bool in = tid < D;
-      S.mv[tid] = in ? a.m[o * D + tid] : 0.0;
-      S.bv[tid] = in ? a.b[(size_t)prob * a.strideB + (size_t)t * D + tid] : 0.0;
-      S.sg[tid] = in ? a.isg[tid] : 0.0;
-      S.am[tid] = 0.0; S.dl[tid] = 0.0; S.qq[tid] = 0.0; S.rd[tid] = 1.0;
-      if (!in) S.Lm[tid * LD + tid] = 1.0;
-    }
-  }
-  __syncthreads();
-
-#if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 0
-  return;
-#endif
-  // ---- 1. Cholesky, left-looking in panels of four columns.  Per panel p:
-  //   (a) every wave: U = L[4p:, :4p] . L[4p:4p+4, :4p]^T on the matrix cores -- wave w owns the block-rows
-  //       p + 4w + b (b = block of the 4x4x4_4b instruction) -- subtracted from the panel in place;
-  //   (b) wave 0: the four pivots of the panel (lane = row; the 40-pivot chain is the sequential part).
-  for (int p = 0; p < NB; p++) {
-    if (p > 0) {
-      if (p + 4 * wave < NB) {                               // wave-uniform: this wave has a block-row in the panel
-        const int Ib = p + 4 * wave + b;
-        const bool rowok = Ib < NB;
-        const int Ic = rowok ? Ib : NB - 1;
-        const double* arow = S.Lm + (4 * Ic + c4) * LD + r4;  // A-operand [i][k] = L[4I + i][4kk + k]
-        const double* brow = S.Lm + (4 * p + c4) * LD + r4;   // B-operand [k][j] = L[4p + j][4kk + k]
-        double u = 0.0;
-        for (int kk = 0; kk < p; kk++) u = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * kk], brow[4 * kk], u, 0, 0, 0);
-        if (rowok) S.Lm[(4 * Ib + r4) * LD + 4 * p + c4] -= u;   // D[i = r4][j = c4] of block b
-      }
-      __syncthreads();
-    }
-    if (wave == 0) {
-      const int j0 = 4 * p;
-      const double* rowi = S.Lm + li * LD;
-      const double sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
-      double lq[4];
-      bool bad = false;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int j = j0 + q;
-        double sx = sq[q];
-#pragma unroll
-        for (int q2 = 0; q2 < q; q2++) sx = __builtin_fma(-lq[q2], lane_value(lq[q2], j), sx);
-#if defined(VGPA_W4_FAKE_LANE)
-        const double piv = sx + 1.0;
-#else
-        const double piv = lane_value(sx, j);
-#endif
-#if !defined(VGPA_W4_FAKE_LANE) && !defined(VGPA_W4_FAKE_RSQ)
-        if (!(piv > 0.0)) bad = true;
-#endif
-#if defined(VGPA_W4_FAKE_RSQ)
-        const double rdv = piv * 0.1, dg = piv * rdv;
-#else
-        const double rdv = rsqrt(piv), dg = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
-#endif
-        lq[q] = (l > j) ? sx * rdv : 0.0;
-        if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? dg : 0.0);
-        if (l == j) S.rd[j] = rdv;
-      }
-      if (bad && l == 0) s_bad = 1;
-    }
-    __syncthreads();
-    if (s_bad) break;
-  }
-  // inverses of the 4x4 diagonal blocks of L (lane I < NB of wave 0; read after the next workgroup barrier)
-  if (!s_bad && tid < NB) {
-    const double* tb = S.Lm + (4 * tid) * LD + 4 * tid;
-    const double x00 = S.rd[4 * tid], x11 = S.rd[4 * tid + 1], x22 = S.rd[4 * tid + 2], x33 = S.rd[4 * tid + 3];
-    const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
-    const double x10 = -(t10 * x00) * x11;
-    const double x21 = -(t21 * x11) * x22;
-    const double x32 = -(t32 * x22) * x33;
-    const double x20 = -(t20 * x00 + t21 * x10) * x22;
-    const double x31 = -(t31 * x11 + t32 * x21) * x33;
-    const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
-    double* xo = xdiag + 16 * tid;
-    xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
-    xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
-    xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
-    xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
-  }
-  __syncthreads();
-  if (s_bad) {
-    // S_t is not positive definite: the reference raises LinAlgError from chol_inv(S_t) (variational.py:380)
-    if (tid == 0) atomicOr(a.status + prob, 1);
-    return;
-  }
-
-#if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 1
-  return;
-#endif
-  // ---- 2. G = A.L on the matrix cores (wave w: block-rows w, w+4, ...); A.m by wave 3 (it owns the fewest rows)
-  const double* pa = S.Gm + r4 * LD + c4;           // A-operand [k][i] (A^T now, X = L^-1 later)
-  const double* pb = S.Lm + r4 * LD;                // B-operand [k][j]
-  const int colq = l & 15;
-  const int coll = 4 * (4 * NQ + b % rem) + c4;
-  int rowoff[RW], leftoff[LW > 0 ? LW : 1];
-#pragma unroll
-  for (int ii = 0; ii < RW; ii++) { const int I = wave + 4 * ii; rowoff[ii] = 4 * (I < NB ? I : NB - 1); }
-#pragma unroll
-  for (int vv = 0; vv < LW; vv++) {
-    const int v = wave + 4 * vv;
-    const int ib = (v < NLEFT ? v : NLEFT - 1) * G + b / rem;
-    leftoff[vv] = 4 * (ib < NB ? ib : NB - 1);
-  }
-  double acc[(NQ > 0 ? NQ : 1) * RW], accl[LW > 0 ? LW : 1];
-  if (wave == 3) {
-    double sx = 0.0;
-    for (int k = 0; k < D; k++) sx = __builtin_fma(S.Gm[k * LD + li], S.mv[k], sx);
-    if (act) { S.am[l] = sx; if (a.Am) a.Am[o * D + l] = sx; }
-  }
-#pragma unroll
-  for (int u = 0; u < (NQ > 0 ? NQ : 1) * RW; u++) acc[u] = 0.0;
-#pragma unroll
-  for (int u = 0; u < (LW > 0 ? LW : 1); u++) accl[u] = 0.0;
-#pragma unroll
-  for (int kk = 0; kk < NB; kk++) {
-    double bq[NQ > 0 ? NQ : 1];
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-      if (kk >= 4 * q) bq[q] = pb[kk * 4 * LD + 16 * q + colq];      // L[k][j] = 0 for k < j: whole blocks skipped
-    double bl = 0.0;
-    if (NLEFT > 0 && kk >= 4 * NQ) bl = pb[kk * 4 * LD + coll];
-#pragma unroll
-    for (int ii = 0; ii < RW; ii++) {
-      if (NQ > 0) {
-        const double af = pa[kk * 4 * LD + rowoff[ii]];
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-          if (kk >= 4 * q) acc[q * RW + ii] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * RW + ii], 0, 0, 0);
-      }
-    }
-    if (NLEFT > 0 && kk >= 4 * NQ) {
-#pragma unroll
-      for (int vv = 0; vv < LW; vv++) {
-        const double af = pa[kk * 4 * LD + leftoff[vv]];
-        accl[vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bl, accl[vv], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();                                 // every wave is done reading A^T (and am is complete)
-#pragma unroll
-  for (int ii = 0; ii < RW; ii++) {
-    const int I = wave + 4 * ii;
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-      if (I < NB) S.Gm[(4 * I + r4) * LD + 16 * q + 4 * b + c4] = acc[q * RW + ii];
-  }
-#pragma unroll
-  for (int vv = 0; vv < LW; vv++) {
-    const int v = wave + 4 * vv;
-    const int Ib = v * G + b / rem;
-    if (v < NLEFT && b < G * REM && Ib < NB) S.Gm[(4 * Ib + r4) * LD + 4 * (4 * NQ + b % rem) + c4] = accl[vv];
-  }
-  __syncthreads();
-
-#if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 2
-  return;
-#endif
-  // ---- 3. v_p: lane j evaluates both sigma points of column j; wave w takes the rows [w Q, (w+1) Q)
-  const bool hyper = a.hyp != nullptr;
-  double r0sq = 0.0, v0 = 0.0;
-  {
-    auto col_of = [&](int q) { return q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D); };
-    auto sgn_of = [&](int q) { return q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0); };
-    auto chi = [&](int q, int i) { return S.mv[i] + sgn_of(q) * S.Lm[i * LD + col_of(q)]; };
-    // X(p*D + i) of the flattened (M, D) sigma-point matrix for i in [-2, D + 1]: neighbours across the row ends
-    auto flat = [&](int p, int i) { return i < 0 ? chi(wrap(p - 1, M), i + D) : (i >= D ? chi(wrap(p + 1, M), i - D) : chi(p, i)); };
-    const int jc = act ? l : 0;
-    const int pP = 1 + jc, pM = 1 + D + jc;
-    const int Q = (D + 3) / 4;
-    const int i_lo = wave * Q, i_hi = (i_lo + Q < D) ? (i_lo + Q) : D;
-    double vplus = 0.0, vminus = 0.0;
-    if (i_lo < i_hi) {
-      double am2 = flat(pP, i_lo - 2), am1 = flat(pP, i_lo - 1), a0 = flat(pP, i_lo), a1 = flat(pP, i_lo + 1);
-      double bm2 = flat(pM, i_lo - 2), bm1 = flat(pM, i_lo - 1), b0 = flat(pM, i_lo), b1 = flat(pM, i_lo + 1);
-      const double* lcol = S.Lm + jc;
-      double* gcol = S.Gm + jc;
-      for (int i = i_lo; i < i_hi; i++) {
-        const double gi = gcol[i * LD], ami = S.am[i], bvi = S.bv[i], sgi = S.sg[i];
-#if defined(VGPA_W4_EXTRA_LDS)   // diagnostic build only: six more LDS reads per row (is the kernel bound by LDS instructions?)
-        {
-          const volatile double* vq = S.qq;
-          double junk = vq[i] + vq[i + 1] + vq[i + 2] + vq[i + 3] + vq[i + 4] + vq[i + 5];    // (runs into rd[]: still inside the carve-up)
-          if (junk == 1.2345e300) vplus += 1.0;
-        }
-#endif
-        const double ra = ((a1 - am2) * am1 - a0 + theta) + (ami + gi) - bvi;
-        const double rb = ((b1 - bm2) * bm1 - b0 + theta) + (ami - gi) - bvi;
-        vplus = __builtin_fma(sgi, ra * ra, vplus);
-        vminus = __builtin_fma(sgi, rb * rb, vminus);
-        if (hyper && act) gcol[i * LD] = ra * ra + rb * rb;
-        am2 = am1; am1 = a0; a0 = a1;
-        bm2 = bm1; bm1 = b0; b0 = b1;
-        const int in = i + 2;
-        if (in < D) {
-          const double mi = S.mv[in], li2 = lcol[in * LD];
-          a1 = mi + li2; b1 = mi - li2;
-        } else {
-          a1 = flat(pP, in); b1 = flat(pM, in);
-        }
-      }
-    }
-    if (pad) { vpart[wave * Dp + l] = vplus; vpart[(4 + wave) * Dp + l] = vminus; }
-    // the mean point (wave 1, lane i holds term i of the sum)
-    if (wave == 1) {
-      if (act) {
-        const int i = l;
-        const double xm2 = (i >= 2) ? S.mv[i - 2] : chi(M - 1, D - 2 + i);
-        const double xm1 = (i >= 1) ? S.mv[i - 1] : chi(M - 1, D - 1);
-        const double x1 = (i + 1 < D) ? S.mv[i + 1] : chi(1, 0);
-        const double r0 = ((x1 - xm2) * xm1 - S.mv[i] + theta) + S.am[i] - S.bv[i];
-        r0sq = r0 * r0;
-        v0 = S.sg[i] * r0sq;
-      }
-      v0 = wave_sum(v0);
-      if (l == 0) S.vv[0] = v0;
-      if (hyper && pad) S.vv[1 + l] = r0sq;
-    }
-  }
-  __syncthreads();
-#if defined(VGPA_W4_STOP) && VGPA_W4_STOP <= 3
-  return;
-#endif
-  const double w0 = kappa / c, w1 = 1.0 / (2.0 * c);
-  if (wave == 0) {
-    const double vplus = ((vpart[li] + vpart[Dp + li]) + vpart[2 * Dp + li]) + vpart[3 * Dp + li];
-    const double vminus = ((vpart[4 * Dp + li] + vpart[5 * Dp + li]) + vpart[6 * Dp + li]) + vpart[7 * Dp + li];
-    if (hyper && act) {
-      double sm = 0.0;
-      for (int j = 0; j < D; j++) sm += S.Gm[l * LD + j];
-      const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
-      const double efi = (St[ip1 * D + im1] - St[im2 * D + im1]) + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
-      double* hp = a.hyp + o * 2 * D;
-      hp[i] = efi + S.am[i] - S.bv[i];
-      hp[D + i] = w0 * S.vv[1 + l] + w1 * sm;
-    }
-    const double e_part = act ? (vplus + vminus) : 0.0;
-    const double e_t = 0.5 * (w0 * S.vv[0] + w1 * wave_sum(e_part));
-    if (act) {
-      S.dl[l] = w1 * (vplus - vminus);
-      S.qq[l] = 0.5 * c * (w1 * (vplus + vminus)) - e_t;
-    }
-    if (l == 0) a.e_t[o] = e_t;
-    wave_sync();
-
-  }
-  __syncthreads();
-
-  // ---- 4. X = L^-1 into Gm by blocked forward substitution on the matrix cores.  Wave w owns the column blocks
-  //         4w .. 4w+3 of X for every block-row, so the recursion over block-rows needs no workgroup barrier:
-  //           T_b   = sum_{K < I} L[I][K] . X[K][J_b]          (accumulator; J_b = 4w + b)
-  //           X[I][J_b] = -inv(L[I][I]) . T_b                  (T_b is already laid out as the B-operand)
-  //         with X[I][I] = inv(L[I][I]) and zeros above the diagonal.
-  {
-    const int Jb = 4 * wave + b;
-    if (4 * wave < NB) {
-      double* xcol = S.Gm + r4 * LD + 4 * Jb + c4;           // X[4K + r4][4 J_b + c4]: B-operand and output position
-      const bool colok = Jb < NB;
-      for (int I = 0; I < NB; I++) {
-        double xo = 0.0;
-        if (I >= 4 * wave) {                                 // wave-uniform
-          const double* arow = S.Lm + (4 * I + c4) * LD + r4;  // A-operand [i][k] = L[4I + i][4K + k]
-          double tacc = 0.0;
-          for (int K = 4 * wave; K < I; K++)
-            tacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * K], colok ? xcol[4 * K * LD] : 0.0, tacc, 0, 0, 0);
-          const double xd = xdiag[16 * I + 4 * c4 + r4];     // A-operand [i][k] = inv(L[I][I])[i][k], lane (c4 = i, r4 = k)
-          const double prod = __builtin_amdgcn_mfma_f64_4x4x4f64(xd, tacc, 0.0, 0, 0, 0);
-          xo = (Jb < I) ? -prod : ((Jb == I) ? xdiag[16 * I + 4 * r4 + c4] : 0.0);
-        }
-        if (colok) xcol[4 * I * LD] = xo;                    // D[i = r4][j = c4]: X[4I + r4][4 J_b + c4]
-        wave_sync();
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- 5. dE/dm = (c/2) X^T delta (wave 3); dE/dS = (c/2) X^T diag(q) X on the matrix cores, q applied to the
-  //         B fragment on the fly (no scaled copy of X in LDS); <f> by wave 2
-  if (wave == 3) {
-    double sx = 0.0;
-    for (int k = 0; k < Dp; k++) sx = __builtin_fma(S.Gm[k * LD + li], S.dl[k], sx);   // X[k][l] = 0 for k < l
-    if (act) a.dEm[o * D + l] = 0.5 * c * sx;
-  }
-  if (wave == 2 && act) {
-    const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
-    const double cxx = St[ip1 * D + im1] - St[im2 * D + im1];
-    a.Ef[o * D + i] = cxx + (S.mv[ip1] - S.mv[im2]) * S.mv[im1] - S.mv[i] + theta;
-  }
-  {
-    const double* px = S.Gm + r4 * LD;              // X as B-operand [k][j]
-    switch (wave) {                                 // the triangular skips are compile-time per wave
-      case 0: l96_syrk_rows<NB, 0>(pa, px, S.qq + r4, LD, colq, coll, b, acc, accl); break;
-      case 1: l96_syrk_rows<NB, 1>(pa, px, S.qq + r4, LD, colq, coll, b, acc, accl); break;
-      case 2: l96_syrk_rows<NB, 2>(pa, px, S.qq + r4, LD, colq, coll, b, acc, accl); break;
-      default: l96_syrk_rows<NB, 3>(pa, px, S.qq + r4, LD, colq, coll, b, acc, accl); break;
-    }
-    double* ds = a.dEs + o * D * D;
-#pragma unroll
-    for (int ii = 0; ii < RW; ii++) {
-      const int I = wave + 4 * ii;
-      const int row = 4 * I + r4;
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const int col = 16 * q + 4 * b + c4;
-#if defined(VGPA_W4_NOMEM)
-        if (I < NB && row < D && col < D && acc[q * RW + ii] == 1.2345e300) ds[row * D + col] = 0.0;
-#else
-        if (I < NB && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[q * RW + ii];
-#endif
-      }
-    }
-#pragma unroll
-    for (int vv = 0; vv < LW; vv++) {
-      const int v = wave + 4 * vv;
-      const int Ib = v * G + b / rem;
-      const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
-      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) ds[row * D + col] = 0.5 * c * accl[vv];
-    }
-  }
-  if (a.Edf) {
-    double* ed = a.Edf + o * D * D;
-    for (int e = tid; e < D * D; e += NT) {
       const int k = e / D, j = e - k * D;
       const int kp1 = wrap(k + 1, D), km1 = wrap(k - 1, D), km2 = wrap(k - 2, D);
       double v = 0.0;
@@ -1517,35 +1022,8 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_energy_l63, grid, dim3(64), 0, st, a);
   } else if (a.model == VGPA_MODEL_L96) {
     if (a.D < 4 || a.D > kMaxSmallD) return hipErrorInvalidValue;
-    if (a.four_waves) {   // the four-waves-per-grid-point variant (VGPA_FLAG_FORCE_GENERIC); the one-wave kernel is faster
-      size_t lds4 = l96w4_lds_doubles(a.D) * sizeof(double);
-#ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
-      lds4 += VGPA_L96_LDSPAD;
-#endif
-      const long long ntasks = (long long)a.Np * a.batch;
-      if (ntasks > 0x7fffffffLL) return hipErrorInvalidValue;
-#define VGPA_L96W4_CASE(NBV)                                                                                            \
-  case NBV:                                                                                                             \
-    if (lds4 > 48 * 1024)                                                                                               \
-      (void)hipFuncSetAttribute((const void*)k_energy_l96_w4<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
-    hipLaunchKernelGGL(k_energy_l96_w4<NBV>, dim3((unsigned)ntasks), dim3(NT), lds4, st, a);                              \
-    return hipGetLastError();
-      switch ((a.D + 3) / 4) {
-        VGPA_L96W4_CASE(1) VGPA_L96W4_CASE(2) VGPA_L96W4_CASE(3) VGPA_L96W4_CASE(4) VGPA_L96W4_CASE(5) VGPA_L96W4_CASE(6)
-        VGPA_L96W4_CASE(7) VGPA_L96W4_CASE(8) VGPA_L96W4_CASE(9) VGPA_L96W4_CASE(10) VGPA_L96W4_CASE(11) VGPA_L96W4_CASE(12)
-        VGPA_L96W4_CASE(13) VGPA_L96W4_CASE(14) VGPA_L96W4_CASE(15) VGPA_L96W4_CASE(16)
-        default: return hipErrorInvalidValue;
-      }
-#undef VGPA_L96W4_CASE
-    }
     const bool one_matrix = (a.hyp == nullptr);      // the hyper-parameter integrands need the second LDS matrix
     size_t lds = (one_matrix ? l96r_lds_doubles(a.D) : l96_lds_doubles(a.D)) * sizeof(double);
-#ifdef VGPA_L96_ALIAS
-    lds -= (size_t)l96_dp(a.D) * l96_ld(a.D) * sizeof(double);
-#endif
-#ifdef VGPA_L96_LDSPAD   // diagnostic build only: inflate the LDS request to lower the occupancy
-    lds += VGPA_L96_LDSPAD;
-#endif
     const long long nwaves = (long long)a.Np * a.batch;
     if (nwaves > 0x7fffffffLL) return hipErrorInvalidValue;
 #define VGPA_L96_CASE(NBV)                                                                                          \

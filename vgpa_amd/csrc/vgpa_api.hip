@@ -251,7 +251,6 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
   a.e_t = c->d_et; a.Ef = c->d_Ef; a.Edf = edf; a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.status = c->d_status;
   a.Am = (c->cfg.model == VGPA_MODEL_L96) ? c->d_Am : nullptr;
   a.hyp = c->hyp_on ? c->d_hyp : nullptr;
-  a.four_waves = (c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) ? 1 : 0;
   return a;
 }
 

@@ -41,7 +41,6 @@ struct OdeArgs {
 
 struct EnergyArgs {
   int model, D, Np, batch;
-  int four_waves;           // diagnostics: the four-waves-per-grid-point Lorenz-96 kernel (VGPA_FLAG_FORCE_GENERIC)
   double dt;
   double theta[kMaxTheta];
   double sigma1;            // 1-D models: sigma
