@@ -119,6 +119,23 @@ def test_odd_batches(batch, method):
         assert rel_err(gb[i], g_ref) < TOL
 
 
+def test_batched_operator_level_sweeps_with_dense_jumps():
+    """FwdOde / BwdOde semantics (dense jump arrays) through the MFMA stepping kernels, two problems in one context."""
+    from test_large_d import make_inputs
+    d, n = 24, 11
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
+    ctx = va.Context("NONE", "rk4", d, n, 0.01, sigma=np.eye(d), batch=2)
+    a2 = np.stack([a, a * 1.01])
+    lam, psi = ctx.solve_bwd(a2, np.stack([gm, gm]), np.stack([gs, gs]), np.stack([jm, jm]), np.stack([js, js]))
+    for i in range(2):
+        lam_o, psi_o = vo.solve_bwd("rk4", 0.01, False, a2[i], gm, gs, jm, js)
+        assert rel_err(lam[i], lam_o) < TOL and rel_err(psi[i], psi_o) < TOL
+    mt, st = ctx.solve_fwd(a2, np.stack([b, b]), m0, s0, sigma)
+    for i in range(2):
+        mt_o, st_o = vo.solve_fwd("rk4", 0.01, False, a2[i], b, m0, s0, sigma)
+        assert rel_err(mt[i], mt_o) < TOL and rel_err(st[i], st_o) < TOL
+
+
 def test_state_errors():
     p, x = make_problem("L63", 3, 10)
     ctx = gpu_context(p)

@@ -21,11 +21,11 @@
 //     the VALU while the P waves are in the product), stage A(t) HBM -> registers -> LDS one step ahead and stream
 //     S_k / Psi_t back to HBM.
 //   * One workgroup (4 P + 4 E waves, one of each per SIMD) per problem; the phases alternate product / element-wise
-//     stage with ONE workgroup barrier each.  Two further schedules were built and measured in round 2 and are not kept
-//     (DESIGN.md s.4.1): two problems per workgroup in alternating phases (the matrix pipe works in every phase, but the
-//     product of one problem and the element-wise waves of the other slow each other down: 2.8 k cycles per
-//     problem-stage against 2.8 k for this one), and counters in LDS instead of barriers (the P waves run products back
-//     to back, but polling and the longer hand-off latency cost more than the drained pipeline they avoid).
+//     stage with ONE workgroup barrier each.  Also built and measured in round 2, not kept: two problems
+//     per workgroup in alternating phases -- with separate E waves per problem and with every E wave serving both --
+//     (the matrix pipe has work in every phase, but LDS traffic and the fp64 VALU work of the other problem's element-wise
+//     stage stretch the product by what the overlap saves: +4 % forward, slower backward), and counters in LDS instead of
+//     barriers (products back to back, but polling and the longer hand-off latency cost more than the drained pipeline).
 // LDS per problem (D = 40): stage state X 15 KB + two A-operand buffers (start/end point R, mid-point M) 26 KB + W 13 KB
 // + vectors + the constant matrix jump 13 KB: 82 KB.
 #pragma once
@@ -585,301 +585,232 @@ __device__ __forceinline__ double matvec_sum(const Lds<NB>& L, int i) {
   return s;
 }
 
-// The E role: the Runge-Kutta state of the problem, the vector recursion, the HBM stores.
+// ---- the E role: the Runge-Kutta state of a problem, its vector recursion, its HBM stores --------------------------------
+// Forward and backward are the same arithmetic: with V = what the P waves leave in W (product minus half the forcing term),
+// the stage slope of the matrix is f = -(V + V^T) in BOTH directions (backward: Psi_{t-1} = Psi_t - dt (-G + W' + W'^T) with
+// the G/2 already inside V), and the slope of the vector is c - A.v with c = b (forward) or dEsde_dm (backward); the
+// backward sweep adds the jumps after the step (euler.py:139-149).  Step i of a sweep starts at grid point tidx(i) and
+// ends at tidx(i + 1), tidx(i) = i forward, Np - 1 - i backward.
+template <int NIT>
+struct EState {
+  d2_t xk[NIT], acc[NIT];      // S_k / Psi_t of this thread's items; RK4 / Heun slope sum
+  double vk, v1, v2, v3;       // vector entry and its RK slopes
+  double c0, c1, c2;           // vector forcing at the step's start / end point and at the next step's end point
+  double jm, jm_next;          // vector jump behind this / the next step (backward)
+  int n_obs_cur, n_obs_next;   // observation index behind this / the next step, or -1 (backward, sparse jumps)
+  const double* cin;           // b (forward) / dEsde_dm (backward) of the problem, [Np][D]
+  double* vout;                // m / lam, [Np][D]
+  double* mout;                // S / Psi, [Np][D][D]
+  int prob;
+};
+
 template <int METHOD, bool FWD, int NB, int NE, bool DENSEJ>
-__device__ __forceinline__ void e_role(const OdeArgs& a, int prob, const Lds<NB>& L, double* __restrict__ SIG, int te) {
-  // The library is built with -ffp-contract=off (the other kernels keep the reference's operation order); the Runge-Kutta
-  // bookkeeping here may fuse a*b+c: every fused operation is one rounding closer to the exact value and one instruction
-  // less on the fp64 pipe these waves share with the matrix cores.  Parity bound of the test-suite: 1e-9 (north star 1e-6).
-#pragma clang fp contract(fast)
+struct ERole {
   using g = Geo<NB>;
-  constexpr int NIT = EGeo<NB, NE>::NIT, NS = n_stages<METHOD>();
-  const int D = a.D, DD = D * D, Np = a.Np;
-  const double dt = a.dt, h = 0.5 * a.dt;
-  const int n_steps = Np - 1;
-  const unsigned D8 = 8u * (unsigned)D, te8 = 8u * (unsigned)te;
-  // The E waves issue few instructions, all on the critical path of their problem; the P wave of the same SIMD always has
-  // an MFMA ready.  Without priority the E waves' fp64 VALU work waits for the matrix pipe until the product is over.
-  __builtin_amdgcn_s_setprio(3);
-  ETab<NB, NE> T;
-  build_etab<NB, NE>(D, te, T);
-  const bool vl = te < D;                                  // this thread carries entry `te` of the vector recursion
-  auto item = [&](int q) { return ((T.mask >> q) & 1u) != 0u; };
-  auto row2 = [&](int q) { return ((T.mask >> (8 + q)) & 1u) != 0u; };
-  auto opbuf = [&](int op) -> const double* { return op == OP_M ? L.M : L.R; };
-  constexpr double sixth = 1.0 / 6.0;
+  static constexpr int NIT = EGeo<NB, NE>::NIT, NS = n_stages<METHOD>();
+  using State = EState<NIT>;
+  const OdeArgs& a;
+  const ETab<NB, NE>& T;
+  double* SIG;
+  const int te;
+  const bool vl;
+  const unsigned D8, te8;
 
-  d2_t xk[NIT], acc[NIT];
-  double vk = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;           // vector entry and its RK slopes
-#pragma unroll
-  for (int q = 0; q < NIT; q++) { xk[q] = d2_t{0.0, 0.0}; acc[q] = d2_t{0.0, 0.0}; }
+  __device__ __forceinline__ ERole(const OdeArgs& a_, const ETab<NB, NE>& T_, double* sig, int te_)
+      : a(a_), T(T_), SIG(sig), te(te_), vl(te_ < a_.D), D8(8u * (unsigned)a_.D), te8(8u * (unsigned)te_) {}
+  __device__ __forceinline__ bool item(int q) const { return ((T.mask >> q) & 1u) != 0u; }
+  __device__ __forceinline__ bool row2(int q) const { return ((T.mask >> (8 + q)) & 1u) != 0u; }
+  __device__ __forceinline__ int tidx(int i) const { return FWD ? i : a.Np - 1 - i; }
+  __device__ __forceinline__ size_t mat(int t) const { return (size_t)t * a.D * a.D; }
+  __device__ __forceinline__ size_t vec(int t) const { return (size_t)t * a.D; }
 
-  __syncthreads();                                         // LDS zero-filled
-  if (FWD) {
-    // ------------------------------------------------------------------------------------------ forward: (m, S)
-    const double* bb = a.b + (size_t)prob * a.strideB;
-    double* mt = a.m + (size_t)prob * Np * D;
-    double* st = a.S + (size_t)prob * Np * DD;
+  __device__ __forceinline__ void store_state(const State& S, int t) const {
+    double* so = S.mout + mat(t);
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
       if (item(q)) {
-        xk[q][0] = ldg(a.S0, T.gofs[q]);
-        xk[q][1] = row2(q) ? ldg(a.S0, T.gofs[q] + D8) : 0.0;
-        stg(st, T.gofs[q], xk[q][0]);
-        if (row2(q)) stg(st, T.gofs[q] + D8, xk[q][1]);
-        *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xk[q];
+        stg(so, T.gofs[q], S.xk[q][0]);
+        if (row2(q)) stg(so, T.gofs[q] + D8, S.xk[q][1]);
       }
     }
-    if (vl) { vk = ldg(a.m0, te8); stg(mt, te8, vk); L.xv[te] = vk; }
-    double b0 = vl ? ldg(bb, te8) : 0.0;
-    double b1 = (vl && Np > 1) ? ldg(bb + D, te8) : 0.0;
-#pragma unroll
-    for (int q = 0; q < NIT; q++) settle(xk[q]);
-    settle(b0); settle(b1); settle(vk);
-    __syncthreads();                                       // prologue published
+    if (vl) stg(S.vout + vec(t), te8, S.vk);
+  }
 
-    VGPA_STAMP_DECL;
-    const int srole = (te < 64) ? 1 : 3;
-    (void)srole;
-    for (int k = 0; k < n_steps; k++) {
-      const double b2 = (vl && k + 2 < Np) ? ldg(bb + (size_t)(k + 2) * D, te8) : 0.0;     // for the next step
-      const double bmid = 0.5 * (b0 + b1);
-#pragma unroll
-      for (int j = 0; j < NS; j++) {
-        matvec_partials<NB, NE, true>(opbuf(stage_op<METHOD, true>(j, false, k)), L, te);
-        // chores beside the product of this problem: HBM stores of the previous step, operands of the coming stages
-        if (j == 0) {
-          if (k > 0) {       // S_k, m_k -> HBM
-            double* so = st + (size_t)k * DD;
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-              if (item(q)) {
-                stg(so, T.gofs[q], xk[q][0]);
-                if (row2(q)) stg(so, T.gofs[q] + D8, xk[q][1]);
-              }
-            }
-            if (vl) stg(mt + (size_t)k * D, te8, vk);
-          }
-        }
-        VGPA_STAMP(srole, 0);            // mat-vec + chores
-        __syncthreads();
-        VGPA_STAMP(srole, 1);            // barrier (the product of this problem)
-        // ---- element-wise stage j (the P waves are busy with the other problem)
-        double vs = 0.0;
-        if (vl) vs = matvec_sum<NB, NE, true>(L, te);
-        // In batches of up to four items: every LDS read of the batch first, then the arithmetic, then the publish.  No
-        // branches (threads without an item read element (0, 0) and publish into their trash unit); one LDS round trip
-        // per batch; the scheduling barrier keeps the reads of the next batch (and their registers) behind this one.
-#pragma unroll
-        for (int q0 = 0; q0 < NIT; q0 += 4) {
-          d2_t wv[4], wt[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int q = q0 + u;
-            if (q < NIT) {
-              wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
-              wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int q = q0 + u;
-            if (q < NIT) {
-              d2_t xn;
-              const d2_t f = -wv[u] - wt[u];                // = -(W + W^T) + Sigma: the P waves started from -Sigma/2
-              if (METHOD == VGPA_ODE_EULER) {
-                xk[q] = xk[q] + f * dt; xn = xk[q];
-              } else if (METHOD == VGPA_ODE_HEUN) {
-                if (j == 0) { acc[q] = f; xn = xk[q] + f * dt; }
-                else { xk[q] = xk[q] + h * (acc[q] + f); xn = xk[q]; }
-              } else if (METHOD == VGPA_ODE_RK2) {
-                if (j == 0) xn = xk[q] + h * f;
-                else { xk[q] = xk[q] + dt * f; xn = xk[q]; }
-              } else {                                      // acc = k1 + 2 k2 + 2 k3 + k4, summed as the stages come
-                if (j == 0) { acc[q] = f; xn = xk[q] + h * f; }
-                else if (j == 1) { acc[q] = acc[q] + 2.0 * f; xn = xk[q] + h * f; }
-                else if (j == 2) { acc[q] = acc[q] + 2.0 * f; xn = xk[q] + dt * f; }
-                else { xk[q] = xk[q] + (dt * (acc[q] + f)) * sixth; xn = xk[q]; }
-              }
-              *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
-            }
-          }
-          if (q0 + 4 < NIT) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (vl) {
-          double vn;
-          if (METHOD == VGPA_ODE_EULER) { vk = vk + (-vs + b0) * dt; vn = vk; }
-          else if (METHOD == VGPA_ODE_HEUN) {
-            if (j == 0) { v1 = -vs + b0; vn = vk + v1 * dt; }
-            else { vk = vk + h * (v1 + (-vs + b1)); vn = vk; }
-          } else if (METHOD == VGPA_ODE_RK2) {
-            if (j == 0) { vn = vk + h * (-vs + b0); }
-            else { vk = vk + dt * (-vs + bmid); vn = vk; }
-          } else {
-            if (j == 0) { v1 = -vs + b0; vn = vk + h * v1; }
-            else if (j == 1) { v2 = -vs + bmid; vn = vk + h * v2; }
-            else if (j == 2) { v3 = -vs + bmid; vn = vk + dt * v3; }
-            else { vk = vk + (dt * (v1 + 2.0 * (v2 + v3) + (-vs + b1))) * sixth; vn = vk; }
-          }
-          L.xv[te] = vn;
-        }
-        VGPA_STAMP(srole, 2);            // element-wise stage
-        __syncthreads();
-        VGPA_STAMP(srole, 4);            // barrier
-      }
-      b0 = b1; b1 = b2;
+  __device__ __forceinline__ double jump_vector(const State& S, int t, int n_obs) const {
+    if (!FWD) {
+      if (DENSEJ) { if (vl) return ldg(a.jm_dense + ((size_t)S.prob * a.Np + t) * a.D, te8); }
+      else if (vl && n_obs >= 0) return ldg(a.jm_sparse + ((size_t)S.prob * a.n_obs + n_obs) * a.D, te8);
     }
-    if (n_steps > 0) {       // S, m of the last grid point
-      double* so = st + (size_t)n_steps * DD;
-#pragma unroll
-      for (int q = 0; q < NIT; q++) {
-        if (item(q)) {
-          stg(so, T.gofs[q], xk[q][0]);
-          if (row2(q)) stg(so, T.gofs[q] + D8, xk[q][1]);
-        }
-      }
-      if (vl) stg(mt + (size_t)n_steps * D, te8, vk);
-    }
-  } else {
-    // ------------------------------------------------------------------------------------------ backward: (lam, Psi)
-    const double* gm = a.dEm + (size_t)prob * Np * D;
-    double* lam = a.lam + (size_t)prob * Np * D;
-    double* psi = a.psi + (size_t)prob * Np * DD;
-    const bool sparse = !DENSEJ && a.obs_idx;
+    return 0.0;
+  }
+
+  // state at the first grid point of the sweep, published; forcing of the first step
+  __device__ __forceinline__ void prologue(State& S, int prob, const Lds<NB>& L, bool write_sig) const {
+    const int Np = a.Np, n_steps = Np - 1;
+    S.prob = prob;
+    S.cin = FWD ? a.b + (size_t)prob * a.strideB : a.dEm + (size_t)prob * Np * a.D;
+    S.vout = (FWD ? a.m : a.lam) + (size_t)prob * Np * a.D;
+    S.mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * a.D * a.D;
+    S.vk = S.v1 = S.v2 = S.v3 = 0.0; S.jm = S.jm_next = 0.0; S.n_obs_cur = S.n_obs_next = -1; S.c2 = 0.0;
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
-      if (item(q)) {
-        double* p1p = psi + (size_t)(Np - 1) * DD;
-        stg(p1p, T.gofs[q], 0.0);
-        if (row2(q)) stg(p1p, T.gofs[q] + D8, 0.0);
-        if (!DENSEJ) {
-          d2_t js{0.0, 0.0};
-          if (a.js_const) { js[0] = ldg(a.js_const, T.gofs[q]); js[1] = row2(q) ? ldg(a.js_const, T.gofs[q] + D8) : 0.0; }
-          *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = js;
-        }
+      S.xk[q] = d2_t{0.0, 0.0}; S.acc[q] = d2_t{0.0, 0.0};
+      if (FWD && item(q)) {
+        S.xk[q][0] = ldg(a.S0, T.gofs[q]);
+        S.xk[q][1] = row2(q) ? ldg(a.S0, T.gofs[q] + D8) : 0.0;
+        *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = S.xk[q];
+      }
+      if (!FWD && !DENSEJ && write_sig && item(q)) {     // the constant matrix jump, once per workgroup
+        d2_t js{0.0, 0.0};
+        if (a.js_const) { js[0] = ldg(a.js_const, T.gofs[q]); js[1] = row2(q) ? ldg(a.js_const, T.gofs[q] + D8) : 0.0; }
+        *reinterpret_cast<d2_t*>(SIG + 2 * (te + q * NE)) = js;
       }
     }
-    if (vl) stg(lam + (size_t)(Np - 1) * D, te8, 0.0);
-    // per-step vectors are fetched one step ahead: g0 = dEsde_dm[t], g1 = dEsde_dm[t-1]; jump of index t-1
-    double g0 = vl ? ldg(gm + (size_t)(Np - 1) * D, te8) : 0.0;
-    double g1 = (vl && Np > 1) ? ldg(gm + (size_t)(Np - 2) * D, te8) : 0.0;
-    int n_obs_cur = (sparse && Np > 1) ? a.obs_idx[Np - 2] : -1;
-    double jm = 0.0;
-    if (Np > 1) {
-      if (DENSEJ) { if (vl) jm = ldg(a.jm_dense + ((size_t)prob * Np + (Np - 2)) * D, te8); }
-      else if (vl && n_obs_cur >= 0) jm = ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs_cur) * D, te8);
+    if (FWD && vl) { S.vk = ldg(a.m0, te8); L.xv[te] = S.vk; }
+    store_state(S, tidx(0));
+    S.c0 = vl ? ldg(S.cin + vec(tidx(0)), te8) : 0.0;
+    S.c1 = (vl && n_steps >= 1) ? ldg(S.cin + vec(tidx(1)), te8) : 0.0;
+    if (!FWD && n_steps >= 1) {
+      S.n_obs_cur = (!DENSEJ && a.obs_idx) ? a.obs_idx[tidx(1)] : -1;
+      S.jm = jump_vector(S, tidx(1), S.n_obs_cur);
     }
-    settle(g0); settle(g1); settle(jm);
-    __syncthreads();                                       // prologue published
+#pragma unroll
+    for (int q = 0; q < NIT; q++) settle(S.xk[q]);
+    settle(S.c0); settle(S.c1); settle(S.vk); settle(S.jm);
+  }
 
-    for (int t = Np - 1; t > 0; t--) {
-      const double g2 = (vl && t >= 2) ? ldg(gm + (size_t)(t - 2) * D, te8) : 0.0;          // for the next step
-      const int n_obs_next = (sparse && t >= 2) ? a.obs_idx[t - 2] : -1;
-      double jm_next = 0.0;
-      if (t >= 2) {
-        if (DENSEJ) { if (vl) jm_next = ldg(a.jm_dense + ((size_t)prob * Np + (t - 2)) * D, te8); }
-        else if (vl && n_obs_next >= 0) jm_next = ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs_next) * D, te8);
-      }
-      const double gmid = 0.5 * (g1 + g0);
-#pragma unroll
-      for (int j = 0; j < NS; j++) {
-        matvec_partials<NB, NE, false>(opbuf(stage_op<METHOD, false>(j, false, Np - 1 - t)), L, te);
-        if (j == 0) {
-          if (t < Np - 1) {  // Psi_t, lam_t -> HBM; G_{t-1} for the step's end point
-            double* po = psi + (size_t)t * DD;
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-              if (item(q)) {
-                stg(po, T.gofs[q], xk[q][0]);
-                if (row2(q)) stg(po, T.gofs[q] + D8, xk[q][1]);
-              }
-            }
-            if (vl) stg(lam + (size_t)t * D, te8, vk);
-          }
-        }
-        __syncthreads();
-        const bool last = (j == NS - 1);
-        double vs = 0.0;
-        if (vl) vs = matvec_sum<NB, NE, false>(L, te);
-#pragma unroll
-        for (int q0 = 0; q0 < NIT; q0 += 4) {
-          d2_t wv[4], wt[4], js[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int q = q0 + u;
-            if (q < NIT) {
-              wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
-              wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
-              js[u] = d2_t{0.0, 0.0};
-              if (last) {      // matrix jump of index t-1, added after the step (euler.py:139-149)
-                if (DENSEJ) {
-                  if (item(q)) {
-                    const double* jp = a.js_dense + ((size_t)prob * Np + (t - 1)) * DD;
-                    js[u][0] = ldg(jp, T.gofs[q]); js[u][1] = row2(q) ? ldg(jp, T.gofs[q] + D8) : 0.0;
-                  }
-                } else if (n_obs_cur >= 0) {
-                  js[u] = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * NE));
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int q = q0 + u;
-            if (q < NIT) {
-              d2_t xn;
-              const d2_t r = wt[u] + wv[u];                 // = -G + W'^T + W': the P waves started from -G/2
-              if (METHOD == VGPA_ODE_EULER) {
-                xk[q] = xk[q] - r * dt + js[u]; xn = xk[q];
-              } else if (METHOD == VGPA_ODE_HEUN) {
-                if (j == 0) { acc[q] = r; xn = xk[q] - r * dt; }
-                else { xk[q] = xk[q] - h * (acc[q] + r) + js[u]; xn = xk[q]; }
-              } else if (METHOD == VGPA_ODE_RK2) {
-                if (j == 0) xn = xk[q] - h * r;
-                else { xk[q] = xk[q] - dt * r + js[u]; xn = xk[q]; }
-              } else {
-                if (j == 0) { acc[q] = r; xn = xk[q] - h * r; }
-                else if (j == 1) { acc[q] = acc[q] + 2.0 * r; xn = xk[q] - h * r; }
-                else if (j == 2) { acc[q] = acc[q] + 2.0 * r; xn = xk[q] - dt * r; }
-                else { xk[q] = xk[q] - (dt * (acc[q] + r)) * sixth + js[u]; xn = xk[q]; }
-              }
-              *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
-            }
-          }
-          if (q0 + 4 < NIT) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (vl) {
-          double vn;
-          if (METHOD == VGPA_ODE_EULER) { vk = vk - (-g0 + vs) * dt + jm; vn = vk; }
-          else if (METHOD == VGPA_ODE_HEUN) {
-            if (j == 0) { v1 = -g0 + vs; vn = vk - v1 * dt; }
-            else { vk = vk - h * (v1 + (-g1 + vs)) + jm; vn = vk; }
-          } else if (METHOD == VGPA_ODE_RK2) {
-            if (j == 0) { vn = vk - h * (-g0 + vs); }
-            else { vk = vk - dt * (-gmid + vs) + jm; vn = vk; }
-          } else {
-            if (j == 0) { v1 = -g0 + vs; vn = vk - h * v1; }
-            else if (j == 1) { v2 = -gmid + vs; vn = vk - h * v2; }
-            else if (j == 2) { v3 = -gmid + vs; vn = vk - dt * v3; }
-            else { vk = vk - (dt * (v1 + 2.0 * (v2 + v3) + (-g1 + vs))) * sixth + jm; vn = vk; }
-          }
-          L.xv[te] = vn;
-        }
-        __syncthreads();
-      }
-      g0 = g1; g1 = g2; jm = jm_next; n_obs_cur = n_obs_next;
-    }
-    if (n_steps > 0) {       // Psi, lam of the first grid point
-#pragma unroll
-      for (int q = 0; q < NIT; q++) {
-        if (item(q)) {
-          stg(psi, T.gofs[q], xk[q][0]);
-          if (row2(q)) stg(psi, T.gofs[q] + D8, xk[q][1]);
-        }
-      }
-      if (vl) stg(lam, te8, vk);
+  // prefetches for the NEXT step (they arrive while this one runs)
+  __device__ __forceinline__ void head(State& S, int i) const {
+    const int n_steps = a.Np - 1;
+    S.c2 = (vl && i + 2 <= n_steps) ? ldg(S.cin + vec(tidx(i + 2)), te8) : 0.0;
+    if (!FWD) {
+      S.n_obs_next = (!DENSEJ && a.obs_idx && i + 2 <= n_steps) ? a.obs_idx[tidx(i + 2)] : -1;
+      S.jm_next = (i + 2 <= n_steps) ? jump_vector(S, tidx(i + 2), S.n_obs_next) : 0.0;
     }
   }
+  __device__ __forceinline__ void tail(State& S) const {
+    S.c0 = S.c1; S.c1 = S.c2; S.jm = S.jm_next; S.n_obs_cur = S.n_obs_next;
+  }
+
+  // beside the product of stage j of step i of this problem: partial sums of the vector's inner product, HBM stores
+  __device__ __forceinline__ void chores(const State& S, const Lds<NB>& L, int j, int i) const {
+    const int op = stage_op<METHOD, FWD>(j, false, i);
+    matvec_partials<NB, NE, FWD>(op == OP_M ? L.M : L.R, L, te);
+    if (j == 0 && i > 0) store_state(S, tidx(i));
+  }
+
+  // the element-wise stage j of step i: next stage state published, vector entry published
+  __device__ __forceinline__ void elem(State& S, const Lds<NB>& L, int j, int i) const {
+#pragma clang fp contract(fast)
+    constexpr double sixth = 1.0 / 6.0;
+    const double dt = a.dt, h = 0.5 * a.dt;
+    const bool last = (j == NS - 1);
+    double vs = 0.0;
+    if (vl) vs = matvec_sum<NB, NE, FWD>(L, te);
+    // In batches of up to four items: every LDS read of the batch first, then the arithmetic, then the publish.  No
+    // branches (threads without an item read element (0, 0) and publish into their trash unit); one LDS round trip per
+    // batch; the scheduling barrier keeps the reads of the next batch (and their registers) behind this one.
+#pragma unroll
+    for (int q0 = 0; q0 < NIT; q0 += 4) {
+      d2_t wv[4], wt[4], js[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u;
+        if (q < NIT) {
+          wv[u][0] = L.W[T.offW[q]]; wv[u][1] = L.W[T.offW[q] + g::LDW];
+          wt[u] = *reinterpret_cast<const d2_t*>(L.W + T.offWt[q]);
+          js[u] = d2_t{0.0, 0.0};
+          if (!FWD && last) {      // matrix jump behind the step
+            if (DENSEJ) {
+              if (item(q)) {
+                const double* jp = a.js_dense + ((size_t)S.prob * a.Np + tidx(i + 1)) * a.D * a.D;
+                js[u][0] = ldg(jp, T.gofs[q]); js[u][1] = row2(q) ? ldg(jp, T.gofs[q] + D8) : 0.0;
+              }
+            } else if (S.n_obs_cur >= 0) {
+              js[u] = *reinterpret_cast<const d2_t*>(SIG + 2 * (te + q * NE));
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u;
+        if (q < NIT) {
+          d2_t xn;
+          const d2_t f = -wv[u] - wt[u];
+          if (METHOD == VGPA_ODE_EULER) {
+            S.xk[q] = S.xk[q] + f * dt + js[u]; xn = S.xk[q];
+          } else if (METHOD == VGPA_ODE_HEUN) {
+            if (j == 0) { S.acc[q] = f; xn = S.xk[q] + f * dt; }
+            else { S.xk[q] = S.xk[q] + h * (S.acc[q] + f) + js[u]; xn = S.xk[q]; }
+          } else if (METHOD == VGPA_ODE_RK2) {
+            if (j == 0) xn = S.xk[q] + h * f;
+            else { S.xk[q] = S.xk[q] + dt * f + js[u]; xn = S.xk[q]; }
+          } else {                                      // acc = k1 + 2 k2 + 2 k3 + k4, summed as the stages come
+            if (j == 0) { S.acc[q] = f; xn = S.xk[q] + h * f; }
+            else if (j == 1) { S.acc[q] = S.acc[q] + 2.0 * f; xn = S.xk[q] + h * f; }
+            else if (j == 2) { S.acc[q] = S.acc[q] + 2.0 * f; xn = S.xk[q] + dt * f; }
+            else { S.xk[q] = S.xk[q] + (dt * (S.acc[q] + f)) * sixth + js[u]; xn = S.xk[q]; }
+          }
+          *reinterpret_cast<d2_t*>(L.X + T.offX[q]) = xn;
+        }
+      }
+      if (q0 + 4 < NIT) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (vl) {
+      const double cmid = 0.5 * (S.c0 + S.c1);
+      double vn;
+      if (METHOD == VGPA_ODE_EULER) { S.vk = S.vk + (S.c0 - vs) * dt + S.jm; vn = S.vk; }
+      else if (METHOD == VGPA_ODE_HEUN) {
+        if (j == 0) { S.v1 = S.c0 - vs; vn = S.vk + S.v1 * dt; }
+        else { S.vk = S.vk + h * (S.v1 + (S.c1 - vs)) + S.jm; vn = S.vk; }
+      } else if (METHOD == VGPA_ODE_RK2) {
+        if (j == 0) vn = S.vk + h * (S.c0 - vs);
+        else { S.vk = S.vk + dt * (cmid - vs) + S.jm; vn = S.vk; }
+      } else {
+        if (j == 0) { S.v1 = S.c0 - vs; vn = S.vk + h * S.v1; }
+        else if (j == 1) { S.v2 = cmid - vs; vn = S.vk + h * S.v2; }
+        else if (j == 2) { S.v3 = cmid - vs; vn = S.vk + dt * S.v3; }
+        else { S.vk = S.vk + (dt * (S.v1 + 2.0 * (S.v2 + S.v3) + (S.c1 - vs))) * sixth + S.jm; vn = S.vk; }
+      }
+      L.xv[te] = vn;
+    }
+  }
+};
+
+// One workgroup integrates one problem: the phases alternate product / element-wise stage, one workgroup barrier each.
+template <int METHOD, bool FWD, int NB, bool DENSEJ>
+__device__ __forceinline__ void e_role(const OdeArgs& a, int prob, const Lds<NB>& L, double* __restrict__ SIG, int te) {
+  using Role = ERole<METHOD, FWD, NB, kNE, DENSEJ>;
+  constexpr int NS = Role::NS;
+  const int n_steps = a.Np - 1;
+  // The E waves issue few instructions, all on the critical path; the P wave of the same SIMD has MFMAs in flight when the
+  // element-wise phase starts.  Without priority their fp64 VALU work would wait for the matrix pipe.
+  __builtin_amdgcn_s_setprio(3);
+  ETab<NB, kNE> T;
+  build_etab<NB, kNE>(a.D, te, T);
+  const Role R(a, T, SIG, te);
+  typename Role::State S;
+  __syncthreads();                                         // LDS zero-filled
+  R.prologue(S, prob, L, true);
+  __syncthreads();                                         // prologue published
+  VGPA_STAMP_DECL;
+  for (int k = 0; k < n_steps; k++) {
+    R.head(S, k);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      R.chores(S, L, j, k);              // beside the product
+      VGPA_STAMP(1, 0);
+      __syncthreads();
+      VGPA_STAMP(1, 1);
+      R.elem(S, L, j, k);
+      VGPA_STAMP(1, 2);
+      __syncthreads();
+      VGPA_STAMP(1, 4);
+    }
+    R.tail(S);
+  }
+  if (n_steps > 0) R.store_state(S, R.tidx(n_steps));
 }
 
 // =================================================================================================================
@@ -896,7 +827,7 @@ __global__ void __launch_bounds__(64 * kNPW + kNE) k_ode_pe(OdeArgs a) {
   double* SIG = smem + g::PROB;
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
   if (wave < kNPW) p_role<METHOD, FWD, NB>(a, prob, L, wave, lane);
-  else e_role<METHOD, FWD, NB, kNE, DENSEJ>(a, prob, L, SIG, tid - 64 * kNPW);
+  else e_role<METHOD, FWD, NB, DENSEJ>(a, prob, L, SIG, tid - 64 * kNPW);
 }
 
 template <int METHOD, bool FWD, int NB>
