@@ -99,6 +99,16 @@ typedef struct {
   double e0;             /* KL(q0||p0), constant in x (src/var_bayes/prior_kl0.py:46-92)    */
 } vgpa_config;
 
+/* What the library does NOT build (VGPA_ERR_UNSUPPORTED; the reference's numpy handles these at its own speed):
+ *   - D > 64 for OU / DW / L63 (their D is 1 / 1 / 3 by definition) -- D > 64 exists for Lorenz-96 and for the bare ODE
+ *     operators (model NONE);
+ *   - D > 64 with a non-symmetric s0 / sigma / dEsde_dS / dEobs_dS (the large-D path uses W + W^T; for D <= 64 the
+ *     generic kernels take any input), with a dense (non-diagonal) system noise in the gradient, or with batch > 1;
+ *   - the hyper-parameter members of <model>.energy() (vgpa_energy_full's dEsde_dth / dEsde_dsig) for D > 64;
+ *   - VGPA_FETCH_PSIT / VGPA_FETCH_DESDE_DS in the time-chunked large-D sweep (they are never resident there).
+ * The matrix-core stepping kernels cover D <= 44 with symmetric inputs; 44 < D <= 64 and non-symmetric operator-level
+ * inputs run on the generic LDS kernels (same results, ~15x slower at D = 40). */
+
 /* lifetime ------------------------------------------------------------------------------- */
 int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg);
 void vgpa_destroy(vgpa_ctx* ctx);
