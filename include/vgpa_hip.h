@@ -69,9 +69,11 @@ enum {
   VGPA_FLAG_FORCE_GENERIC = 1, /* use the generic (no symmetry assumption) stepping kernels */
   VGPA_FLAG_LIBRARY_GEMM = 8,  /* D > 64: rocBLAS dgemm (dlopen'ed) for the plain stage products W = A.X / A^T.Psi instead of the
                                   hand-written MFMA GEMM; everything fused stays hand-written.  Off by default. */
-  VGPA_FLAG_STREAM_LARGE_D = 4 /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and
+  VGPA_FLAG_STREAM_LARGE_D = 4, /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and
                                   dEsde_dS_t live in chunk buffers; VGPA_FETCH_PSIT is unavailable).  Chosen automatically
                                   when the resident arrays would not fit into free device memory. */
+  VGPA_FLAG_SYM_UNITS = 16     /* 5 <= D <= 44: the symmetric-unit stepping kernels (ode_sym_impl.h; two problems per CU, the
+                                  default for 44 < D <= 64) instead of the role-specialised ones.  Same results to rounding. */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;
@@ -106,8 +108,8 @@ typedef struct {
  *     generic kernels take any input), with a dense (non-diagonal) system noise in the gradient, or with batch > 1;
  *   - the hyper-parameter members of <model>.energy() (vgpa_energy_full's dEsde_dth / dEsde_dsig) for D > 64;
  *   - VGPA_FETCH_PSIT / VGPA_FETCH_DESDE_DS in the time-chunked large-D sweep (they are never resident there).
- * The matrix-core stepping kernels cover D <= 44 with symmetric inputs; 44 < D <= 64 and non-symmetric operator-level
- * inputs run on the generic LDS kernels (same results, ~15x slower at D = 40). */
+ * The matrix-core stepping kernels cover D <= 64 with symmetric inputs; non-symmetric operator-level inputs run on the
+ * generic LDS kernels (same results, ~15x slower at D = 40). */
 
 /* lifetime ------------------------------------------------------------------------------- */
 int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg);

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import vgpa_amd as va
-from vgpa_amd._lib import FLAG_FORCE_GENERIC
+from vgpa_amd._lib import FLAG_FORCE_GENERIC, FLAG_SYM_UNITS
 from conftest import rel_err
 from oracle import vgpa_oracle as vo
 
@@ -80,6 +80,39 @@ def test_every_block_geometry(d, method):
     n = 14 if d <= 44 else 8
     p, x = make_problem("L96", d, n, method=method)
     check(p, x)
+
+
+@pytest.mark.parametrize("d", [45, 48, 57, 64])
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_matrix_core_steppers_above_44(d, method):
+    """44 < D <= 64: the symmetric-unit kernels (ode_sym_impl.h) are the only matrix-core steppers there."""
+    p, x = make_problem("L96", d, 9, method=method)
+    check(p, x)
+
+
+@pytest.mark.parametrize("d", [5, 8, 9, 12, 17, 24, 31, 36, 40, 44])
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_symmetric_unit_steppers_every_geometry(d, method):
+    """The symmetric-unit kernels where the role-specialised ones are the default (VGPA_FLAG_SYM_UNITS), odd D included."""
+    p, x = make_problem("L96", d, 12, method=method)
+    check(p, x, flags=FLAG_SYM_UNITS)
+
+
+@pytest.mark.parametrize("model,d", [("L96", 12), ("L96", 40), ("L96", 52)])
+def test_symmetric_unit_steppers_dense_inputs_and_batches(model, d):
+    rng = np.random.default_rng(3)
+    h = np.eye(d) + 0.1 * rng.standard_normal((d, d))
+    p, x = make_problem(model, d, 16, dense=True, h_op=h)          # dense Sigma / S0 / R / H: dense matrix jumps
+    check(p, x, flags=FLAG_SYM_UNITS)
+    p, x = make_problem(model, d, 23, method="rk4")
+    ctx = gpu_context(p, batch=3, flags=FLAG_SYM_UNITS)
+    xb = np.stack([x + 0.01 * rng.standard_normal(x.size) for _ in range(3)])
+    fb, gb = ctx.sweep(xb)
+    for i in range(3):
+        f_ref, g_ref, _ = vo.sweep(p, xb[i], faithful=False)
+        assert abs(fb[i] - f_ref) <= TOL * abs(f_ref)
+        assert rel_err(gb[i], g_ref) < TOL
+    ctx.close()
 
 
 @pytest.mark.parametrize("model,d", [("L96", 12), ("L96", 40), ("L63", 3)])

@@ -1,0 +1,125 @@
+// Micro-benchmark for the symmetric-unit stage (round 2): Z = Aop^T X + X^T Aop on 2x2-block units of the upper triangle,
+// unit-major with the element-wise update and the direct + mirror publish behind each unit, ONE barrier per stage.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off sym_product.hip -o sym_product
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d2_t __attribute__((ext_vector_type(2)));
+constexpr int NB = 10, P = 40, KKE = 10, RP = 2 * KKE, NKP = KKE / 2, LDX = 80, NSB = 5, NU = 15, MAXS = 4;
+constexpr int XS = RP * LDX;
+
+template <int RL, int MODE>   // RL: slots [r*RL, (r+1)*RL) share their a fragments; MODE 1: update + publish + barrier; 2: barrier only
+__global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters, int pad_lds) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* X0 = smem; double* X1 = X0 + XS; double* R = X1 + XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 3 * XS; i += 256) smem[i] = 1e-3 * (i % 97);
+  const int r4 = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3, bi = b >> 1, bj = b & 1;
+  constexpr int NA = MAXS / RL;
+  int colI[NA], colJ[MAXS], offD[MAXS], offM[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) {
+    int u = wave + 4 * s; if (u >= NU) u = NU - 1;
+    int I0 = 0, rem = u;
+    while (rem >= NSB - I0) { rem -= NSB - I0; I0++; }
+    const int J0 = I0 + rem;
+    const int Ib = 2 * I0 + bi, Jb = 2 * J0 + bj;
+    if (s % RL == 0) colI[s / RL] = 2 * ((4 * Ib + c4) ^ r4);
+    colJ[s] = 2 * ((4 * Jb + c4) ^ r4);
+    const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+    offD[s] = (row >> 1) * LDX + 2 * (col ^ ((row >> 1) & 3)) + (row & 1);
+    offM[s] = (col >> 1) * LDX + 2 * (row ^ ((col >> 1) & 3)) + (col & 1);
+  }
+  double xk[MAXS], acc[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) { xk[s] = 0.001 * lane; acc[s] = 0.0; }
+  __syncthreads();
+  long long t0 = clock64();
+  for (int it = 0; it < iters; it++) {
+    const double* Xc = (it & 1) ? X1 : X0;
+    double* Xn = (it & 1) ? X0 : X1;
+    const double* pa = R + r4 * LDX;
+    const double* px = Xc + r4 * LDX;
+    double w[MAXS];
+    d2_t a1[2][NA], a2[2][NA], b1[2][MAXS], b2[2][MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) w[s] = -xk[s];
+    auto load = [&](int buf, int kp) {
+#pragma unroll
+      for (int r = 0; r < NA; r++) {
+        a1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colI[r]);
+        a2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colI[r]);
+      }
+#pragma unroll
+      for (int s = 0; s < MAXS; s++) {
+        b1[buf][s] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colJ[s]);
+        b2[buf][s] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colJ[s]);
+      }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < NKP; kp++) {
+      const int cur = kp & 1;
+      if (kp + 1 < NKP) load(cur ^ 1, kp + 1);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int s = 0; s < MAXS; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur][s / RL][h], b1[cur][s][h], w[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < MAXS; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][s / RL][h], b2[cur][s][h], w[s], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+      if (MODE == 1) {
+        const double f = -w[s];
+        acc[s] = acc[s] + 2.0 * f;
+        const double xn = xk[s] + 0.005 * f;
+        Xn[offD[s]] = xn;
+        Xn[offM[s]] = xn;
+      } else {
+        acc[s] += w[s];
+      }
+    }
+    __syncthreads();
+  }
+  long long t1 = clock64();
+  double sum = 0;
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) sum += acc[s];
+  if (sum == 1.2345) sink[tid] = sum;
+  if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <int IL, int MODE>
+void run(long long* d, double* sink, const char* name) {
+  const int iters = 2000;
+  for (int two : {0, 1}) {
+    const size_t lds = two ? 3 * XS * 8 : 100 * 1024;    // 46 KB -> several workgroups per CU; 100 KB -> one
+    auto kern = k<IL, MODE>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int blocks : {256, 512, 768}) {
+      if (!two && blocks != 256) continue;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d, sink, iters, 0); hipDeviceSynchronize();
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d, sink, iters, 0);
+      hipEventRecord(e1); hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      long long h[4]; hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+      printf("%-28s RL=%d lds=%3zuKB blocks=%3d: %.3f ms = %.0f ns per stage-launch; wave cycles/stage %.0f %.0f %.0f %.0f  %s\n", name, IL, lds / 1024, blocks, ms,
+             ms * 1e6 / iters, (double)h[0] / iters, (double)h[1] / iters, (double)h[2] / iters, (double)h[3] / iters, hipGetErrorString(hipGetLastError()));
+    }
+  }
+}
+
+int main() {
+  long long* d; hipMalloc(&d, 8 * 4 * 1024);
+  double* sink; hipMalloc(&sink, 8 * 256);
+  run<1, 2>(d, sink, "db product + barrier");
+  run<2, 2>(d, sink, "db product + barrier");
+  run<4, 2>(d, sink, "db product + barrier");
+  run<1, 1>(d, sink, "db product+update+publish+bar");
+  run<2, 1>(d, sink, "db product+update+publish+bar");
+  run<4, 1>(d, sink, "db product+update+publish+bar");
+  return 0;
+}

@@ -20,6 +20,7 @@ FETCH_IDS = {"mt": 0, "st": 1, "lamt": 2, "psit": 3, "Efx": 4, "Edf": 5, "dEsde_
 FLAG_FORCE_GENERIC = 1
 FLAG_STREAM_LARGE_D = 4
 FLAG_LIBRARY_GEMM = 8
+FLAG_SYM_UNITS = 16
 OPT_LD_CHUNK = 1
 
 # exported symbols, checked by the CPU test-suite against include/vgpa_hip.h

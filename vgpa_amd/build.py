@@ -33,7 +33,7 @@ def _newer(src, dst, extra=()):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(CSRC, "ode_mfma_impl.h"),
+    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(CSRC, "ode_mfma_impl.h"), os.path.join(CSRC, "ode_sym_impl.h"),
                os.path.join(HERE, "..", "include", "vgpa_hip.h")]
     objs, procs = [], []
     for s in SOURCES:

@@ -6,7 +6,7 @@ namespace vgpa {
 bool ode_mfma_supported(int method, bool, int D) {
   if (D < 1) return false;
   const int nb = (D + 3) / 4;
-  if (nb > mfma::kMaxNB) return false;
+  if (nb > 16) return false;   // sym::kMaxNB: D <= 64
   switch (method) {
     case VGPA_ODE_EULER: return mfma_method_supported<VGPA_ODE_EULER>(nb);
     case VGPA_ODE_HEUN: return mfma_method_supported<VGPA_ODE_HEUN>(nb);

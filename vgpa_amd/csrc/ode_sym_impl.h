@@ -1,0 +1,626 @@
+// Symmetric-unit stepping kernels (round 2, second design): the slope of the symmetric recursion on the fp64 matrix cores
+// WITHOUT a transpose exchange, one workgroup barrier per Runge-Kutta stage, two workgroups (problems) per CU.
+// (Included by ode_mfma_m{0,1,2,3}.hip next to ode_mfma_impl.h, which keeps the role-specialised kernels.)
+//
+// Math.  With X symmetric (X = S_k forward, Psi_t backward) and Aop the operand matrix (A^T forward, A backward; row index
+// = contraction index) the slope of both recursions is f = -Z, Z = Aop^T X + X^T Aop - F  (ode_solver.py:60,94; F = Sigma
+// forward, dEsde_dS backward).  Z is symmetric, so only the blocks on and above the diagonal are computed -- each as
+//     Z[I][J] = sum_k Aop[k][I] X[k][J] + sum_k X[k][I] Aop[k][J] - F[I][J]
+// i.e. TWO chains of 4x4x4 matrix-core products into ONE accumulator.  The lane that holds an accumulator element owns the
+// Runge-Kutta state of that element (S_k / Psi_t, the slope sum): it applies the stepper right behind the last product
+// and publishes the new stage state at (row, col) AND at (col, row) of the next stage's operand buffer.  Nothing is
+// exchanged, nothing is read back, the element-wise work of one unit runs under the products of the next.
+//
+// Mapping to gfx950.
+//   * Unit = 2x2 blocks of 4x4 = one v_mfma_f64_4x4x4_4b_f64 accumulator: super-block (c, j) of the upper triangle (or
+//     (j, c) of the lower one -- same thing by symmetry).  Units are dealt to waves in RUNS of two that share the
+//     super-row c, hence their a-fragments (sym_run): D = 40 has 15 units = 8 runs, two runs per wave; per k-pair a wave
+//     reads 12 fragments (ds_read_b128, each feeding two k-steps) for 16 products.
+//   * LDS: two stage-state buffers (read X_cur, publish into X_next: no second barrier), two A-operand buffers (start /
+//     end point, mid-point), all in ONE layout: element (k, c) at (k >> 1) * LD + 2 (c ^ ((k >> 1) & 3)) + (k & 1),
+//     LD = 16 (mod 32) doubles (a ds_read_b128 lane group holds lanes of TWO adjacent row pairs, each reading the same 8
+//     units of a 2x2-block operand: 128 bytes apart they use disjoint halves of the 64 banks; = 0 (mod 16) keeps the
+//     mirror publish below conflict-free).  Rows 2p, 2p+1 share a 16-byte unit (one read feeds two k-steps); the XOR of the unit's
+//     column with the row pair's low bits costs the fragment reads nothing (row pair = 4 kp + lane / 16, so the XOR is a
+//     per-lane constant) and makes the mirror publish conflict-free (the 16 lanes of a store group hit 16 different
+//     8-byte slots).  74.6 KB at D = 40: two workgroups per CU, 256 registers each.
+//   * The vector recursion (m / lambda) is independent of the matrix one.  Its inner product is split over all 256
+//     threads (partial sums before the barrier); behind the barrier EVERY wave sums them and advances its own copy of the
+//     vector, so no second barrier orders "vector published" before "next partial sums".
+//   * A(t) is staged HBM -> registers -> LDS one step ahead beside the products; S_k / Psi_t go back to HBM from the
+//     stage buffer (coalesced row-pair items) while the first product of the next step runs.
+#pragma once
+#include "ode_mfma_impl.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace vgpa {
+namespace sym {
+
+using mfma::cdiv;
+using mfma::cmax;
+using mfma::cmin;
+using mfma::d2_t;
+using mfma::ldg;
+using mfma::n_stages;
+using mfma::settle;
+using mfma::stage_op;
+using mfma::stg;
+#ifdef VGPA_STAMPS
+using mfma::g_stamp;
+#endif
+using mfma::OP_M;
+using mfma::OP_R;
+using mfma::OP_X;
+
+constexpr int kMaxNB = 16;          // D <= 64
+
+// ---- runs: a cover of the unordered pairs {c, j} of super-block indices (loops included) by stars of <= 2 edges ---------
+// Run = super-row c with up to two partners.  Greedy: every loop (c, c) with the edge to c + 1; then, vertex by vertex, two
+// uncovered edges at a time; what is left are single edges.  Returns the `want`-th run (c = -1 beyond the last one) and,
+// through `count`, their number.  Bit (8 i + j), i <= j, of `cov` = pair covered.
+struct Run { int c, j0, j1; };
+
+__host__ __device__ constexpr unsigned long long pair_bit(int i, int j) {
+  return 1ull << (i <= j ? 8 * i + j : 8 * j + i);
+}
+
+__host__ __device__ constexpr Run sym_run(int nsb, int want, int* count) {
+  unsigned long long cov = 0ull;
+  int n = 0;
+  Run res{-1, -1, -1};
+  for (int c = 0; c < nsb; c++) {
+    int j1 = (c + 1) % nsb;
+    if (j1 == c || (cov & pair_bit(c, j1))) j1 = -1;
+    cov |= pair_bit(c, c);
+    if (j1 >= 0) cov |= pair_bit(c, j1);
+    if (n == want) res = Run{c, c, j1};
+    n++;
+  }
+  for (int v = 0; v < nsb; v++) {
+    for (;;) {
+      int a = -1, b = -1;
+      for (int j = 0; j < nsb; j++) {
+        if (j == v || (cov & pair_bit(v, j))) continue;
+        if (a < 0) a = j;
+        else if (b < 0) b = j;
+      }
+      if (b < 0) break;
+      cov |= pair_bit(v, a) | pair_bit(v, b);
+      if (n == want) res = Run{v, a, b};
+      n++;
+    }
+  }
+  for (int v = 0; v < nsb; v++)
+    for (int j = v + 1; j < nsb; j++) {
+      if (cov & pair_bit(v, j)) continue;
+      cov |= pair_bit(v, j);
+      if (n == want) res = Run{v, j, -1};
+      n++;
+    }
+  if (count) *count = n;
+  return res;
+}
+
+__host__ __device__ constexpr int sym_run_count(int nsb) {
+  int n = 0;
+  (void)sym_run(nsb, -2, &n);
+  return n;
+}
+
+template <int NB_>
+struct SGeo {
+  static constexpr int NB = NB_;
+  static constexpr int P = 4 * NB;                 // padded to 4x4 blocks
+  static constexpr int NSB = (NB + 1) / 2;         // 8x8 super-blocks per dimension
+  static constexpr int KKE = 2 * NSB;              // k-steps (4 rows each), even
+  static constexpr int PP = 4 * KKE;               // padded to super-blocks
+  static constexpr int RP = 2 * KKE;               // row pairs of a buffer
+  static constexpr int NKP = NSB;                  // k-pairs (fragment reads) per product chain
+  static constexpr int LD = 32 * cdiv(2 * PP - 16, 32) + 16;   // doubles per row pair, = 16 (mod 32): see the header
+  static constexpr int XS = RP * LD;
+  static constexpr int NRUNS = sym_run_count(NSB);
+  static constexpr int NR = cdiv(NRUNS, 4);        // runs per wave
+  static constexpr int MAXS = 2 * NR;              // unit slots per wave
+  // vector recursion
+  static constexpr int XV = PP + 4;                // one copy of the stage vector per wave
+  static constexpr int NPARTF = cmin(256 / PP, RP);          // forward: lane = (column i, part of the row pairs)
+  static constexpr int RPP = cdiv(RP, NPARTF);
+  static constexpr int NPF = cmin(NPARTF, cdiv(RP, RPP));    // parts that hold a sum
+  static constexpr int NCB = PP / 4;                         // backward: lane = (row pair, part of the 4-column blocks)
+  static constexpr int NPARTB = cmin(256 / RP, NCB);
+  static constexpr int CBP = cdiv(NCB, NPARTB);
+  static constexpr int NPART = cmax(NPF, NPARTB);
+  static constexpr int PV = NPART * PP;
+  static constexpr int NIT = cdiv((P / 2) * P, 256);         // row-pair items per thread (column fastest)
+  static constexpr int NTILE = cdiv(P / 2, 8) * cdiv(P, 8);  // forward staging: 8 x 8 tiles of (row pair, column)
+  static constexpr int NITF = cdiv(NTILE, 4);
+  static constexpr size_t LDS_DOUBLES = (size_t)4 * XS + 4 * XV + 2 * PV + 2 * 256;
+  static_assert(NPARTF >= 1 && NPARTB >= 1, "dimension too large for 256 threads");
+};
+
+// element (k, c) of a buffer
+template <int NB>
+__host__ __device__ constexpr int elem_off(int k, int c) {
+  return (k >> 1) * SGeo<NB>::LD + 2 * (c ^ ((k >> 1) & 3)) + (k & 1);
+}
+// 16-byte unit (row pair p, column c)
+template <int NB>
+__host__ __device__ constexpr int unit_off(int p, int c) {
+  return p * SGeo<NB>::LD + 2 * (c ^ (p & 3));
+}
+
+// row-pair items, column fastest over the threads: the HBM side of the state stores and of the backward operand staging
+template <int NB>
+struct ItemTab {
+  static constexpr int NIT = SGeo<NB>::NIT;
+  int lo[NIT];          // unit offset inside a buffer, or -1
+  unsigned g0[NIT];     // byte offset of element (2p, c) in a D x D matrix
+  unsigned g1[NIT];     // ... of element (2p+1, c); = g0 when that row does not exist (the value is dropped)
+  bool two[NIT];        // row 2p+1 exists
+};
+template <int NB>
+__device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB>& T) {
+  using g = SGeo<NB>;
+#pragma unroll
+  for (int q = 0; q < g::NIT; q++) {
+    const int e = tid + 256 * q;
+    const int p = e / g::P, c = e - p * g::P;
+    const bool ok = 2 * p < D && c < D;
+    T.lo[q] = ok ? unit_off<NB>(p, c) : -1;
+    T.g0[q] = ok ? 8u * (unsigned)(2 * p * D + c) : 0u;
+    T.two[q] = ok && 2 * p + 1 < D;
+    T.g1[q] = T.two[q] ? T.g0[q] + 8u * (unsigned)D : T.g0[q];
+  }
+}
+
+// forward operand staging (operand = A^T: unit (sp, so) = A[so][2sp], A[so][2sp+1]) in 8 x 8 tiles: the 8 lanes of a
+// ds_write_b128 group store 8 consecutive columns of one row pair (conflict-free), a wave reads 8 rows x 128 contiguous bytes
+template <int NB>
+struct TileTab {
+  static constexpr int NIT = SGeo<NB>::NITF;
+  int lo[NIT];
+  unsigned g0[NIT], g1[NIT];   // byte offsets of A[so][2sp], A[so][2sp+1] (g1 = g0 when column 2sp+1 does not exist)
+  bool two[NIT];
+};
+template <int NB>
+__device__ __forceinline__ void build_tiles(int D, int wave, int lane, TileTab<NB>& T) {
+  using g = SGeo<NB>;
+  constexpr int nsot = cdiv(g::P, 8);
+#pragma unroll
+  for (int q = 0; q < g::NITF; q++) {
+    const int tile = wave + 4 * q;
+    const int spt = tile / nsot, sot = tile - spt * nsot;
+    const int sp = 8 * spt + (lane >> 3), so = 8 * sot + (lane & 7);
+    const bool ok = 2 * sp < D && so < D;
+    T.lo[q] = ok ? unit_off<NB>(sp, so) : -1;
+    T.g0[q] = ok ? 8u * (unsigned)(so * D + 2 * sp) : 0u;
+    T.two[q] = ok && 2 * sp + 1 < D;
+    T.g1[q] = T.two[q] ? T.g0[q] + 8u : T.g0[q];
+  }
+}
+
+// Memory waits.  The compiler's wait-count pass cannot tell, across the loop back-edge, how old a loaded value is: the first
+// use of ANY value loaded in the previous iteration becomes s_waitcnt vmcnt(0) -- it waits for every load and store issued so
+// far.  So a step issues all its HBM loads at ONE point (behind the staging of stage min(1, NS-1): A, the forcing terms, the
+// jumps of two steps ahead) and consumes them at ONE point (the rotation at the top of the next step, >= 1 stage later).
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE>   // WPE: waves per SIMD the register budget allows for
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
+#pragma clang fp contract(fast)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using g = SGeo<NB>;
+  constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = g::MAXS, LD = g::LD, NKP = g::NKP;
+  constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
+  constexpr int JSEC = NS > 1 ? 1 : 0;
+  constexpr double sixth = 1.0 / 6.0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = (int)blockIdx.x;
+  const int D = a.D, Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
+  const double dt = a.dt, h = 0.5 * a.dt;
+  double* const Xb0 = smem;
+  double* const Xb1 = Xb0 + g::XS;
+  double* const Rb = Xb1 + g::XS;
+  double* const Mb = Rb + g::XS;
+  double* const xvw = Mb + g::XS + wave * g::XV;           // this wave's copy of the stage vector
+  double* const pvb = Mb + g::XS + 4 * g::XV;              // [2][NPART][PP] partial inner products
+  double* const trash = pvb + 2 * g::PV + 2 * tid;         // one 16-byte unit per thread
+  for (int i = tid; i < (int)g::LDS_DOUBLES; i += 256) smem[i] = 0.0;
+  auto tidx = [&](int i) { return FWD ? i : Np - 1 - i; };
+  auto tclamp = [&](int i) { return tidx(i <= n_steps ? i : n_steps); };
+
+  // ---- unit slots of this lane ------------------------------------------------------------------------------------------
+  const int r4 = lane >> 4, bq = (lane >> 2) & 3, c4 = lane & 3, bi = bq >> 1, bj = bq & 1;
+  int colI[NR], colJ[MAXS], offD[MAXS], offM[MAXS];
+  unsigned gofs[MAXS];
+  bool own[MAXS], wd[MAXS], wm[MAXS];
+#pragma unroll
+  for (int rl = 0; rl < NR; rl++) {
+    const Run run = sym_run(g::NSB, wave + 4 * rl, nullptr);
+    const bool rv = run.c >= 0;
+    const int c = rv ? run.c : 0;
+    const int Ib = 2 * c + bi;
+    colI[rl] = 2 * ((4 * Ib + c4) ^ r4);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int s = 2 * rl + t;
+      const int jr = t ? run.j1 : run.j0;
+      const bool valid = rv && jr >= 0;
+      const int j = valid ? jr : 0;
+      const int Jb = 2 * j + bj;
+      const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+      colJ[s] = 2 * ((4 * Jb + c4) ^ r4);
+      offD[s] = elem_off<NB>(row, col);
+      offM[s] = elem_off<NB>(col, row);
+      const bool act = valid && (c != j || row <= col);    // diagonal super-blocks: the upper half represents
+      wd[s] = act;
+      wm[s] = act && row != col;
+      own[s] = act && row < D && col < D;
+      gofs[s] = own[s] ? 8u * (unsigned)(row * D + col) : 0u;
+    }
+  }
+  ItemTab<NB> IT;
+  build_items<NB>(D, tid, IT);
+  TileTab<NB> TT;
+  if (FWD) build_tiles<NB>(D, wave, lane, TT);
+
+  // ---- operand staging --------------------------------------------------------------------------------------------------
+  const double* A = a.A + (size_t)prob * a.strideA;
+  d2_t an[NITS];
+  auto load_a = [&](const double* At) {
+#pragma unroll
+    for (int q = 0; q < NITS; q++) {
+      an[q][0] = ldg(At, FWD ? TT.g0[q] : IT.g0[q]);
+      an[q][1] = ldg(At, FWD ? TT.g1[q] : IT.g1[q]);
+    }
+  };
+  auto unit_ptr = [&](double* buf, int q) -> d2_t* {
+    const int lo = FWD ? TT.lo[q] : IT.lo[q];
+    return reinterpret_cast<d2_t*>(lo >= 0 ? buf + lo : trash);
+  };
+  auto store_a = [&](double* buf, const d2_t (&v)[NITS]) {
+#pragma unroll
+    for (int q = 0; q < NITS; q++) {
+      d2_t o = v[q];
+      if (!(FWD ? TT.two[q] : IT.two[q])) o[1] = 0.0;
+      *unit_ptr(buf, q) = o;
+    }
+  };
+  // beside the stages of step `step` (see mfma::stage_op): M <- mid-point / end point (stage 0), R <- end point (stage JSEC)
+  auto stage_after = [&](int j, int step) {
+    if (j == 0) {
+      double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
+      if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) {
+        d2_t mid[NITS];
+#pragma unroll
+        for (int q = 0; q < NITS; q++) mid[q] = *unit_ptr(Rb, q);
+#pragma unroll
+        for (int q = 0; q < NITS; q++) { mid[q][0] = 0.5 * (mid[q][0] + an[q][0]); mid[q][1] = 0.5 * (mid[q][1] + an[q][1]); }
+        store_a(dst, mid);
+      } else {
+        store_a(dst, an);
+      }
+    }
+    if (j == JSEC && NS > 1) store_a(Rb, an);
+  };
+
+  // ---- matrix state -----------------------------------------------------------------------------------------------------
+  const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
+  double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * DD;
+  double xk[MAXS], acc[MAXS], fc[MAXS], fn[MAXS], fnn[MAXS], jsc[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) {
+    fc[s] = ldg(G + (FWD ? 0 : (size_t)tidx(0) * DD), gofs[s]);
+    fn[s] = FWD ? 0.0 : ldg(G + (size_t)tclamp(1) * DD, gofs[s]);
+    fnn[s] = 0.0;
+    xk[s] = (FWD && own[s]) ? ldg(a.S0, gofs[s]) : 0.0;
+    acc[s] = 0.0;
+    jsc[s] = (!FWD && !DENSEJ && a.js_const && own[s]) ? ldg(a.js_const, gofs[s]) : 0.0;
+  }
+
+  // ---- vector state: every wave keeps the whole vector in its lanes < D (the other lanes compute along on element 0) ----
+  const bool vl = lane < D;
+  const unsigned lane8 = vl ? 8u * (unsigned)lane : 0u;
+  double* const xv_mine = vl ? xvw + lane : trash;
+  const double* cin = FWD ? a.b + (size_t)prob * a.strideB : a.dEm + (size_t)prob * Np * D;
+  double* const vout = (FWD ? a.m : a.lam) + (size_t)prob * Np * D;
+  auto vec = [&](int t) { return (size_t)t * D; };
+  const bool sparse_j = !FWD && !DENSEJ && a.obs_idx && a.jm_sparse;
+  // vector jump behind the step that ends at grid point t (n_obs: its observation index or -1)
+  auto jump_vector = [&](int t, int n_obs) -> double {
+    if (!FWD && DENSEJ) return ldg(a.jm_dense + ((size_t)prob * Np + t) * D, lane8);
+    if (sparse_j && __builtin_amdgcn_readfirstlane(n_obs) >= 0) return ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs) * D, lane8);
+    return 0.0;
+  };
+  double vk = FWD ? ldg(a.m0, lane8) : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  double c0 = ldg(cin + vec(tidx(0)), lane8), c1 = ldg(cin + vec(tclamp(1)), lane8), c2 = 0.0;
+  int n_obs_cur = sparse_j ? a.obs_idx[tclamp(1)] : -1, n_obs_next = sparse_j ? a.obs_idx[tclamp(2)] : -1, n_obs_nn = -1;
+  double jm = n_steps >= 1 ? jump_vector(tidx(1), n_obs_cur) : 0.0, jm_next = 0.0;
+
+  __syncthreads();                       // LDS zero-filled
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) {       // first stage state
+    if (FWD) {
+      *(wd[s] ? Xb0 + offD[s] : trash) = xk[s];
+      *(wm[s] ? Xb0 + offM[s] : trash) = xk[s];
+    }
+  }
+  *xv_mine = vk;
+  load_a(A + (size_t)tidx(0) * DD);
+  store_a(Rb, an);
+  load_a(A + (size_t)tclamp(1) * DD);
+#pragma unroll
+  for (int s = 0; s < MAXS; s++) { settle(fc[s]); settle(fn[s]); settle(xk[s]); settle(jsc[s]); }
+  settle(c0); settle(c1); settle(vk); settle(jm);
+#pragma unroll
+  for (int q = 0; q < NITS; q++) settle(an[q]);
+  __syncthreads();                       // prologue published
+
+  // S_k / Psi_t and m_k / lam_t of grid point t to HBM: the matrix from the stage buffer that holds it
+  auto store_state = [&](const double* Xc, int t) {
+    double* so = mout + (size_t)t * DD;
+    d2_t v[g::NIT];
+#pragma unroll
+    for (int q = 0; q < g::NIT; q++) v[q] = *reinterpret_cast<const d2_t*>(IT.lo[q] >= 0 ? Xc + IT.lo[q] : trash);
+#pragma unroll
+    for (int q = 0; q < g::NIT; q++) {
+      if (IT.lo[q] >= 0) {
+        stg(so, IT.g0[q], v[q][0]);
+        if (IT.two[q]) stg(so, IT.g1[q], v[q][1]);
+      }
+    }
+    if (wave == 0 && vl) stg(vout + vec(t), lane8, vk);
+  };
+
+  // every HBM load of a step, issued together (see "Memory waits"): what the step after the next one needs
+  auto prefetch = [&](int step) {
+    load_a(A + (size_t)tclamp(step + 2) * DD);
+    c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+    if (!FWD) {
+#pragma unroll
+      for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * DD, gofs[s]);
+      jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
+      n_obs_nn = (sparse_j && step + 3 <= n_steps) ? a.obs_idx[tidx(step + 3)] : -1;
+    }
+  };
+
+  // partial inner products of the vector's slope, all threads; pv = this stage's half of the partial-sum buffer
+  auto matvec_partials = [&](const double* Aop, double* pv) {
+    if (FWD) {          // sum_k Aop[k][i] v[k]: lane = (i, part of the row pairs)
+      const int part0 = tid / g::PP, i = tid - part0 * g::PP;
+      const bool act = part0 < g::NPF;
+      const int part = act ? part0 : 0;
+      d2_t av[g::RPP], xq[g::RPP];
+#pragma unroll
+      for (int r = 0; r < g::RPP; r++) {
+        const int rp0 = part * g::RPP + r;
+        const bool in = rp0 < g::RP;
+        const int rp = in ? rp0 : 0;
+        av[r] = *reinterpret_cast<const d2_t*>(Aop + unit_off<NB>(rp, i));
+        xq[r] = *reinterpret_cast<const d2_t*>(xvw + 2 * rp);
+        if (!in) xq[r] = d2_t{0.0, 0.0};
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < g::RPP; r++) {
+        s = __builtin_fma(av[r][0], xq[r][0], s);
+        s = __builtin_fma(av[r][1], xq[r][1], s);
+      }
+      *(act ? pv + part * g::PP + i : trash) = s;
+    } else {            // sum_k Aop[i][k] v[k]: lane = (row pair ip, part of the 4-column blocks, rotated by ip / 4)
+      const int part0 = tid / g::RP, ip = tid - part0 * g::RP;
+      const bool act = part0 < g::NPARTB;
+      const int part = act ? part0 : 0;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < g::CBP; q++) {
+        const int cbq = part + q * g::NPARTB;
+        const bool in = cbq < g::NCB;
+        int cb = (in ? cbq : 0) + (ip >> 2);
+        if (cb >= g::NCB) cb -= g::NCB;
+        d2_t av[4];
+        double xq[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          av[kk] = *reinterpret_cast<const d2_t*>(Aop + ip * LD + 2 * (4 * cb + (kk ^ (ip & 3))));   // column 4 cb + kk
+          xq[kk] = xvw[4 * cb + kk];
+          if (!in) xq[kk] = 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          s0 = __builtin_fma(av[kk][0], xq[kk], s0);
+          s1 = __builtin_fma(av[kk][1], xq[kk], s1);
+        }
+      }
+      d2_t o; o[0] = s0; o[1] = s1;
+      *reinterpret_cast<d2_t*>(act ? pv + part * g::PP + 2 * ip : trash) = o;
+    }
+  };
+
+  // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
+  auto vector_stage = [&](int j, const double* pv) {
+    constexpr int NPS = FWD ? g::NPF : g::NPARTB;
+    const double* pl = pv + (vl ? lane : 0);
+    double vs = pl[0];
+#pragma unroll
+    for (int q = 1; q < NPS; q++) vs += pl[q * g::PP];
+    const double cmid = 0.5 * (c0 + c1);
+    double vn;
+    if (METHOD == VGPA_ODE_EULER) { vk = vk + (c0 - vs) * dt + jm; vn = vk; }
+    else if (METHOD == VGPA_ODE_HEUN) {
+      if (j == 0) { v1 = c0 - vs; vn = vk + v1 * dt; }
+      else { vk = vk + h * (v1 + (c1 - vs)) + jm; vn = vk; }
+    } else if (METHOD == VGPA_ODE_RK2) {
+      if (j == 0) vn = vk + h * (c0 - vs);
+      else { vk = vk + dt * (cmid - vs) + jm; vn = vk; }
+    } else {
+      if (j == 0) { v1 = c0 - vs; vn = vk + h * v1; }
+      else if (j == 1) { v2 = cmid - vs; vn = vk + h * v2; }
+      else if (j == 2) { v3 = cmid - vs; vn = vk + dt * v3; }
+      else { vk = vk + (dt * (v1 + 2.0 * (v2 + v3) + (c1 - vs))) * sixth + jm; vn = vk; }
+    }
+    *xv_mine = vn;
+  };
+
+  // the stepper on one owned element: slope f = -z of stage j; returns the next stage state
+  auto element = [&](int s, int j, double z, double js) -> double {
+    const double f = -z;
+    double xn;
+    if (METHOD == VGPA_ODE_EULER) { xk[s] = xk[s] + f * dt + js; xn = xk[s]; }
+    else if (METHOD == VGPA_ODE_HEUN) {
+      if (j == 0) { acc[s] = f; xn = xk[s] + f * dt; }
+      else { xk[s] = xk[s] + h * (acc[s] + f) + js; xn = xk[s]; }
+    } else if (METHOD == VGPA_ODE_RK2) {
+      if (j == 0) xn = xk[s] + h * f;
+      else { xk[s] = xk[s] + dt * f + js; xn = xk[s]; }
+    } else {                                            // acc = k1 + 2 k2 + 2 k3 + k4, summed as the stages come
+      if (j == 0) { acc[s] = f; xn = xk[s] + h * f; }
+      else if (j == 1) { acc[s] = acc[s] + 2.0 * f; xn = xk[s] + h * f; }
+      else if (j == 2) { acc[s] = acc[s] + 2.0 * f; xn = xk[s] + dt * f; }
+      else { xk[s] = xk[s] + (dt * (acc[s] + f)) * sixth + js; xn = xk[s]; }
+    }
+    return xn;
+  };
+
+  // products + stepper + publish of stage j, GR runs at a time
+  auto product_stage = [&](int j, int step, const double* Aop, const double* Xc, double* Xn) {
+    const double* pa = Aop + r4 * LD;
+    const double* px = Xc + r4 * LD;
+    const bool last = (j == NS - 1);
+    const bool jump_now = !FWD && last && !DENSEJ && __builtin_amdgcn_readfirstlane(n_obs_cur) >= 0;
+#pragma unroll
+    for (int g0 = 0; g0 < NR; g0 += GR) {
+      constexpr int NSL = 2 * GR;
+      double w[NSL], jsd[NSL];
+      d2_t a1[2][GR], a2[2][GR], b1[2][NSL], b2[2][NSL];
+#pragma unroll
+      for (int u = 0; u < NSL; u++) {
+        const int s = 2 * g0 + u;
+        double f = 0.0;
+        jsd[u] = 0.0;
+        if (s < MAXS) {
+          if (FWD || METHOD == VGPA_ODE_EULER) f = fc[s];
+          else if (METHOD == VGPA_ODE_HEUN) f = j == 0 ? fc[s] : fn[s];
+          else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
+          else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
+          f = own[s] ? -f : 0.0;
+          if (!FWD && last && DENSEJ)    // dense matrix jump behind the step (euler.py:139-149): requested before the products
+            jsd[u] = ldg(a.js_dense + ((size_t)prob * Np + tidx(step + 1)) * DD, gofs[s]);
+        }
+        w[u] = f;
+      }
+      auto load = [&](int buf, int kp) {
+#pragma unroll
+        for (int r = 0; r < GR; r++) {
+          const int rl = g0 + r < NR ? g0 + r : NR - 1;
+          a1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colI[rl]);
+          a2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colI[rl]);
+        }
+#pragma unroll
+        for (int u = 0; u < NSL; u++) {
+          const int s = 2 * g0 + u < MAXS ? 2 * g0 + u : MAXS - 1;
+          b1[buf][u] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colJ[s]);
+          b2[buf][u] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colJ[s]);
+        }
+      };
+      load(0, 0);
+#pragma unroll
+      for (int kp = 0; kp < NKP; kp++) {
+        const int cur = kp & 1;
+        if (kp + 1 < NKP) load(cur ^ 1, kp + 1);
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+          for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur][u >> 1][hh], b1[cur][u][hh], w[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][u >> 1][hh], b2[cur][u][hh], w[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NSL; u++) {
+        const int s = 2 * g0 + u;
+        if (s < MAXS) {
+          double js = 0.0;
+          if (!FWD && last) js = DENSEJ ? (own[s] ? jsd[u] : 0.0) : (jump_now ? jsc[s] : 0.0);
+          const double xn = element(s, j, w[u], js);
+          *(wd[s] ? Xn + offD[s] : trash) = xn;
+          *(wm[s] ? Xn + offM[s] : trash) = xn;
+        }
+      }
+    }
+  };
+
+  // ---- time loop ----------------------------------------------------------------------------------------------------------
+#ifdef VGPA_SYM_PRIO
+  // two workgroups share every SIMD: give the wave in the odd hardware slot a static priority, so that the pair does not
+  // settle into taking turns instruction by instruction (MI355X_MICROARCH "two waves per SIMD", item 4)
+  if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_setprio(VGPA_SYM_PRIO);
+#endif
+  // stage buffer that holds the current stage state: with an even number of stages per step a compile-time function of j
+  VGPA_STAMP_DECL;
+  for (int k = 0; k < n_steps; k++) {
+    if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
+      c0 = c1; c1 = c2;
+#pragma unroll
+      for (int q = 0; q < NITS; q++) settle(an[q]);
+      if (!FWD) {
+#pragma unroll
+        for (int s = 0; s < MAXS; s++) { fc[s] = fn[s]; fn[s] = fnn[s]; }
+        jm = jm_next; n_obs_cur = n_obs_next; n_obs_next = n_obs_nn;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      const int par = (NS & 1) ? (k & 1) : (j & 1);
+      const double* Xc = par ? Xb1 : Xb0;
+      double* Xn = par ? Xb0 : Xb1;
+      double* pv = pvb + par * g::PV;
+      const int opm = stage_op<METHOD, FWD>(j, true, k);
+      product_stage(j, k, opm == OP_X ? Xc : (opm == OP_M ? Mb : Rb), Xc, Xn);
+      VGPA_STAMP(0, 0);
+      const int opv = stage_op<METHOD, FWD>(j, false, k);
+      matvec_partials(opv == OP_M ? Mb : Rb, pv);
+      VGPA_STAMP(0, 1);
+      stage_after(j, k);
+      if (j == 0) store_state(Xc, tidx(k));
+      if (j == JSEC) prefetch(k);
+      VGPA_STAMP(0, 2);
+      __syncthreads();
+      VGPA_STAMP(0, 3);
+      vector_stage(j, pv);
+      VGPA_STAMP(0, 4);
+    }
+  }
+  store_state(((NS & 1) && (n_steps & 1)) ? Xb1 : Xb0, tidx(n_steps));
+}
+
+template <int METHOD, bool FWD, int NB>
+hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
+  constexpr size_t lds = SGeo<NB>::LDS_DOUBLES * sizeof(double);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+#ifndef VGPA_SYM_GR
+#define VGPA_SYM_GR 1
+#endif
+  constexpr int GR = SGeo<NB>::NR >= VGPA_SYM_GR ? VGPA_SYM_GR : 1;
+  const bool dense = !FWD && a.js_dense;
+  constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
+  auto kern = dense ? k_ode_sym<METHOD, FWD, NB, true, GR, WPE> : k_ode_sym<METHOD, FWD, NB, false, GR, WPE>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(a.batch), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// D <= 44 has both kernel families.  Default: the role-specialised 8-wave kernels of ode_mfma_impl.h (faster for one problem
+// per CU and for a single problem); VGPA_ODE_KERNEL=sym selects the symmetric-unit kernels (faster from two problems per CU on).
+inline bool use_sym_kernels() {
+  static const bool sym = [] { const char* e = getenv("VGPA_ODE_KERNEL"); return e && !strcmp(e, "sym"); }();
+  return sym;
+}
+template <int METHOD, bool FWD, int NB>
+hipError_t launch_any(const OdeArgs& a, hipStream_t st) {
+  if (a.sym_units || use_sym_kernels()) return launch_sym<METHOD, FWD, NB>(a, st);
+  return mfma::launch_nb<METHOD, FWD, NB>(a, st);
+}
+
+}  // namespace sym
+}  // namespace vgpa

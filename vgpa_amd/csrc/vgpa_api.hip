@@ -199,6 +199,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
     return VGPA_OK;
   }
   OdeArgs a{};
+  a.sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) ? 1 : 0;
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
@@ -228,6 +229,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
     return VGPA_OK;
   }
   OdeArgs a{};
+  a.sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) ? 1 : 0;
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;

@@ -16,6 +16,7 @@ constexpr int kMaxTheta = 4;
 // Arguments of the time-stepping kernels (fwd: moments, bwd: Lagrange multipliers).
 struct OdeArgs {
   int D, Np, batch;
+  int sym_units;            // D <= 44: symmetric-unit kernels instead of the role-specialised ones (VGPA_FLAG_SYM_UNITS)
   size_t strideA, strideB;  // elements between consecutive problems in A / b (x layout: len_x for both)
   double dt;
   // forward
