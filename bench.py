@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="independent problems per GPU per step")
     ap.add_argument("--np", dest="n_pts", type=int, default=1001)
     ap.add_argument("--dim", type=int, default=40)
     ap.add_argument("--method", default="RK4")
@@ -239,9 +239,14 @@ def main():
     }
     nb_blocks = (d + 3) // 4
     method_id = {"EULER": 0, "HEUN": 1, "RK2": 2, "RK4": 3}.get(args.method.upper(), 3)
-    # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 44)
-    symbols = {"solve_fwd": f"vgpa::mfma::k_ode_pe<{method_id}, true, {nb_blocks}, false>",
-               "solve_bwd": f"vgpa::mfma::k_ode_pe<{method_id}, false, {nb_blocks}, false>",
+    # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 64): symmetric-unit kernels from two
+    # problems per CU on (and for 44 < D), role-specialised ones below (vgpa_api.hip::use_sym_units)
+    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    sym_units = d > 44 or B >= 2 * n_cu or os.environ.get("VGPA_ODE_KERNEL") == "sym"
+    wpe = 2 if nb_blocks <= 10 else 1
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, 1, {wpe}>") if sym_units else \
+               (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
+    symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
                "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():

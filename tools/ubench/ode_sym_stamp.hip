@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   printf("%s RK4 D=40 Np=%d B=%d GR=%d: %.3f ms  (%.0f cycles/stage at 2.2 GHz)  err=%s\n", fwd ? "fwd" : "bwd", Np, B, VGPA_SYM_GR, ms, ms * 1e-3 * 2.2e9 / (4 * (Np - 1)), hipGetErrorString(hipGetLastError()));
 #ifdef VGPA_STAMPS
   long long st[4][8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(mfma::g_stamp), sizeof(st));
-  const char* pn[5] = {"product+update+publish", "partials", "staging+stores+prefetch", "barrier", "vector"};
+  const char* pn[5] = {"product+update+publish", "tail", "barrier", "next fragments + vector", "-"};
   printf("wave 0 of workgroup 0, cycles/stage:"); for (int i = 0; i < 5; i++) printf(" [%s %lld]", pn[i], st[0][i] / (4 * (Np - 1))); printf("\n");
 #endif
   return 0;

@@ -200,6 +200,11 @@ __device__ __forceinline__ void build_tiles(int D, int wave, int lane, TileTab<N
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier: the fence also waits
+// for every outstanding HBM access (vmcnt(0)) -- here the state stores of stage 0 and the prefetches of stage 1, i.e. a full
+// HBM round trip in front of two of the four barriers of a step.  The waves of a workgroup exchange nothing through HBM.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Memory waits.  The compiler's wait-count pass cannot tell, across the loop back-edge, how old a loaded value is: the first
 // use of ANY value loaded in the previous iteration becomes s_waitcnt vmcnt(0) -- it waits for every load and store issued so
 // far.  So a step issues all its HBM loads at ONE point (behind the staging of stage min(1, NS-1): A, the forcing terms, the
@@ -285,24 +290,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       *unit_ptr(buf, q) = o;
     }
   };
-  // beside the stages of step `step` (see mfma::stage_op): M <- mid-point / end point (stage 0), R <- end point (stage JSEC)
-  auto stage_after = [&](int j, int step) {
-    if (j == 0) {
-      double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
-      if (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4) {
-        d2_t mid[NITS];
-#pragma unroll
-        for (int q = 0; q < NITS; q++) mid[q] = *unit_ptr(Rb, q);
-#pragma unroll
-        for (int q = 0; q < NITS; q++) { mid[q][0] = 0.5 * (mid[q][0] + an[q][0]); mid[q][1] = 0.5 * (mid[q][1] + an[q][1]); }
-        store_a(dst, mid);
-      } else {
-        store_a(dst, an);
-      }
-    }
-    if (j == JSEC && NS > 1) store_a(Rb, an);
-  };
-
   // ---- matrix state -----------------------------------------------------------------------------------------------------
   const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
   double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * DD;
@@ -356,11 +343,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   __syncthreads();                       // prologue published
 
   // S_k / Psi_t and m_k / lam_t of grid point t to HBM: the matrix from the stage buffer that holds it
-  auto store_state = [&](const double* Xc, int t) {
+  auto store_items = [&](const d2_t (&v)[g::NIT], int t) {
     double* so = mout + (size_t)t * DD;
-    d2_t v[g::NIT];
-#pragma unroll
-    for (int q = 0; q < g::NIT; q++) v[q] = *reinterpret_cast<const d2_t*>(IT.lo[q] >= 0 ? Xc + IT.lo[q] : trash);
 #pragma unroll
     for (int q = 0; q < g::NIT; q++) {
       if (IT.lo[q] >= 0) {
@@ -369,6 +353,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       }
     }
     if (wave == 0 && vl) stg(vout + vec(t), lane8, vk);
+  };
+  auto load_items = [&](const double* Xc, d2_t (&v)[g::NIT]) {
+#pragma unroll
+    for (int q = 0; q < g::NIT; q++) v[q] = *reinterpret_cast<const d2_t*>(IT.lo[q] >= 0 ? Xc + IT.lo[q] : trash);
   };
 
   // every HBM load of a step, issued together (see "Memory waits"): what the step after the next one needs
@@ -383,57 +371,89 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     }
   };
 
-  // partial inner products of the vector's slope, all threads; pv = this stage's half of the partial-sum buffer
-  auto matvec_partials = [&](const double* Aop, double* pv) {
-    if (FWD) {          // sum_k Aop[k][i] v[k]: lane = (i, part of the row pairs)
-      const int part0 = tid / g::PP, i = tid - part0 * g::PP;
-      const bool act = part0 < g::NPF;
-      const int part = act ? part0 : 0;
-      d2_t av[g::RPP], xq[g::RPP];
+  // Everything of stage j that is not the matrix product, as ONE LDS round trip: all reads (operand and stage-vector entries
+  // of the vector's partial inner products; at stage 0 the start-point operand for the mid-point and the stage state for
+  // HBM), then the arithmetic, then all LDS writes, then the HBM stores and -- at stage JSEC -- the step's HBM loads.  (An LDS
+  // read cannot be moved above an LDS write by the compiler, so read-compute-write pieces in sequence cost one round trip
+  // each.)  Partial inner products: forward sum_k Aop[k][i] v[k], lane = (i, part of the row pairs); backward
+  // sum_k Aop[i][k] v[k], lane = (row pair ip, part of the 4-column blocks, rotated by ip / 4: conflict-free).
+  auto tail = [&](int j, int step, const double* Aop, const double* Xc, double* pv) {
+    constexpr bool MID = (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4);
+    constexpr int NAV = FWD ? g::RPP : 4 * g::CBP;
+    d2_t av[NAV], xqf[FWD ? g::RPP : 1], mid[NITS], items[g::NIT];
+    double xqb[FWD ? 1 : 4 * g::CBP];
+    const int pdiv = FWD ? g::PP : g::RP;
+    const int part0 = tid / pdiv, idx = tid - part0 * pdiv;       // forward: idx = column i; backward: idx = row pair ip
+    const bool act = part0 < (FWD ? g::NPF : g::NPARTB);
+    const int part = act ? part0 : 0;
+    // ---- reads
+    if (FWD) {
 #pragma unroll
       for (int r = 0; r < g::RPP; r++) {
         const int rp0 = part * g::RPP + r;
-        const bool in = rp0 < g::RP;
-        const int rp = in ? rp0 : 0;
-        av[r] = *reinterpret_cast<const d2_t*>(Aop + unit_off<NB>(rp, i));
-        xq[r] = *reinterpret_cast<const d2_t*>(xvw + 2 * rp);
-        if (!in) xq[r] = d2_t{0.0, 0.0};
+        const int rp = rp0 < g::RP ? rp0 : 0;
+        av[r] = *reinterpret_cast<const d2_t*>(Aop + unit_off<NB>(rp, idx));
+        xqf[r] = *reinterpret_cast<const d2_t*>(xvw + 2 * rp);
       }
-      double s = 0.0;
-#pragma unroll
-      for (int r = 0; r < g::RPP; r++) {
-        s = __builtin_fma(av[r][0], xq[r][0], s);
-        s = __builtin_fma(av[r][1], xq[r][1], s);
-      }
-      *(act ? pv + part * g::PP + i : trash) = s;
-    } else {            // sum_k Aop[i][k] v[k]: lane = (row pair ip, part of the 4-column blocks, rotated by ip / 4)
-      const int part0 = tid / g::RP, ip = tid - part0 * g::RP;
-      const bool act = part0 < g::NPARTB;
-      const int part = act ? part0 : 0;
-      double s0 = 0.0, s1 = 0.0;
+    } else {
 #pragma unroll
       for (int q = 0; q < g::CBP; q++) {
         const int cbq = part + q * g::NPARTB;
-        const bool in = cbq < g::NCB;
-        int cb = (in ? cbq : 0) + (ip >> 2);
+        int cb = (cbq < g::NCB ? cbq : 0) + (idx >> 2);
         if (cb >= g::NCB) cb -= g::NCB;
-        d2_t av[4];
-        double xq[4];
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          av[kk] = *reinterpret_cast<const d2_t*>(Aop + ip * LD + 2 * (4 * cb + (kk ^ (ip & 3))));   // column 4 cb + kk
-          xq[kk] = xvw[4 * cb + kk];
-          if (!in) xq[kk] = 0.0;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          s0 = __builtin_fma(av[kk][0], xq[kk], s0);
-          s1 = __builtin_fma(av[kk][1], xq[kk], s1);
+          av[4 * q + kk] = *reinterpret_cast<const d2_t*>(Aop + idx * LD + 2 * (4 * cb + (kk ^ (idx & 3))));   // column 4 cb + kk
+          xqb[4 * q + kk] = xvw[4 * cb + kk];
         }
       }
-      d2_t o; o[0] = s0; o[1] = s1;
-      *reinterpret_cast<d2_t*>(act ? pv + part * g::PP + 2 * ip : trash) = o;
     }
+    if (j == 0 && MID) {
+#pragma unroll
+      for (int q = 0; q < NITS; q++) mid[q] = *unit_ptr(Rb, q);
+    }
+    if (j == 0) load_items(Xc, items);
+    // ---- arithmetic
+    double s0 = 0.0, s1 = 0.0;
+    if (FWD) {
+#pragma unroll
+      for (int r = 0; r < g::RPP; r++) {
+        const bool in = part * g::RPP + r < g::RP;
+        s0 = __builtin_fma(av[r][0], in ? xqf[r][0] : 0.0, s0);
+        s0 = __builtin_fma(av[r][1], in ? xqf[r][1] : 0.0, s0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < g::CBP; q++) {
+        const bool in = part + q * g::NPARTB < g::NCB;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double xv = in ? xqb[4 * q + kk] : 0.0;
+          s0 = __builtin_fma(av[4 * q + kk][0], xv, s0);
+          s1 = __builtin_fma(av[4 * q + kk][1], xv, s1);
+        }
+      }
+    }
+    if (j == 0 && MID) {
+#pragma unroll
+      for (int q = 0; q < NITS; q++) { mid[q][0] = 0.5 * (mid[q][0] + an[q][0]); mid[q][1] = 0.5 * (mid[q][1] + an[q][1]); }
+    }
+    // ---- LDS writes (operand staging: see mfma::stage_op -- M <- mid-point / end point at stage 0, R <- end point at JSEC)
+    if (FWD) {
+      *(act ? pv + part * g::PP + idx : trash) = s0;
+    } else {
+      d2_t o; o[0] = s0; o[1] = s1;
+      *reinterpret_cast<d2_t*>(act ? pv + part * g::PP + 2 * idx : trash) = o;
+    }
+    if (j == 0) {
+      double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
+      if (MID) store_a(dst, mid);
+      else store_a(dst, an);
+    }
+    if (j == JSEC && NS > 1) store_a(Rb, an);
+    // ---- HBM
+    if (j == 0) store_items(items, tidx(step));
+    if (j == JSEC) prefetch(step);
   };
 
   // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
@@ -481,69 +501,78 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     return xn;
   };
 
-  // products + stepper + publish of stage j, GR runs at a time
+  // ---- the product of a stage: NG groups of GR runs, NKP k-pairs each, as ONE software pipeline of NG * NKP steps -----------
+  // Step t = (group, k-pair): the fragments of step t + 1 are requested before the products of step t issue -- also across
+  // the group boundary (the next group's first fragments are on their way while this group's stepper runs) and across the
+  // STAGE boundary: product_begin requests step 0 of the next stage right behind the barrier, in front of the vector work.
+  constexpr int NG = cdiv(NR, GR), NSL = 2 * GR, NSTEP = NG * NKP;
+  d2_t fa1[2][GR], fa2[2][GR], fb1[2][NSL], fb2[2][NSL];
+  auto frag_load = [&](int buf, int t, const double* pa, const double* px) {
+    const int g0 = (t / NKP) * GR, kp = t % NKP;
+#pragma unroll
+    for (int r = 0; r < GR; r++) {
+      const int rl = g0 + r < NR ? g0 + r : NR - 1;
+      fa1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colI[rl]);
+      fa2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colI[rl]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSL; u++) {
+      const int sl = 2 * g0 + u < MAXS ? 2 * g0 + u : MAXS - 1;
+      fb1[buf][u] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colJ[sl]);
+      fb2[buf][u] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colJ[sl]);
+    }
+  };
+  auto product_begin = [&](const double* Aop, const double* Xc) { frag_load(0, 0, Aop + r4 * LD, Xc + r4 * LD); };
+
+  // products (their step-0 fragments are in flight) + stepper + publish of stage j
   auto product_stage = [&](int j, int step, const double* Aop, const double* Xc, double* Xn) {
     const double* pa = Aop + r4 * LD;
     const double* px = Xc + r4 * LD;
     const bool last = (j == NS - 1);
     const bool jump_now = !FWD && last && !DENSEJ && __builtin_amdgcn_readfirstlane(n_obs_cur) >= 0;
+    double jsd[MAXS];
+    if (!FWD && last && DENSEJ) {        // dense matrix jump behind the step (euler.py:139-149): requested before the products
 #pragma unroll
-    for (int g0 = 0; g0 < NR; g0 += GR) {
-      constexpr int NSL = 2 * GR;
-      double w[NSL], jsd[NSL];
-      d2_t a1[2][GR], a2[2][GR], b1[2][NSL], b2[2][NSL];
+      for (int s = 0; s < MAXS; s++) jsd[s] = ldg(a.js_dense + ((size_t)prob * Np + tidx(step + 1)) * DD, gofs[s]);
+    }
+    double w[NSL];
 #pragma unroll
-      for (int u = 0; u < NSL; u++) {
-        const int s = 2 * g0 + u;
-        double f = 0.0;
-        jsd[u] = 0.0;
-        if (s < MAXS) {
-          if (FWD || METHOD == VGPA_ODE_EULER) f = fc[s];
-          else if (METHOD == VGPA_ODE_HEUN) f = j == 0 ? fc[s] : fn[s];
-          else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
-          else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
-          f = own[s] ? -f : 0.0;
-          if (!FWD && last && DENSEJ)    // dense matrix jump behind the step (euler.py:139-149): requested before the products
-            jsd[u] = ldg(a.js_dense + ((size_t)prob * Np + tidx(step + 1)) * DD, gofs[s]);
-        }
-        w[u] = f;
-      }
-      auto load = [&](int buf, int kp) {
-#pragma unroll
-        for (int r = 0; r < GR; r++) {
-          const int rl = g0 + r < NR ? g0 + r : NR - 1;
-          a1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colI[rl]);
-          a2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colI[rl]);
-        }
+    for (int t = 0; t < NSTEP; t++) {
+      const int gi = t / NKP, kp = t % NKP, g0 = gi * GR, cur = t & 1;
+      if (t + 1 < NSTEP) frag_load(cur ^ 1, t + 1, pa, px);
+      if (kp == 0) {                     // accumulators start from minus the stage's forcing term
 #pragma unroll
         for (int u = 0; u < NSL; u++) {
-          const int s = 2 * g0 + u < MAXS ? 2 * g0 + u : MAXS - 1;
-          b1[buf][u] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colJ[s]);
-          b2[buf][u] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colJ[s]);
-        }
-      };
-      load(0, 0);
-#pragma unroll
-      for (int kp = 0; kp < NKP; kp++) {
-        const int cur = kp & 1;
-        if (kp + 1 < NKP) load(cur ^ 1, kp + 1);
-#pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-#pragma unroll
-          for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur][u >> 1][hh], b1[cur][u][hh], w[u], 0, 0, 0);
-#pragma unroll
-          for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][u >> 1][hh], b2[cur][u][hh], w[u], 0, 0, 0);
+          const int s = 2 * g0 + u;
+          double f = 0.0;
+          if (s < MAXS) {
+            if (FWD || METHOD == VGPA_ODE_EULER) f = fc[s];
+            else if (METHOD == VGPA_ODE_HEUN) f = j == 0 ? fc[s] : fn[s];
+            else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
+            else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
+            f = own[s] ? -f : 0.0;
+          }
+          w[u] = f;
         }
       }
 #pragma unroll
-      for (int u = 0; u < NSL; u++) {
-        const int s = 2 * g0 + u;
-        if (s < MAXS) {
-          double js = 0.0;
-          if (!FWD && last) js = DENSEJ ? (own[s] ? jsd[u] : 0.0) : (jump_now ? jsc[s] : 0.0);
-          const double xn = element(s, j, w[u], js);
-          *(wd[s] ? Xn + offD[s] : trash) = xn;
-          *(wm[s] ? Xn + offM[s] : trash) = xn;
+      for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+        for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa1[cur][u >> 1][hh], fb1[cur][u][hh], w[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa2[cur][u >> 1][hh], fb2[cur][u][hh], w[u], 0, 0, 0);
+      }
+      if (kp == NKP - 1) {
+#pragma unroll
+        for (int u = 0; u < NSL; u++) {
+          const int s = 2 * g0 + u;
+          if (s < MAXS) {
+            double js = 0.0;
+            if (!FWD && last) js = DENSEJ ? (own[s] ? jsd[s] : 0.0) : (jump_now ? jsc[s] : 0.0);
+            const double xn = element(s, j, w[u], js);
+            *(wd[s] ? Xn + offD[s] : trash) = xn;
+            *(wm[s] ? Xn + offM[s] : trash) = xn;
+          }
         }
       }
     }
@@ -555,7 +584,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // settle into taking turns instruction by instruction (MI355X_MICROARCH "two waves per SIMD", item 4)
   if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_setprio(VGPA_SYM_PRIO);
 #endif
-  // stage buffer that holds the current stage state: with an even number of stages per step a compile-time function of j
+  // which buffers stage j of step k reads: the stage buffer that holds the current stage state (with an even number of
+  // stages per step a compile-time function of j) and the A operand of the matrix / of the vector
+  auto xcur = [&](int k, int j) -> double* { return (((NS & 1) ? (k & 1) : (j & 1)) ? Xb1 : Xb0); };
+  auto aop = [&](int k, int j, bool matrix) -> const double* {
+    const int op = stage_op<METHOD, FWD>(j, matrix, k);
+    return op == OP_X ? xcur(k, j) : (op == OP_M ? Mb : Rb);
+  };
+  product_begin(aop(0, 0, true), xcur(0, 0));
   VGPA_STAMP_DECL;
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
@@ -570,27 +606,27 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     }
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-      const int par = (NS & 1) ? (k & 1) : (j & 1);
-      const double* Xc = par ? Xb1 : Xb0;
-      double* Xn = par ? Xb0 : Xb1;
-      double* pv = pvb + par * g::PV;
-      const int opm = stage_op<METHOD, FWD>(j, true, k);
-      product_stage(j, k, opm == OP_X ? Xc : (opm == OP_M ? Mb : Rb), Xc, Xn);
+      const double* Xc = xcur(k, j);
+      double* Xn = (Xc == Xb0) ? Xb1 : Xb0;
+      double* pv = pvb + (Xc == Xb0 ? 0 : g::PV);
+      product_stage(j, k, aop(k, j, true), Xc, Xn);
       VGPA_STAMP(0, 0);
-      const int opv = stage_op<METHOD, FWD>(j, false, k);
-      matvec_partials(opv == OP_M ? Mb : Rb, pv);
+      tail(j, k, aop(k, j, false), Xc, pv);
       VGPA_STAMP(0, 1);
-      stage_after(j, k);
-      if (j == 0) store_state(Xc, tidx(k));
-      if (j == JSEC) prefetch(k);
+      lds_barrier();
       VGPA_STAMP(0, 2);
-      __syncthreads();
-      VGPA_STAMP(0, 3);
+      // the next stage's first fragments (Xn is complete now; past the last stage of the sweep they are read and dropped)
+      const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
+      product_begin(aop(kn, jn, true), Xn);
       vector_stage(j, pv);
-      VGPA_STAMP(0, 4);
+      VGPA_STAMP(0, 3);
     }
   }
-  store_state(((NS & 1) && (n_steps & 1)) ? Xb1 : Xb0, tidx(n_steps));
+  {
+    d2_t items[g::NIT];
+    load_items(xcur(n_steps, 0), items);
+    store_items(items, tidx(n_steps));
+  }
 }
 
 template <int METHOD, bool FWD, int NB>

@@ -178,6 +178,20 @@ static bool use_wave(vgpa_ctx* c) {
   return c->D >= 2 && c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && c->B < 512;
 }
 
+// D <= 44 has two families of matrix-core stepping kernels: the symmetric-unit ones (two problems per CU, 4 waves each) win
+// once every CU gets two problems, the role-specialised ones (one problem per CU, 8 waves) below that and for one problem.
+static bool use_sym_units(vgpa_ctx* c) {
+  if (c->cfg.flags & VGPA_FLAG_SYM_UNITS) return true;
+  static int n_cu[64] = {0};
+  const int dev = c->cfg.device >= 0 && c->cfg.device < 64 ? c->cfg.device : 0;
+  if (!n_cu[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu[dev] = v;
+  }
+  return c->B >= 2 * n_cu[dev];
+}
+
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
   return sym && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && ode_mfma_supported(c->cfg.method, fwd, c->D);
 }
@@ -199,7 +213,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
     return VGPA_OK;
   }
   OdeArgs a{};
-  a.sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) ? 1 : 0;
+  a.sym_units = use_sym_units(c) ? 1 : 0;
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
@@ -229,7 +243,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
     return VGPA_OK;
   }
   OdeArgs a{};
-  a.sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) ? 1 : 0;
+  a.sym_units = use_sym_units(c) ? 1 : 0;
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
