@@ -15,7 +15,7 @@ import re
 import sqlite3
 import sys
 
-KEYS = [(r"k_ode_pe<\d+, true", "solve_fwd"), (r"k_ode_pe<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"),
+KEYS = [(r"k_ode_(pe|sym)<\d+, true", "solve_fwd"), (r"k_ode_(pe|sym)<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"),
         (r"k_grad", "grad")]
 
 
@@ -70,7 +70,12 @@ def traffic(fetch_db, write_db, B, D, Np, out_csv, out_json):
         fh.write("kernel,grid_size,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected\n")
         for r in rows:
             fh.write('"%s",%s,%d,%.1f,%.1f,%.0f\n' % r)
-    json.dump(res, open(out_json, "w"), indent=1)
+    try:                                   # keep the entries of other batch sizes / dimensions
+        old = json.load(open(out_json))
+    except (OSError, ValueError):
+        old = {}
+    old.update(res)
+    json.dump(old, open(out_json, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 
 
