@@ -261,6 +261,30 @@ int vgpa_shard_solve_fwd(vgpa_shard* s, const double* lin_a, const double* off_b
                          const double* sigma, double* m_own, double* s_own);
 int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde_dm, const double* desde_ds,
                          const double* deobs_dm, const double* deobs_ds, double* lam_own, double* psi_own);
+/* The fused sweep -- free energy AND gradient of VarGP (src/var_bayes/variational.py:141-288) -- of ONE Lorenz-96 problem
+ * (diagonal system noise, diagonal R, H = I: the restrictions of every D > 64 path) on the row-sharded recursion:
+ *   forward recursion, row-sharded, (m_t, S_t) time-sharded  ->  observation terms and E_sde terms of the rank's own grid
+ *   points (time-parallel: lorenz_96.py:316-438 per grid point)  ->  ONE grouped all-gather of dEsde_dm / dEsde_dS / E_sde(t)
+ *   (+ a small one of the observation jumps)  ->  backward recursion, row-sharded  ->  gradient of the own grid points.
+ * x_dev = [A_t (Np,D,D) | b_t (Np,D)] replicated on every rank (device); F comes back on every rank (host); the gradient
+ * stays TIME-sharded: grad_a_own [t_hi - t_lo][D][D], grad_b_own [t_hi - t_lo][D] (device).  Memory per rank besides x: one
+ * gathered (Np, D, D) array (dEsde_dS) and four time slices (S, Psi, dEsde_dS, the gradient).  Synchronises the shard's
+ * stream before returning.  VGPA_ERR_NOT_PD when a marginal covariance S_t of an own grid point is not positive definite. */
+typedef struct {
+  double theta;                   /* Lorenz-96 forcing */
+  const double* inv_sigma_diag;   /* [D] device: diagonal of Sigma^-1 */
+  const double* m0;               /* [D] device */
+  const double* s0;               /* [D][D] device */
+  const double* sigma;            /* [D][D] device */
+  int32_t n_obs;
+  const int64_t* obs_t;           /* [n_obs] HOST: grid indices of the observations, increasing */
+  const double* obs_y;            /* [n_obs][D] device */
+  const double* obs_rinv_diag;    /* [D] device: diagonal of R^-1 */
+  double obs_const;               /* n_obs (D log(2 pi) + log det R)  (gaussian_like.py:87-92) */
+  double e0;                      /* KL(q0||p0), constant in x */
+} vgpa_shard_problem;
+int vgpa_shard_sweep(vgpa_shard* s, const vgpa_shard_problem* problem, const double* x_dev, double* f_host,
+                     double* grad_a_own, double* grad_b_own);
 /* RCCL behind the vgpa_comm table: collectives over xGMI; the library is dlopen'ed on first use */
 #define VGPA_RCCL_UNIQUE_ID_BYTES 128
 int vgpa_rccl_unique_id(void* out_128_bytes);

@@ -477,6 +477,49 @@ def test_native_sharded_driver_with_virtual_ranks(method, d, n, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,d,n,world", [("rk4", 128, 11, 2), ("rk4", 96, 13, 3), ("heun", 192, 9, 4), ("euler", 80, 7, 1),
+                                              ("rk2", 128, 10, 4), ("rk4", 1024, 10, 8)])
+def test_native_sharded_fused_sweep_with_virtual_ranks(method, d, n, world):
+    """vgpa_shard_sweep: forward (row-sharded) -> time-parallel observation / E_sde terms -> one all-gather -> backward
+    (row-sharded) -> time-parallel gradient.  F on every rank and every rank's gradient slice vs the oracle's sweep."""
+    import threading
+    import torch
+    from vgpa_amd.large_d import NativeShardedRecursion
+    from test_gpu_edge_cases import make_problem
+    p, x = make_problem("L96", d, n, method=method)
+    f_o, g_o, _ = vo.sweep(p, x, faithful=False)
+    ga_o, gb_o = g_o[:n * d * d].reshape(n, d, d), g_o[n * d * d:].reshape(n, d)
+    e0 = float(np.asarray(vo.kl0(p)))
+    comm = _CallbackComm(world)
+    errs, fails = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            rec = NativeShardedRecursion(method, p.dt, d, n, rank=rank, world=world, device=0,
+                                         comm=comm.table(rank) if world > 1 else None)
+            lo, hi = rec.time_slice
+            for _ in range(2):             # twice: the buffers of the first call are reused
+                f, ga, gb = rec.sweep(x, p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), e0)
+            e = abs(f - f_o) / abs(f_o)
+            if hi > lo:
+                e = max(e, rel_err(ga.cpu().numpy(), ga_o[lo:hi]), rel_err(gb.cpu().numpy(), gb_o[lo:hi]))
+            errs[rank] = e
+            rec.close()
+        except BaseException as exc:      # noqa: BLE001 - a dead thread would leave the others at the barrier
+            fails.append(exc)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not fails, fails
+    assert all(e is not None and e < TOL for e in errs), errs
+
+
+@pytest.mark.gpu
 def test_rccl_table_single_rank():
     """librccl behind vgpa_comm: unique id through the C ABI, communicator of one rank on this GPU, a grouped in-place
     all-gather and an all-to-all through the table's function pointers."""

@@ -32,7 +32,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming",
            "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x",
            "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
-           "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
+           "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
            "vgpa_rccl_comm_destroy"]
 
 P_DOUBLE = POINTER(c_double)
@@ -56,6 +56,13 @@ class VgpaComm(ctypes.Structure):
     """vgpa_comm (include/vgpa_hip.h): the collectives of the row-sharded recursion as a table of function pointers."""
     _fields_ = [("user", c_void_p), ("all_gather", COMM_COLLECTIVE), ("all_to_all", COMM_COLLECTIVE),
                 ("group_begin", COMM_GROUP), ("group_end", COMM_GROUP)]
+
+
+class VgpaShardProblem(ctypes.Structure):
+    """vgpa_shard_problem (include/vgpa_hip.h): what the fused row-sharded sweep needs besides x (device pointers, obs_t host)."""
+    _fields_ = [("theta", c_double), ("inv_sigma_diag", c_void_p), ("m0", c_void_p), ("s0", c_void_p), ("sigma", c_void_p),
+                ("n_obs", c_int32), ("obs_t", POINTER(c_int64)), ("obs_y", c_void_p), ("obs_rinv_diag", c_void_p),
+                ("obs_const", c_double), ("e0", c_double)]
 
 
 class VgpaConfig(ctypes.Structure):
@@ -124,6 +131,8 @@ def load():
     lib.vgpa_shard_synchronize.argtypes = [c_void_p]
     lib.vgpa_shard_solve_fwd.argtypes = [c_void_p] + [c_void_p] * 7
     lib.vgpa_shard_solve_bwd.argtypes = [c_void_p] + [c_void_p] * 7
+    lib.vgpa_shard_sweep.argtypes = [c_void_p, POINTER(VgpaShardProblem), c_void_p, P_DOUBLE, c_void_p, c_void_p]
+    lib.vgpa_shard_sweep.restype = c_int
     lib.vgpa_rccl_unique_id.argtypes = [c_void_p]
     lib.vgpa_rccl_comm_create.argtypes = [POINTER(VgpaComm), c_void_p, c_int, c_int, c_int]
     lib.vgpa_rccl_comm_destroy.argtypes = [POINTER(VgpaComm)]

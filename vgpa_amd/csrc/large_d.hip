@@ -19,6 +19,7 @@
 // (A lane map i = l & 15, k = l >> 4; B k = l >> 4, j = l & 15; C col = l & 15, row = (l >> 4) + 4 r -- probed,
 // profiles/r01_fp64_mfma_layout_probe.txt), LDS tiles stored k-major with leading dimensions chosen for
 // conflict-free b64 fragment reads, register-prefetched global loads, two LDS buffers, one barrier per k-step.
+#include <cmath>
 #include <cstdlib>
 
 #include "vgpa_internal.h"
@@ -806,9 +807,26 @@ hipError_t shard_solve_fwd(ShardCtx& c, int Np, const double* A, const double* b
   return hipSuccess;
 }
 
-// (lam_t, Psi_t) with dense jump arrays (operator level); same ownership of the grid.
-hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const double* gm, const double* gs, const double* jm,
-                           const double* js, double* lam_own, double* psi_own) {
+// Inputs of the backward recursion.  dEsde_dm / dEsde_dS either as plain [Np] arrays (operator level) or as the all-gathered
+// time slices of the fused sweep, [world][pad_len] (slot() maps a grid point to its place); jumps either as dense [Np]
+// arrays (operator level; zero rows off the observations) or sparse: observation index per grid point (host), one
+// vector per observation, one constant matrix.
+struct BwdIn {
+  const double* gm = nullptr; const double* gs = nullptr;
+  int pad_len = 0, world = 1, Np = 0;
+  const double* jm_dense = nullptr; const double* js_dense = nullptr;
+  const int32_t* obs_idx = nullptr; const double* jm_sparse = nullptr; const double* js_const = nullptr;
+  size_t slot(int t) const {
+    if (!pad_len) return (size_t)t;
+    const int base = Np / world, rem = Np % world;
+    const int q = (t < rem * (base + 1)) ? t / (base + 1) : rem + (base ? (t - rem * (base + 1)) / base : 0);
+    const int lo = q * base + (q < rem ? q : rem);
+    return (size_t)q * pad_len + (t - lo);
+  }
+};
+
+// (lam_t, Psi_t); same ownership of the grid as the forward recursion.
+hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const BwdIn& in, double* lam_own, double* psi_own) {
   const int D = c.D;
   const size_t DD = (size_t)D * D;
   const double dt = c.dt, h = 0.5 * dt;
@@ -825,9 +843,12 @@ hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const double* g
   };
   LD_TRY(keep(Np - 1, w.cur, w.vcur));
   for (int t = Np - 1; t > 0; t--) {
-    const double *At = A + t * DD, *Am = A + (t - 1) * DD, *Gt = gs + t * DD, *Gm = gs + (t - 1) * DD;
-    const double *gt = gm + (size_t)t * D, *gmm = gm + (size_t)(t - 1) * D;
-    const double *Jn = js + (size_t)(t - 1) * DD, *jn = jm + (size_t)(t - 1) * D;
+    const double *At = A + t * DD, *Am = A + (t - 1) * DD, *Gt = in.gs + in.slot(t) * DD, *Gm = in.gs + in.slot(t - 1) * DD;
+    const double *gt = in.gm + in.slot(t) * D, *gmm = in.gm + in.slot(t - 1) * D;
+    const int nobs = in.obs_idx ? in.obs_idx[t - 1] : 0;        // sparse jumps: only behind a step that ends at an observation
+    const bool has_jump = in.obs_idx ? nobs >= 0 : true;
+    const double* Jn = in.obs_idx ? in.js_const : in.js_dense + (size_t)(t - 1) * DD;
+    const double* jn = in.obs_idx ? in.jm_sparse + (size_t)(nobs >= 0 ? nobs : 0) * D : in.jm_dense + (size_t)(t - 1) * D;
     const double *Pt = w.cur, *lt = w.vcur;
     double *Pn = w.nxt, *ln = w.vnxt;
     StageSpec s{};
@@ -837,7 +858,7 @@ hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const double* g
                    double cx, double cf, bool jump) {
       s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
       s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
-      s.J = jump ? Jn : nullptr; s.jv = jump ? jn : nullptr;
+      s.J = (jump && has_jump) ? Jn : nullptr; s.jv = (jump && has_jump) ? jn : nullptr;
     };
     if (c.method == VGPA_ODE_EULER) {
       set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
@@ -858,6 +879,140 @@ hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const double* g
     double* t2 = w.vcur; w.vcur = w.vnxt; w.vnxt = t2;
   }
   return hipSuccess;
+}
+
+// ---- the fused sweep of ONE Lorenz-96 problem on the row-sharded recursion -----------------------------------------------
+// Observation terms with diagonal R and H = I (gaussian_like.py:87-137), time-sharded: observation n needs m at its grid
+// point t_n (owned by one rank) and -- quirk Q4 -- the diagonal of S at grid index n (owned by possibly another one).  Every
+// rank writes what it owns (zeros otherwise) into its part of the gather buffer: jm[n][:] and the scalar term of n.
+__global__ void __launch_bounds__(256) k_shard_obs(int D, int lo, int hi, const int64_t* __restrict__ obs_t, const double* __restrict__ obs_y,
+                                                   const double* __restrict__ rinv, const double* __restrict__ m_own, const double* __restrict__ S_own,
+                                                   double* __restrict__ jm, double* __restrict__ part) {
+  __shared__ double red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int64_t tn = obs_t[n];
+  const bool own_m = tn >= lo && tn < hi, own_s = n >= lo && n < hi;
+  double acc = 0.0;
+  for (int i = tid; i < D; i += 256) {
+    double j = 0.0;
+    if (own_m) {
+      const double w = obs_y[(size_t)n * D + i] - m_own[(size_t)(tn - lo) * D + i];
+      j = -(rinv[i] * w);
+      acc += w * (rinv[i] * w);
+    }
+    jm[(size_t)n * D + i] = j;
+    if (own_s) acc += rinv[i] * S_own[((size_t)(n - lo) * D + i) * D + i];
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) part[n] = red[0];
+}
+
+// sums over the ranks' parts (fixed order): jm [M][D], eobs = 0.5 (sum_n term_n + const)
+__global__ void __launch_bounds__(256) k_shard_obs_sum(int D, int M, int world, const double* __restrict__ all, double obs_const,
+                                                       double* __restrict__ jm, double* __restrict__ eobs) {
+  __shared__ double red[256];
+  const size_t cnt = (size_t)M * (D + 1);
+  const int tid = threadIdx.x;
+  for (size_t e = (size_t)blockIdx.x * 256 + tid; e < (size_t)M * D; e += (size_t)gridDim.x * 256) {
+    double v = 0.0;
+    for (int q = 0; q < world; q++) v += all[q * cnt + e];
+    jm[e] = v;
+  }
+  if (blockIdx.x == 0) {
+    double acc = 0.0;
+    for (int n = tid; n < M; n += 256)
+      for (int q = 0; q < world; q++) acc += all[q * cnt + (size_t)M * D + n];
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) eobs[0] = 0.5 * (red[0] + obs_const);
+  }
+}
+
+// e_t of the whole grid out of the gathered slices
+__global__ void __launch_bounds__(256) k_shard_unpad(int Np, int world, int pad_len, const double* __restrict__ padded, double* __restrict__ full) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Np) return;
+  const int base = Np / world, rem = Np % world;
+  const int q = (t < rem * (base + 1)) ? t / (base + 1) : rem + (base ? (t - rem * (base + 1)) / base : 0);
+  const int lo = q * base + (q < rem ? q : rem);
+  full[t] = padded[(size_t)q * pad_len + (t - lo)];
+}
+
+__global__ void k_diag_half(int D, const double* __restrict__ rinv, double* __restrict__ jsc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D) jsc[(size_t)i * D + i] = 0.5 * rinv[i];
+}
+
+struct SweepBuffers {       // device memory of the fused sweep, allocated on first use
+  double *m_own = nullptr, *S_own = nullptr, *lam_own = nullptr, *psi_own = nullptr, *Ef_own = nullptr;
+  double *gm_all = nullptr, *gs_all = nullptr, *et_all = nullptr, *et_full = nullptr, *obuf = nullptr, *jm = nullptr, *jsc = nullptr;
+  double *scal = nullptr;   // eobs, esde, f
+  double* lde_ws = nullptr;
+  int64_t* obs_t = nullptr;
+  int32_t* status = nullptr;
+  int lde_nb = 0, M = 0;
+};
+
+struct SweepProblem {
+  double theta, obs_const, e0;
+  const double *isg, *m0, *S0, *Sigma, *obs_y, *rinv;
+  int M; const int64_t* obs_t_host;
+};
+
+// fwd (row-sharded) -> observation terms + E_sde terms of the own grid points -> all-gather -> bwd (row-sharded) -> gradient
+// of the own grid points -> F.  Everything is enqueued on the shard's stream; the caller synchronises.
+hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem& p, const double* x, const std::vector<int32_t>& obs_idx,
+                       double* gA_own, double* gB_own) {
+  const int D = c.D, world = c.world;
+  const size_t DD = (size_t)D * D;
+  int lo, hi;
+  time_slice(Np, c.rank, world, &lo, &hi);
+  const int n_own = hi - lo, pad = (Np + world - 1) / world;
+  const double* A = x;
+  const double* b = x + (size_t)Np * DD;
+  hipStream_t st = c.st;
+  LD_TRY(hipMemsetAsync(B.status, 0, sizeof(int32_t), st));
+  LD_TRY(shard_solve_fwd(c, Np, A, b, p.m0, p.S0, p.Sigma, B.m_own, B.S_own));
+  // observation terms
+  const size_t ocnt = (size_t)p.M * (D + 1);
+  if (p.M > 0) {
+    double* mine = B.obuf + (size_t)c.rank * ocnt;
+    hipLaunchKernelGGL(k_shard_obs, dim3(p.M), dim3(256), 0, st, D, lo, hi, B.obs_t, p.obs_y, p.rinv, B.m_own, B.S_own, mine, mine + (size_t)p.M * D);
+    if (world > 1) SH_COMM(c.comm.all_gather(c.comm.user, mine, B.obuf, (uint64_t)ocnt, st));
+    const int blocks = (int)(((size_t)p.M * D + 255) / 256 < 1024 ? ((size_t)p.M * D + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_shard_obs_sum, dim3(blocks), dim3(256), 0, st, D, p.M, world, B.obuf, p.obs_const, B.jm, B.scal);
+  } else {
+    LD_TRY(hipMemsetAsync(B.scal, 0, sizeof(double), st));
+  }
+  // E_sde terms of the own grid points, written into this rank's part of the gather buffers
+  double* gm_mine = B.gm_all + (size_t)c.rank * pad * D;
+  double* gs_mine = B.gs_all + (size_t)c.rank * pad * DD;
+  double* et_mine = B.et_all + (size_t)c.rank * pad;
+  if (n_own > 0)
+    LD_TRY(lde_energy(D, n_own, p.theta, p.isg, A + (size_t)lo * DD, b + (size_t)lo * D, B.m_own, B.S_own, et_mine, B.Ef_own, nullptr,
+                      gm_mine, gs_mine, B.status, B.lde_ws, B.lde_nb, st));
+  if (world > 1) {
+    if (c.comm.group_begin) SH_COMM(c.comm.group_begin(c.comm.user));
+    SH_COMM(c.comm.all_gather(c.comm.user, gs_mine, B.gs_all, (uint64_t)pad * DD, st));
+    SH_COMM(c.comm.all_gather(c.comm.user, gm_mine, B.gm_all, (uint64_t)pad * D, st));
+    SH_COMM(c.comm.all_gather(c.comm.user, et_mine, B.et_all, (uint64_t)pad, st));
+    if (c.comm.group_end) SH_COMM(c.comm.group_end(c.comm.user));
+  }
+  BwdIn in;
+  in.gm = B.gm_all; in.gs = B.gs_all; in.pad_len = pad; in.world = world; in.Np = Np;
+  in.obs_idx = obs_idx.data(); in.jm_sparse = B.jm; in.js_const = B.jsc;
+  LD_TRY(shard_solve_bwd(c, Np, A, in, B.lam_own, B.psi_own));
+  if (n_own > 0)
+    LD_TRY(lde_grad(D, n_own, c.dt, p.isg, A + (size_t)lo * DD, b + (size_t)lo * D, B.m_own, B.S_own, B.lam_own, B.psi_own, B.Ef_own,
+                    gA_own, gB_own, B.lde_ws, B.lde_nb, st));
+  hipLaunchKernelGGL(k_shard_unpad, dim3((Np + 255) / 256), dim3(256), 0, st, Np, world, pad, B.et_all, B.et_full);
+  ReduceArgs r{};
+  r.Np = Np; r.batch = 1; r.dt = c.dt; r.pre = 1.0; r.div = 1.0; r.e0 = p.e0;
+  r.e_t = B.et_full; r.eobs = B.scal; r.esde = B.scal + 1; r.f = B.scal + 2;
+  return launch_reduce(r, st);
 }
 #undef SH_COMM
 #undef LD_TRY
@@ -898,6 +1053,9 @@ struct vgpa_shard {
   int Np = 0, device = 0;
   double* ws = nullptr;
   bool own_stream = false;
+  ld::SweepBuffers sb;                 // fused sweep only
+  std::vector<void*> sweep_allocs;
+  std::vector<int32_t> obs_idx;        // grid point -> observation number or -1 (host)
 };
 
 int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_pts, int rank, int world, int device,
@@ -930,6 +1088,7 @@ void vgpa_shard_destroy(vgpa_shard* s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->c.st);
   if (s->ws) (void)hipFree(s->ws);
+  for (void* q : s->sweep_allocs) (void)hipFree(q);
   if (s->own_stream) (void)hipStreamDestroy(s->c.st);
   delete s;
 }
@@ -959,8 +1118,70 @@ int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde
                          const double* deobs_dm, const double* deobs_ds, double* lam_own, double* psi_own) {
   if (!s || !lin_a || !desde_dm || !desde_ds || !deobs_dm || !deobs_ds || !lam_own || !psi_own) return VGPA_ERR_ARG;
   if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
-  return ld::shard_solve_bwd(s->c, s->Np, lin_a, desde_dm, desde_ds, deobs_dm, deobs_ds, lam_own, psi_own) == hipSuccess
-             ? VGPA_OK : VGPA_ERR_DEVICE;
+  ld::BwdIn in;
+  in.gm = desde_dm; in.gs = desde_ds; in.jm_dense = deobs_dm; in.js_dense = deobs_ds; in.Np = s->Np;
+  return ld::shard_solve_bwd(s->c, s->Np, lin_a, in, lam_own, psi_own) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
+int vgpa_shard_sweep(vgpa_shard* s, const vgpa_shard_problem* p, const double* x_dev, double* f_host, double* grad_a_own,
+                     double* grad_b_own) {
+  if (!s || !p || !x_dev || !f_host || !grad_a_own || !grad_b_own) return VGPA_ERR_ARG;
+  if (!p->inv_sigma_diag || !p->m0 || !p->s0 || !p->sigma || p->n_obs < 0) return VGPA_ERR_ARG;
+  if (p->n_obs > 0 && (!p->obs_t || !p->obs_y || !p->obs_rinv_diag)) return VGPA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  const int D = s->c.D, Np = s->Np, world = s->c.world, M = p->n_obs;
+  const size_t DD = (size_t)D * D;
+  int lo, hi;
+  ld::time_slice(Np, s->c.rank, world, &lo, &hi);
+  const size_t n_own = (size_t)(hi - lo > 0 ? hi - lo : 1), pad = (size_t)(Np + world - 1) / world;
+  ld::SweepBuffers& B = s->sb;
+  if (!B.m_own || B.M != M) {
+    for (void* q : s->sweep_allocs) (void)hipFree(q);
+    s->sweep_allocs.clear();
+    B = ld::SweepBuffers{};
+    auto alloc = [&](double** ptr, size_t n) -> bool {
+      if (hipMalloc((void**)ptr, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
+      s->sweep_allocs.push_back(*ptr);
+      return hipMemsetAsync(*ptr, 0, (n ? n : 1) * sizeof(double), s->c.st) == hipSuccess;
+    };
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    B.lde_nb = ld::lde_batch(D, std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b)));
+    if (B.lde_nb > (int)n_own) B.lde_nb = (int)n_own;
+    bool ok = alloc(&B.m_own, n_own * D) && alloc(&B.S_own, n_own * DD) && alloc(&B.lam_own, n_own * D) && alloc(&B.psi_own, n_own * DD) &&
+              alloc(&B.Ef_own, n_own * D) && alloc(&B.gm_all, (size_t)world * pad * D) && alloc(&B.gs_all, (size_t)world * pad * DD) &&
+              alloc(&B.et_all, (size_t)world * pad) && alloc(&B.et_full, (size_t)Np) && alloc(&B.obuf, (size_t)world * M * (D + 1)) &&
+              alloc(&B.jm, (size_t)M * D) && alloc(&B.jsc, DD) && alloc(&B.scal, 4) && alloc(&B.lde_ws, ld::lde_workspace_doubles(D, B.lde_nb));
+    double* tmp = nullptr;
+    ok = ok && alloc(&tmp, (size_t)M + 1);
+    B.obs_t = reinterpret_cast<int64_t*>(tmp);
+    tmp = nullptr;
+    ok = ok && alloc(&tmp, 1);
+    B.status = reinterpret_cast<int32_t*>(tmp);
+    if (!ok) return VGPA_ERR_DEVICE;
+    B.M = M;
+  }
+  // per-call problem data (cheap): observation grid, constant matrix jump 0.5 R^-1
+  s->obs_idx.assign((size_t)Np, -1);
+  for (int n = 0; n < M; n++) {
+    const int64_t t = p->obs_t[n];
+    if (t < 0 || t >= Np) return VGPA_ERR_ARG;
+    s->obs_idx[(size_t)t] = n;
+  }
+  if (M > 0) {
+    if (hipMemcpyAsync(B.obs_t, p->obs_t, sizeof(int64_t) * M, hipMemcpyHostToDevice, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+    if (hipMemsetAsync(B.jsc, 0, sizeof(double) * DD, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+    hipLaunchKernelGGL(ld::k_diag_half, dim3((D + 255) / 256), dim3(256), 0, s->c.st, D, p->obs_rinv_diag, B.jsc);
+  }
+  ld::SweepProblem sp{p->theta, p->obs_const, p->e0, p->inv_sigma_diag, p->m0, p->s0, p->sigma, p->obs_y, p->obs_rinv_diag, M, p->obs_t};
+  if (ld::shard_sweep(s->c, Np, B, sp, x_dev, s->obs_idx, grad_a_own, grad_b_own) != hipSuccess) return VGPA_ERR_DEVICE;
+  int32_t status = 0;
+  double f = 0.0;
+  if (hipMemcpyAsync(&f, B.scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  if (hipMemcpyAsync(&status, B.status, sizeof(int32_t), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  if (hipStreamSynchronize(s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  *f_host = f;
+  return (status & 1) ? VGPA_ERR_NOT_PD : VGPA_OK;
 }
 
 }  // extern "C"

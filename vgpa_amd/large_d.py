@@ -362,3 +362,39 @@ class NativeShardedRecursion:
         """(lam_t, Psi_t) for the grid points of `time_slice`."""
         return self._run(self._lib.vgpa_shard_solve_bwd, (lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds),
                          "vgpa_shard_solve_bwd")
+
+    def sweep(self, x, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+        """
+        Free energy and gradient of VarGP (variational.py:141-288) for ONE Lorenz-96 problem on the row-sharded recursion
+        (vgpa_shard_sweep): F on every rank, the gradient TIME-sharded -- returns (F, gLa_own [n_own, D, D], gLb_own [n_own, D])
+        as device tensors for the grid points of `time_slice`.  x = [A_t | b_t] (host array or device tensor, replicated);
+        diagonal system noise `sigma_diag`, diagonal observation noise `obs_noise_diag`, identity observation operator.
+        """
+        import torch
+        from ._lib import VgpaShardProblem
+        d = self.D
+        sig = np.asarray(sigma_diag, dtype=np.float64).reshape(d)
+        rdiag = np.asarray(obs_noise_diag, dtype=np.float64).reshape(d)
+        obs_t = np.ascontiguousarray(obs_t, dtype=np.int64)
+        m_obs = int(obs_t.size)
+        xd = self._dev(x)
+        keep = [xd, self._dev(1.0 / sig), self._dev(m0), self._dev(np.asarray(s0, dtype=np.float64).reshape(d, d)),
+                self._dev(np.diag(sig)), self._dev(np.asarray(obs_y, dtype=np.float64).reshape(max(m_obs, 1), d) if m_obs else np.zeros((1, d))),
+                self._dev(1.0 / rdiag)]
+        prob = VgpaShardProblem()
+        prob.theta = float(theta)
+        prob.inv_sigma_diag, prob.m0, prob.s0, prob.sigma = (keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr())
+        prob.n_obs = m_obs
+        prob.obs_t = obs_t.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        prob.obs_y, prob.obs_rinv_diag = keep[5].data_ptr(), keep[6].data_ptr()
+        prob.obs_const = m_obs * (d * np.log(2.0 * np.pi) + float(np.sum(np.log(rdiag))))
+        prob.e0 = float(e0)
+        n_own = self.time_slice[1] - self.time_slice[0]
+        dev = torch.device("cuda", self.device)
+        ga = torch.empty((max(n_own, 1), d, d), dtype=torch.float64, device=dev)
+        gb = torch.empty((max(n_own, 1), d), dtype=torch.float64, device=dev)
+        f = ctypes.c_double(0.0)
+        torch.cuda.synchronize(self.device)
+        self._check(self._lib.vgpa_shard_sweep(self._h, ctypes.byref(prob), ctypes.c_void_p(xd.data_ptr()), ctypes.byref(f),
+                                               ctypes.c_void_p(ga.data_ptr()), ctypes.c_void_p(gb.data_ptr())), "vgpa_shard_sweep")
+        return f.value, ga[:n_own], gb[:n_own]
