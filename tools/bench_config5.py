@@ -6,6 +6,8 @@ collectives inside libvgpa_hip.so (vgpa_shard_solve_fwd / _bwd, 
     python tools/bench_config5.py [--dim 4096] [--np 11] [--reps 2]                               # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         tools/bench_config5.py --gpus N [...]                                                        # N GPUs, strong scaling
+    ... --sweep        # the FUSED sweep (vgpa_shard_sweep: F + gradient, time-parallel E_sde / gradient phases) instead of the
+                       # two bare recursions
 
 Every rank builds the same seeded inputs on its own GPU (A_t = 8 I + 0.05 N(0,1)/sqrt(D), symmetric dEsde_dS, sparse
 jumps), runs the forward (m_t, S_t) and backward (lam_t, Psi_t) recursions over the same grid -- total work fixed, so
@@ -30,6 +32,7 @@ def main():
     ap.add_argument("--np", dest="n_pts", type=int, default=11)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--method", default="rk4")
+    ap.add_argument("--sweep", action="store_true", help="fused sweep (free energy + gradient) instead of the bare recursions")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -60,6 +63,8 @@ def main():
         jm[t] = torch.randn(d, generator=gen, **f64)
     rec = NativeShardedRecursion(args.method, dt, d, n, rank=rank, world=world, device=local_rank)
     t_lo, t_hi = rec.time_slice
+    if args.sweep:
+        return fused_sweep(args, rec, a, b, m0, gen, rank, world, dev)
 
     def barrier():
         if world > 1:
@@ -97,6 +102,59 @@ def main():
                           "checks": {"sum|S_T|": chk[0], "sum|Psi_0|": chk[1], "asym(S_T)": chk[2]},
                           "collectives_per_stage": 0 if world == 1 else 2, "driver": "native (vgpa_shard_*)", "history": "time-sharded",
                           "all_gather_bytes_per_rank_per_stage": 0 if world == 1 else 8 * d * d // world}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def fused_sweep(args, rec, a, b, m0, gen, rank, world, dev):
+    """F + gradient of one Lorenz-96 problem (theta = 8, Sigma = 4 I, S0 = 0.2 I, r = 1, H = I, an observation every 4th grid
+    point) through vgpa_shard_sweep; strong scaling (the problem is fixed, the ranks split rows inside the recursions and grid
+    points in the energy / gradient phases)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vgpa_amd import parallel as par
+    d, n = args.dim, args.n_pts
+    f64 = dict(dtype=torch.float64, device=dev)
+    b = 8.0 * m0 + torch.randn((n, d), generator=gen, **f64)          # b_t = 8 m0 + noise keeps m_t near m0
+    x = torch.cat((a.reshape(-1), b.reshape(-1)))
+    del a
+    obs_t = np.arange(3, n - 1, 4, dtype=np.int64)
+    obs_y = (8.0 + torch.randn((max(obs_t.size, 1), d), generator=gen, **f64)).cpu().numpy()[:obs_t.size]
+    sig, rdiag = np.full(d, 4.0), np.ones(d)
+    s0 = 0.2 * np.eye(d)
+    m0h = m0.cpu().numpy()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def once():
+        return rec.sweep(x, 8.0, sig, m0h, s0, obs_t, obs_y, rdiag, 0.0)
+
+    f, ga, gb = once()                                       # warm-up (allocates the sweep's buffers)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        f, ga, gb = once()
+    barrier()
+    elapsed = par.max_over_ranks((time.perf_counter() - t0) / args.reps, device="cuda")
+    chk = torch.tensor([float(ga.abs().sum()), float(gb.abs().sum())], **f64)
+    if world > 1:
+        dist.all_reduce(chk)
+    if rank == 0:
+        stages = {"euler": 1, "heun": 2, "rk2": 2, "rk4": 4}[args.method.lower()]
+        flop_rec = 2 * (n - 1) * stages * 2.0 * d ** 3
+        print(json.dumps({"config": f"BASELINE configs[4]: D={d} {args.method.upper()} FUSED sweep (F + gradient), row-sharded recursions + "
+                                    f"time-sharded energy / gradient over {world} GPU(s), Np={n}",
+                          "n_gpus": world, "D": d, "Np": n, "s_per_sweep": elapsed, "sweeps_per_s": 1.0 / elapsed, "F": f,
+                          "finite": bool(np.isfinite(f)), "recursion_tflop_per_sweep": flop_rec / 1e12, "scaling": "strong",
+                          "checks": {"sum|gLa|": float(chk[0]), "sum|gLb|": float(chk[1])},
+                          "collectives": "per RK stage: 1 all-to-all + 1 grouped all-gather; per sweep: 1 grouped all-gather of the "
+                                         "E_sde terms + 1 of the observation jumps" if world > 1 else "none",
+                          "driver": "native (vgpa_shard_sweep)", "gradient": "time-sharded"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
