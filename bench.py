@@ -242,7 +242,7 @@ def main():
     # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 64): symmetric-unit kernels from two
     # problems per CU on (and for 44 < D), role-specialised ones below (vgpa_api.hip::use_sym_units)
     n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    sym_units = d > 44 or B >= 2 * n_cu or os.environ.get("VGPA_ODE_KERNEL") == "sym"
+    sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym"
     wpe = 2 if nb_blocks <= 10 else 1
     step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, 1, {wpe}>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")

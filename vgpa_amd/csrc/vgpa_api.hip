@@ -179,7 +179,8 @@ static bool use_wave(vgpa_ctx* c) {
 }
 
 // D <= 44 has two families of matrix-core stepping kernels: the symmetric-unit ones (two problems per CU, 4 waves each) win
-// once every CU gets two problems, the role-specialised ones (one problem per CU, 8 waves) below that and for one problem.
+// once there are more problems than CUs, the role-specialised ones (one problem per CU, 8 waves) below that and for one
+// problem.  (D = 41 .. 44: one symmetric-unit workgroup per CU only -- its LDS -- so the role-specialised kernels stay.)
 static bool use_sym_units(vgpa_ctx* c) {
   if (c->cfg.flags & VGPA_FLAG_SYM_UNITS) return true;
   static int n_cu[64] = {0};
@@ -189,7 +190,7 @@ static bool use_sym_units(vgpa_ctx* c) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     n_cu[dev] = v;
   }
-  return c->B >= 2 * n_cu[dev];
+  return c->B > n_cu[dev] && (c->D + 3) / 4 <= 10;
 }
 
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
