@@ -7,7 +7,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr int NB = 10, P = 40, KKE = 10, RP = 2 * KKE, NKP = KKE / 2, LDX = 80, NSB = 5, NU = 15, MAXS = 4;
 constexpr int XS = RP * LDX;
 
-template <int RL, int MODE>   // RL: slots [r*RL, (r+1)*RL) share their a fragments; MODE 1: update + publish + barrier; 2: barrier only
+template <int RL, int MODE, int PD>   // PD: prefetch distance in k-pairs (1: two fragment buffers, 2: three); RL: slots [r*RL, (r+1)*RL) share their a fragments; MODE 1: update + publish + barrier; 2: barrier only
 __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters, int pad_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* X0 = smem; double* X1 = X0 + XS; double* R = X1 + XS;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters
     const double* pa = R + r4 * LDX;
     const double* px = Xc + r4 * LDX;
     double w[MAXS];
-    d2_t a1[2][NA], a2[2][NA], b1[2][MAXS], b2[2][MAXS];
+    d2_t a1[PD + 1][NA], a2[PD + 1][NA], b1[PD + 1][MAXS], b2[PD + 1][MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; s++) w[s] = -xk[s];
     auto load = [&](int buf, int kp) {
@@ -56,10 +56,11 @@ __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters
       }
     };
     load(0, 0);
+    if (PD == 2) load(1, 1);
 #pragma unroll
     for (int kp = 0; kp < NKP; kp++) {
-      const int cur = kp & 1;
-      if (kp + 1 < NKP) load(cur ^ 1, kp + 1);
+      const int cur = kp % (PD + 1);
+      if (kp + PD < NKP) load((kp + PD) % (PD + 1), kp + PD);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -90,12 +91,12 @@ __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters
   if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
-template <int IL, int MODE>
+template <int IL, int MODE, int PD>
 void run(long long* d, double* sink, const char* name) {
   const int iters = 2000;
   for (int two : {0, 1}) {
     const size_t lds = two ? 3 * XS * 8 : 100 * 1024;    // 46 KB -> several workgroups per CU; 100 KB -> one
-    auto kern = k<IL, MODE>;
+    auto kern = k<IL, MODE, PD>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int blocks : {256, 512, 768}) {
       if (!two && blocks != 256) continue;
@@ -106,7 +107,7 @@ void run(long long* d, double* sink, const char* name) {
       hipEventRecord(e1); hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
       long long h[4]; hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
-      printf("%-28s RL=%d lds=%3zuKB blocks=%3d: %.3f ms = %.0f ns per stage-launch; wave cycles/stage %.0f %.0f %.0f %.0f  %s\n", name, IL, lds / 1024, blocks, ms,
+      printf("%-28s PD=%d RL=%d lds=%3zuKB blocks=%3d: %.3f ms = %.0f ns per stage-launch; wave cycles/stage %.0f %.0f %.0f %.0f  %s\n", name, PD, IL, lds / 1024, blocks, ms,
              ms * 1e6 / iters, (double)h[0] / iters, (double)h[1] / iters, (double)h[2] / iters, (double)h[3] / iters, hipGetErrorString(hipGetLastError()));
     }
   }
@@ -115,11 +116,9 @@ void run(long long* d, double* sink, const char* name) {
 int main() {
   long long* d; hipMalloc(&d, 8 * 4 * 1024);
   double* sink; hipMalloc(&sink, 8 * 256);
-  run<1, 2>(d, sink, "db product + barrier");
-  run<2, 2>(d, sink, "db product + barrier");
-  run<4, 2>(d, sink, "db product + barrier");
-  run<1, 1>(d, sink, "db product+update+publish+bar");
-  run<2, 1>(d, sink, "db product+update+publish+bar");
-  run<4, 1>(d, sink, "db product+update+publish+bar");
+  run<2, 1, 1>(d, sink, "product+update+publish+bar");
+  run<2, 1, 2>(d, sink, "product+update+publish+bar");
+  run<4, 1, 1>(d, sink, "product+update+publish+bar");
+  run<4, 1, 2>(d, sink, "product+update+publish+bar");
   return 0;
 }
