@@ -54,6 +54,9 @@ using mfma::OP_R;
 using mfma::OP_X;
 
 constexpr int kMaxNB = 16;          // D <= 64
+#ifndef VGPA_SYM_TAILPRIO
+#define VGPA_SYM_TAILPRIO 1
+#endif
 
 // ---- runs: a cover of the unordered pairs {c, j} of super-block indices (loops included) by stars of <= 2 edges ---------
 // Run = super-row c with up to two partners.  Greedy: every loop (c, c) with the edge to c + 1; then, vertex by vertex, two
@@ -611,6 +614,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       double* pv = pvb + (Xc == Xb0 ? 0 : g::PV);
       product_stage(j, k, aop(k, j, true), Xc, Xn);
       VGPA_STAMP(0, 0);
+      // the LDS / VALU phases are short and on the critical path: beside the other workgroup's products they run at a raised
+      // priority (two workgroups per CU: forward 9.33 -> 8.87 ms, backward 9.85 -> 9.77 ms per 512-problem launch)
+      __builtin_amdgcn_s_setprio(VGPA_SYM_TAILPRIO);
       tail(j, k, aop(k, j, false), Xc, pv);
       VGPA_STAMP(0, 1);
       lds_barrier();
@@ -619,6 +625,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
       product_begin(aop(kn, jn, true), Xn);
       vector_stage(j, pv);
+      __builtin_amdgcn_s_setprio(0);
       VGPA_STAMP(0, 3);
     }
   }
