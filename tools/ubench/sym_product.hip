@@ -1,5 +1,7 @@
-// Micro-benchmark for the symmetric-unit stage (round 2): Z = Aop^T X + X^T Aop on 2x2-block units of the upper triangle,
-// unit-major with the element-wise update and the direct + mirror publish behind each unit, ONE barrier per stage.
+// Micro-benchmark for the symmetric-unit stage (round 2): Z = Aop^T X + X^T Aop on 2x2-block units of the upper triangle, the
+// element-wise update and the direct + mirror publish behind the products, ONE barrier per stage -- nothing else (no operand
+// staging, no vector recursion, no HBM).  Variants: RL = units per run that share their a-fragments (fragment reads per
+// MFMA 1.0 / 0.75 / 0.625), PD = prefetch distance of the fragments in k-pairs; 1, 2 and 3 workgroups per CU.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off sym_product.hip -o sym_product
 #include <hip/hip_runtime.h>
 #include <cstdio>

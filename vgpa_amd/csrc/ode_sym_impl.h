@@ -9,7 +9,7 @@
 // i.e. TWO chains of 4x4x4 matrix-core products into ONE accumulator.  The lane that holds an accumulator element owns the
 // Runge-Kutta state of that element (S_k / Psi_t, the slope sum): it applies the stepper right behind the last product
 // and publishes the new stage state at (row, col) AND at (col, row) of the next stage's operand buffer.  Nothing is
-// exchanged, nothing is read back, the element-wise work of one unit runs under the products of the next.
+// exchanged, nothing is read back, the element-wise work of one group of units runs under the products of the next.
 //
 // Mapping to gfx950.
 //   * Unit = 2x2 blocks of 4x4 = one v_mfma_f64_4x4x4_4b_f64 accumulator: super-block (c, j) of the upper triangle (or
@@ -23,12 +23,13 @@
 //     mirror publish below conflict-free).  Rows 2p, 2p+1 share a 16-byte unit (one read feeds two k-steps); the XOR of the unit's
 //     column with the row pair's low bits costs the fragment reads nothing (row pair = 4 kp + lane / 16, so the XOR is a
 //     per-lane constant) and makes the mirror publish conflict-free (the 16 lanes of a store group hit 16 different
-//     8-byte slots).  74.6 KB at D = 40: two workgroups per CU, 256 registers each.
+//     8-byte slots).  60 KB at D = 40: two workgroups per CU, 256 registers each.
 //   * The vector recursion (m / lambda) is independent of the matrix one.  Its inner product is split over all 256
 //     threads (partial sums before the barrier); behind the barrier EVERY wave sums them and advances its own copy of the
 //     vector, so no second barrier orders "vector published" before "next partial sums".
-//   * A(t) is staged HBM -> registers -> LDS one step ahead beside the products; S_k / Psi_t go back to HBM from the
-//     stage buffer (coalesced row-pair items) while the first product of the next step runs.
+//   * A(t) is staged HBM -> registers -> LDS one step ahead; S_k / Psi_t go back to HBM from the stage buffer (coalesced
+//     row-pair items).  Everything of a stage that is not the product is ONE LDS round trip behind it (`tail`).
+// Measurements, what was tried and what bounds the kernel: DESIGN.md s.4.1b; micro-benchmark tools/ubench/sym_product.hip.
 #pragma once
 #include "ode_mfma_impl.h"
 #include <cstdlib>
