@@ -93,6 +93,144 @@ __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters
   if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+// Pair variant: ONE workgroup of 8 waves per CU works on TWO problems.  Waves 0-3 multiply -- problem A's stage, then
+// problem B's, in one software pipeline (B's first fragments fly during A's last products), each followed by its stepper
+// and publish -- waves 4-7 do a synthetic stand-in of everything else (HELP LDS reads + FMAs + writes per problem); one
+// barrier per pair of stages.
+template <int RL, int HELP>
+__global__ void __launch_bounds__(512) k2(long long* out, double* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PS = 4 * XS;                     // per problem: X0, X1, R, M
+  for (int i = tid; i < 2 * PS; i += 512) smem[i] = 1e-3 * (i % 97);
+  __syncthreads();
+  long long t0 = clock64();
+  if (wave < 4) {
+    const int r4 = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3, bi = b >> 1, bj = b & 1;
+    constexpr int NA = MAXS / RL;
+    int colI[NA], colJ[MAXS], offD[MAXS], offM[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+      int u = wave + 4 * s; if (u >= NU) u = NU - 1;
+      int I0 = 0, rem = u;
+      while (rem >= NSB - I0) { rem -= NSB - I0; I0++; }
+      const int J0 = I0 + rem;
+      const int Ib = 2 * I0 + bi, Jb = 2 * J0 + bj;
+      if (s % RL == 0) colI[s / RL] = 2 * ((4 * Ib + c4) ^ r4);
+      colJ[s] = 2 * ((4 * Jb + c4) ^ r4);
+      const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+      offD[s] = (row >> 1) * LDX + 2 * (col ^ ((row >> 1) & 3)) + (row & 1);
+      offM[s] = (col >> 1) * LDX + 2 * (row ^ ((col >> 1) & 3)) + (col & 1);
+    }
+    double xk[2][MAXS], acc[2][MAXS];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int s = 0; s < MAXS; s++) { xk[q][s] = 0.001 * lane; acc[q][s] = 0.0; }
+    d2_t a1[2][NA], a2[2][NA], b1[2][MAXS], b2[2][MAXS];
+    auto load = [&](int buf, int t, int it) {       // t = q * NKP + kp
+      const int q = t / NKP, kp = t % NKP;
+      const double* X = smem + q * PS + ((it & 1) ? XS : 0);
+      const double* R = smem + q * PS + 2 * XS;
+      const double* pa = R + r4 * LDX;
+      const double* px = X + r4 * LDX;
+#pragma unroll
+      for (int r = 0; r < NA; r++) {
+        a1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colI[r]);
+        a2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colI[r]);
+      }
+#pragma unroll
+      for (int s = 0; s < MAXS; s++) {
+        b1[buf][s] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colJ[s]);
+        b2[buf][s] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colJ[s]);
+      }
+    };
+    load(0, 0, 0);
+    for (int it = 0; it < iters; it++) {
+      double w[MAXS];
+#pragma unroll
+      for (int t = 0; t < 2 * NKP; t++) {
+        const int q = t / NKP, kp = t % NKP, cur = t & 1;
+        if (t + 1 < 2 * NKP) load(cur ^ 1, t + 1, it);
+        if (kp == 0) {
+#pragma unroll
+          for (int s = 0; s < MAXS; s++) w[s] = -xk[q][s];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+          for (int s = 0; s < MAXS; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur][s / RL][h], b1[cur][s][h], w[s], 0, 0, 0);
+#pragma unroll
+          for (int s = 0; s < MAXS; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][s / RL][h], b2[cur][s][h], w[s], 0, 0, 0);
+        }
+        if (kp == NKP - 1) {
+          double* Xn = smem + q * PS + ((it & 1) ? 0 : XS);
+#pragma unroll
+          for (int s = 0; s < MAXS; s++) {
+            const double f = -w[s];
+            acc[q][s] = acc[q][s] + 2.0 * f;
+            const double xn = xk[q][s] + 0.005 * f;
+            Xn[offD[s]] = xn;
+            Xn[offM[s]] = xn;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      load(0, 0, it + 1);
+    }
+    double sum = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int s = 0; s < MAXS; s++) sum += acc[q][s];
+    if (sum == 1.2345) sink[tid] = sum;
+  } else {
+    const int ht = tid - 256;
+    double keep = 0.0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double* M = smem + q * PS + 3 * XS;
+        d2_t v[HELP > 0 ? HELP : 1];
+#pragma unroll
+        for (int r = 0; r < HELP; r++) v[r] = *reinterpret_cast<const d2_t*>(M + 2 * ((ht + 256 * r) % (XS / 2)));
+        double s0 = 0.0;
+#pragma unroll
+        for (int r = 0; r < HELP; r++) s0 = __builtin_fma(v[r][0], v[r][1], s0);
+        keep += s0;
+#pragma unroll
+        for (int r = 0; r < HELP / 2; r++) {
+          d2_t o; o[0] = s0; o[1] = 0.5 * s0 + 1e-3;
+          *reinterpret_cast<d2_t*>(smem + q * PS + 3 * XS + 2 * ((ht + 256 * r) % (XS / 2))) = o * 1e-3;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (keep == 1.2345) sink[tid] = keep;
+  }
+  long long t1 = clock64();
+  if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int RL, int HELP>
+void run2(long long* d, double* sink) {
+  const int iters = 2000;
+  const size_t lds = 2 * 4 * XS * 8;
+  auto kern = k2<RL, HELP>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int blocks : {1, 256}) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, d, sink, iters); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, d, sink, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long h[8]; hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
+    printf("pair workgroup (2 problems, 4 product + 4 helper waves) RL=%d HELP=%2d blocks=%3d: %.3f ms = %.0f ns per PAIR of stages; wave cycles: product %.0f helper %.0f  %s\n",
+           RL, HELP, blocks, ms, ms * 1e6 / iters, (double)h[0] / iters, (double)h[4] / iters, hipGetErrorString(hipGetLastError()));
+  }
+}
+
 template <int IL, int MODE, int PD>
 void run(long long* d, double* sink, const char* name) {
   const int iters = 2000;
@@ -116,11 +254,12 @@ void run(long long* d, double* sink, const char* name) {
 }
 
 int main() {
-  long long* d; hipMalloc(&d, 8 * 4 * 1024);
-  double* sink; hipMalloc(&sink, 8 * 256);
+  long long* d; hipMalloc(&d, 8 * 8 * 1024);
+  double* sink; hipMalloc(&sink, 8 * 512);
   run<2, 1, 1>(d, sink, "product+update+publish+bar");
-  run<2, 1, 2>(d, sink, "product+update+publish+bar");
-  run<4, 1, 1>(d, sink, "product+update+publish+bar");
-  run<4, 1, 2>(d, sink, "product+update+publish+bar");
+  run2<2, 0>(d, sink);
+  run2<2, 8>(d, sink);
+  run2<2, 16>(d, sink);
+  run2<4, 8>(d, sink);
   return 0;
 }
