@@ -93,6 +93,97 @@ __global__ void __launch_bounds__(256) k(long long* out, double* sink, int iters
   if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+// Eight-wave variant: one problem per workgroup of EIGHT waves, each wave ONE run of two units (40 MFMAs per stage), so that two
+// workgroups per CU put FOUR in-order waves on every SIMD (needs <= 128 registers).
+__global__ void __launch_bounds__(512) k8(long long* out, double* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* X0 = smem; double* X1 = X0 + XS; double* R = X1 + XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 3 * XS; i += 512) smem[i] = 1e-3 * (i % 97);
+  const int r4 = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3, bi = b >> 1, bj = b & 1;
+  int colI, colJ[2], offD[2], offM[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    int u = 2 * wave + s; if (u >= NU) u = NU - 1;
+    int I0 = 0, rem = u;
+    while (rem >= NSB - I0) { rem -= NSB - I0; I0++; }
+    const int J0 = I0 + rem;
+    const int Ib = 2 * I0 + bi, Jb = 2 * J0 + bj;
+    if (s == 0) colI = 2 * ((4 * Ib + c4) ^ r4);
+    colJ[s] = 2 * ((4 * Jb + c4) ^ r4);
+    const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+    offD[s] = (row >> 1) * LDX + 2 * (col ^ ((row >> 1) & 3)) + (row & 1);
+    offM[s] = (col >> 1) * LDX + 2 * (row ^ ((col >> 1) & 3)) + (col & 1);
+  }
+  double xk[2], acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) { xk[s] = 0.001 * lane; acc[s] = 0.0; }
+  __syncthreads();
+  long long t0 = clock64();
+  for (int it = 0; it < iters; it++) {
+    const double* Xc = (it & 1) ? X1 : X0;
+    double* Xn = (it & 1) ? X0 : X1;
+    const double* pa = R + r4 * LDX;
+    const double* px = Xc + r4 * LDX;
+    double w[2];
+    d2_t a1[2], a2[2], b1[2][2], b2[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) w[s] = -xk[s];
+    auto load = [&](int buf, int kp) {
+      a1[buf] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colI);
+      a2[buf] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colI);
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        b1[buf][s] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LDX + colJ[s]);
+        b2[buf][s] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LDX + colJ[s]);
+      }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < NKP; kp++) {
+      const int cur = kp & 1;
+      if (kp + 1 < NKP) load(cur ^ 1, kp + 1);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur][h], b1[cur][s][h], w[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; s++) w[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][h], b2[cur][s][h], w[s], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const double f = -w[s];
+      acc[s] = acc[s] + 2.0 * f;
+      const double xn = xk[s] + 0.005 * f;
+      Xn[offD[s]] = xn;
+      Xn[offM[s]] = xn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  long long t1 = clock64();
+  double sum = acc[0] + acc[1];
+  if (sum == 1.2345) sink[tid] = sum;
+  if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+void run8(long long* d, double* sink) {
+  const int iters = 2000;
+  const size_t lds = 3 * XS * 8;
+  hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int blocks : {256, 512, 768, 1024}) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), lds, 0, d, sink, iters); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), lds, 0, d, sink, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long h[8]; hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
+    printf("eight waves per problem (one run each) blocks=%4d: %.3f ms = %.0f ns per stage-launch = %.0f ns per problem-stage; wave cycles/stage %.0f  %s\n",
+           blocks, ms, ms * 1e6 / iters, ms * 1e6 / iters / (blocks / 256.0), (double)h[0] / iters, hipGetErrorString(hipGetLastError()));
+  }
+}
+
 // Pair variant: ONE workgroup of 8 waves per CU works on TWO problems.  Waves 0-3 multiply -- problem A's stage, then
 // problem B's, in one software pipeline (B's first fragments fly during A's last products), each followed by its stepper
 // and publish -- waves 4-7 do a synthetic stand-in of everything else (HELP LDS reads + FMAs + writes per problem); one
@@ -257,6 +348,7 @@ int main() {
   long long* d; hipMalloc(&d, 8 * 8 * 1024);
   double* sink; hipMalloc(&sink, 8 * 512);
   run<2, 1, 1>(d, sink, "product+update+publish+bar");
+  run8(d, sink);
   run2<2, 0>(d, sink);
   run2<2, 8>(d, sink);
   run2<2, 16>(d, sink);
