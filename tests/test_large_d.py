@@ -520,6 +520,58 @@ def test_native_sharded_fused_sweep_with_virtual_ranks(method, d, n, world):
 
 
 @pytest.mark.gpu
+def test_native_sharded_fused_sweep_at_config5_matrix_size():
+    """BASELINE configs[4] matrix size (D = 4096; the oracle's sweep would take minutes there): the fused sweep row-sharded
+    over 2 and over 8 virtual ranks must reproduce the one-rank run of the same kernels -- F to 1e-12, every gradient slice to
+    1e-11 -- i.e. the sharding, the gathered layouts and the sparse jumps change nothing."""
+    import threading
+    import torch
+    from vgpa_amd.large_d import NativeShardedRecursion
+    d, n, method = 4096, 4, "rk4"
+    rng = np.random.default_rng(5)
+    m0 = 8.0 + rng.standard_normal(d)
+    a = 8.0 * np.eye(d)[None] + (0.05 / np.sqrt(d)) * rng.standard_normal((n, d, d))
+    b = 8.0 * m0[None] + rng.standard_normal((n, d))
+    x = torch.as_tensor(np.concatenate((a.ravel(), b.ravel())), device="cuda")
+    del a
+    obs_t = np.array([2], dtype=np.int64)
+    obs_y = 8.0 + rng.standard_normal((1, d))
+    sig, rdiag, s0 = np.full(d, 4.0), np.ones(d), 0.2 * np.eye(d)
+
+    def sweep(world):
+        comm = _CallbackComm(world)
+        out, fails = [None] * world, []
+
+        def run(rank):
+            try:
+                torch.cuda.set_device(0)
+                rec = NativeShardedRecursion(method, 0.01, d, n, rank=rank, world=world, device=0,
+                                             comm=comm.table(rank) if world > 1 else None)
+                f, ga, gb = rec.sweep(x, 8.0, sig, m0, s0, obs_t, obs_y, rdiag, 0.0)
+                out[rank] = (rec.time_slice, f, ga.cpu().numpy(), gb.cpu().numpy())
+                rec.close()
+            except BaseException as exc:      # noqa: BLE001
+                fails.append(exc)
+                comm.barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not fails, fails
+        return out
+
+    (_, f1, ga1, gb1), = sweep(1)
+    assert np.isfinite(f1)
+    for world in (2, 8):
+        for (lo, hi), f, ga, gb in sweep(world):
+            assert abs(f - f1) <= 1e-12 * abs(f1)
+            if hi > lo:
+                assert rel_err(ga, ga1[lo:hi]) < 1e-11 and rel_err(gb, gb1[lo:hi]) < 1e-11
+
+
+@pytest.mark.gpu
 def test_rccl_table_single_rank():
     """librccl behind vgpa_comm: unique id through the C ABI, communicator of one rank on this GPU, a grouped in-place
     all-gather and an all-to-all through the table's function pointers."""
