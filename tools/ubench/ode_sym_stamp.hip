@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); go(); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("%s RK4 D=40 Np=%d B=%d GR=%d: %.3f ms  (%.0f cycles/stage at 2.2 GHz)  err=%s\n", fwd ? "fwd" : "bwd", Np, B, VGPA_SYM_GR, ms, ms * 1e-3 * 2.2e9 / (4 * (Np - 1)), hipGetErrorString(hipGetLastError()));
+  printf("%s RK4 D=40 Np=%d B=%d %.3f ms  (%.0f cycles/stage at 2.2 GHz)  err=%s\n", fwd ? "fwd" : "bwd", Np, B, ms, ms * 1e-3 * 2.2e9 / (4 * (Np - 1)), hipGetErrorString(hipGetLastError()));
 #ifdef VGPA_STAMPS
   long long st[4][8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(mfma::g_stamp), sizeof(st));
   const char* pn[5] = {"product+update+publish", "tail", "barrier", "next fragments + vector", "-"};

@@ -636,10 +636,9 @@ template <int METHOD, bool FWD, int NB>
 hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr size_t lds = SGeo<NB>::LDS_DOUBLES * sizeof(double);
   static_assert(lds <= 160 * 1024, "LDS budget");
-#ifndef VGPA_SYM_GR
-#define VGPA_SYM_GR 1
-#endif
-  constexpr int GR = SGeo<NB>::NR >= VGPA_SYM_GR ? VGPA_SYM_GR : 1;
+  // runs per pipeline step.  Two (four accumulators in turn, 16 MFMAs per step) spill with 256 registers and were slower with
+  // 512 (D = 64: 22.0 vs 15.7 ms forward); the kernel is only exercised with one.
+  constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
   auto kern = dense ? k_ode_sym<METHOD, FWD, NB, true, GR, WPE> : k_ode_sym<METHOD, FWD, NB, false, GR, WPE>;
