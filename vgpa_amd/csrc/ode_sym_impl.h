@@ -510,6 +510,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // the group boundary (the next group's first fragments are on their way while this group's stepper runs) and across the
   // STAGE boundary: product_begin requests step 0 of the next stage right behind the barrier, in front of the vector work.
   constexpr int NG = cdiv(NR, GR), NSL = 2 * GR, NSTEP = NG * NKP;
+  static_assert(NR % GR == 0, "a group of runs must be complete (the clamped tail group is not parity-clean)");
   d2_t fa1[2][GR], fa2[2][GR], fb1[2][NSL], fb2[2][NSL];
   auto frag_load = [&](int buf, int t, const double* pa, const double* px) {
     const int g0 = (t / NKP) * GR, kp = t % NKP;
