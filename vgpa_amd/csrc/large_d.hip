@@ -467,9 +467,101 @@ hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
   return hipGetLastError();
 }
 
+// One rank owns every row (Mp = D, W = Wcol): R = -(W + W^T) + E is symmetric, so a workgroup takes the PAIR of tiles (by, bx)
+// and (bx, by), by <= bx: both W tiles are read once (k_stage reads every W tile twice: once straight, once transposed), the
+// forcing term / base state / Runge-Kutta slope slots only on and above the diagonal (they are symmetric and only this kernel
+// reads the slots), the stage state is written at (r, j) and -- through an LDS transposition, coalesced -- at (j, r).  ~36 MB
+// instead of ~64 MB per stage at D = 1024.  The vector recursion rides in the trailing blocks as in k_stage.
+__global__ void __launch_bounds__(NT) k_stage_sym(StageArgs a) {
+  __shared__ double ta[TS][TS + 1], tb[TS][TS + 1], tc[TS][TS + 1];
+  const int nt = (a.D + TS - 1) / TS;
+  const int npair = nt * (nt + 1) / 2;
+  const double sgn = a.fwd ? 1.0 : -1.0;
+  const int D = a.D;
+  if ((int)blockIdx.x < npair) {
+    int by = 0, rem = (int)blockIdx.x;                 // pair index -> (by, bx), by <= bx (row by has nt - by pairs)
+    while (rem >= nt - by) { rem -= nt - by; by++; }
+    const int bx = by + rem;
+    const bool diag = (by == bx);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int rr = ty + 8 * q;
+      const int r = by * TS + rr, j = bx * TS + tx;
+      ta[rr][tx] = (r < D && j < D) ? a.W[(size_t)r * D + j] : 0.0;             // W[by tile][bx tile]
+      if (!diag) {
+        const int r2 = bx * TS + rr, j2 = by * TS + tx;
+        tb[rr][tx] = (r2 < D && j2 < D) ? a.W[(size_t)r2 * D + j2] : 0.0;        // W[bx tile][by tile]
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int rr = ty + 8 * q;
+      const int r = by * TS + rr, j = bx * TS + tx;
+      double res = 0.0;
+      if (r < D && j < D) {
+        const size_t o = (size_t)r * D + j;
+        const double w = ta[rr][tx];
+        const double wt = diag ? ta[tx][rr] : tb[tx][rr];
+        const double e = a.mid_e ? 0.5 * (a.E1[o] + a.E0[o]) : a.E0[o];
+        const double rv = a.fwd ? ((-w - wt) + e) : ((-e + wt) + w);
+        const double k1 = (a.final >= 2) ? a.K1[o] : 0.0;
+        const double k23 = (a.final == 3) ? a.K23[o] : 0.0;
+        if (a.kstore == 1) a.K1[o] = rv;
+        else if (a.kstore == 2) a.K23[o] = rv;
+        else if (a.kstore == 3) a.K23[o] = a.K23[o] + rv;
+        const double jump = (a.final && a.has_j) ? a.J[o] : 0.0;
+        res = stage_combine(rv, a.base[o], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+        a.out[o] = res;
+      }
+      if (!diag) tc[rr][tx] = res;
+    }
+    if (diag) return;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                        // the mirror tile: out[bx tile][by tile] = (this tile)^T
+      const int rr = ty + 8 * q;
+      const int r2 = bx * TS + rr, j2 = by * TS + tx;
+      if (r2 < D && j2 < D) a.out[(size_t)r2 * D + j2] = tc[tx][rr];
+    }
+    return;
+  }
+  // ---- vector recursion: one wave per row
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = ((int)blockIdx.x - npair) * (NT / 64) + wave;
+  if (r >= a.Mp) return;
+  const size_t ro = (size_t)(a.row0 + r) * a.lda;
+  double s = 0.0;
+  for (int k = lane; k < a.D; k += 64) {
+    const double av = a.mid_a ? 0.5 * (a.A0[ro + k] + a.A1[ro + k]) : a.A0[ro + k];
+    s = __builtin_fma(av, a.x[k], s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const double e = a.mid_ev ? 0.5 * (a.e1[r] + a.e0[r]) : a.e0[r];
+    const double rv = a.fwd ? (-s + e) : (-e + s);
+    const double k1 = (a.final >= 2) ? a.k1v[r] : 0.0;
+    const double k23 = (a.final == 3) ? a.k23v[r] : 0.0;
+    if (a.kstore == 1) a.k1v[r] = rv;
+    else if (a.kstore == 2) a.k23v[r] = rv;
+    else if (a.kstore == 3) a.k23v[r] = a.k23v[r] + rv;
+    const double jump = (a.final && a.jv) ? a.jv[r] : 0.0;
+    a.vout[r] = stage_combine(rv, a.vbase[r], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+  }
+}
+
+static const bool stage_sym_off = [] { const char* e = getenv("VGPA_STAGE_FULL"); return e && e[0] == '1'; }();
+
 hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
-  const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
   const int nvec = (a.Mp + (NT / 64) - 1) / (NT / 64);
+  if (a.Mp == a.D && a.row0 == 0 && a.cw == a.D && a.W == a.Wcol && !stage_sym_off) {
+    const int nt = (a.D + TS - 1) / TS;
+    hipLaunchKernelGGL(k_stage_sym, dim3(nt * (nt + 1) / 2 + nvec), dim3(NT), 0, st, a);
+    return hipGetLastError();
+  }
+  const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
   hipLaunchKernelGGL(k_stage, dim3(ntx * nty + nvec), dim3(NT), 0, st, a);
   return hipGetLastError();
 }
