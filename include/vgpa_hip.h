@@ -183,6 +183,10 @@ enum vgpa_option {
   VGPA_OPT_LD_CHUNK = 1        /* grid points per chunk of the time-chunked large-D sweep (>= 1) */
 };
 int vgpa_set_option(vgpa_ctx* ctx, int option, int64_t value);
+/* E0 = KL(q0||p0): constant in x, but the reference recomputes it from the prior's current attributes on EVERY free_energy
+ * call (src/var_bayes/variational.py:185; prior_kl0.py:30-92 reads self.mu0 / self.tau0) -- the host mirror hands the
+ * current value over before each objective call instead of baking it into the context. */
+int vgpa_set_prior_energy(vgpa_ctx* ctx, double e0);
 /* 1 if the context runs the time-chunked large-D sweep (VGPA_FLAG_STREAM_LARGE_D or chosen for lack of memory) */
 int vgpa_is_streaming(vgpa_ctx* ctx);
 

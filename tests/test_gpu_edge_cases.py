@@ -115,6 +115,26 @@ def test_symmetric_unit_steppers_dense_inputs_and_batches(model, d):
     ctx.close()
 
 
+@pytest.mark.parametrize("method", ["rk4", "heun"])
+def test_more_problems_than_compute_units(method):
+    """bench.py's regime: a batch larger than twice the CU count, so that the default dispatch picks the symmetric-unit steppers and
+    two (in the last round of the grid: one) workgroups share a CU.  EVERY problem's F and gradient against the oracle."""
+    import torch
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    batch = 2 * n_cu + 37
+    p, x = make_problem("L96", 40, 12, method=method)
+    rng = np.random.default_rng(17)
+    xb = x[None, :] + 0.02 * rng.standard_normal((batch, x.size))
+    ctx = gpu_context(p, batch=batch)
+    fb, gb = ctx.sweep(xb)
+    worst = 0.0
+    for i in range(batch):
+        f_ref, g_ref, _ = vo.sweep(p, xb[i], faithful=False)
+        worst = max(worst, abs(fb[i] - f_ref) / abs(f_ref), rel_err(gb[i], g_ref))
+    assert worst < TOL, worst
+    ctx.close()
+
+
 @pytest.mark.parametrize("model,d", [("L96", 12), ("L96", 40), ("L63", 3)])
 def test_dense_noise_matrices_and_observation_operator(model, d):
     rng = np.random.default_rng(11)

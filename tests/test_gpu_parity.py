@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import vgpa_amd as va
-from vgpa_amd._lib import FLAG_FORCE_GENERIC
+from vgpa_amd._lib import FLAG_FORCE_GENERIC, FLAG_SYM_UNITS
 from conftest import GOLDEN_DIR, rel_err
 from helpers import build_problem, problem_from_golden, split_x
 from oracle import vgpa_oracle as vo
@@ -158,6 +158,30 @@ def test_full_size_anchors_of_the_reference(tag, name, method, d, pert):
     assert rel_err(np.atleast_1d(out["mt"][-1])[:8], a["mt_last"]) < TOL
 
 
+@pytest.mark.parametrize("pert", [0.0, 0.05])
+def test_full_size_anchors_on_the_bench_kernels(pert):
+    """The kernels bench.py's batch runs on (symmetric-unit steppers k_ode_sym, chosen there because B > #CUs) at the FULL
+    grid of BASELINE configs[2] against the reference's anchors -- F, the gradient and the state norms, not only F."""
+    anchors = json.load(open(os.path.join(GOLDEN_DIR, "anchors.json")))
+    a = anchors["l96d40_rk4_full" + ("_p" if pert else "")]
+    p = build_problem("L96", "RK4", a["tf"], a["dt"], 40, flags=FLAG_SYM_UNITS)
+    v = p["vgp"]
+    x = v.initialization()
+    if pert:
+        x = x + pert * np.random.default_rng(0).standard_normal(x.size)
+    f, g = v.sweep(x)
+    assert abs(f - a["F"]) <= TOL * abs(a["F"])
+    assert abs(np.linalg.norm(g) - a["grad_norm"]) <= TOL * a["grad_norm"]
+    assert abs(np.abs(g).max() - a["grad_absmax"]) <= TOL * a["grad_absmax"]
+    out = v.arg_out
+    assert abs(np.linalg.norm(out["st"].ravel()) - a["st_fro"]) <= TOL * a["st_fro"]
+    assert abs(np.linalg.norm(out["psit"].ravel()) - a["psi_fro"]) <= TOL * a["psi_fro"]
+    assert rel_err(np.atleast_1d(out["mt"][-1])[:8], a["mt_last"]) < TOL
+    # and the two kernel families agree far below the tolerance
+    f_pe, g_pe = build_problem("L96", "RK4", a["tf"], a["dt"], 40)["vgp"].sweep(x)
+    assert abs(f - f_pe) <= 1e-12 * abs(f_pe) and rel_err(g, g_pe) < 1e-10
+
+
 def test_properties_at_baseline_size():
     """Lorenz-96 D=40, Np=1001: symmetry of S_t / Psi_t, batch consistency, determinism, op/fused agreement."""
     p = build_problem("L96", "RK4", 10.0, 0.01, 40)
@@ -185,6 +209,23 @@ def test_properties_at_baseline_size():
     assert abs(fb[0] - f1) <= 1e-12 * abs(f1) and fb[0] == fb[2]
     assert rel_err(gb[0], g1) < 1e-12 and np.array_equal(gb[0], gb[2])
     assert fb[1] != fb[0]
+
+
+def test_prior_change_is_seen_by_the_next_call():
+    """kl0.mu0 / kl0.tau0 are plain attributes in the reference and E0 is re-evaluated on every free_energy call
+    (variational.py:185): a prior changed between two calls must move F by exactly the change of E0."""
+    p = build_problem("L96", "RK4", 0.3, 0.01, 12)
+    v, kl0 = p["vgp"], p["kl0"]
+    x = v.initialization()
+    f1 = v.free_energy(x)
+    e0_old = float(kl0(p["m0"], p["s0"]))
+    kl0.mu0 = kl0.mu0 + 0.5
+    kl0.tau0 = 0.7 * np.eye(12)
+    e0_new = float(kl0(p["m0"], p["s0"]))
+    f2 = v.free_energy(x)
+    assert abs(e0_new - e0_old) > 1.0
+    assert abs((f2 - f1) - (e0_new - e0_old)) <= 1e-12 * abs(f2)
+    assert abs(v._ctx.energy_parts()[0] - e0_new) <= 1e-13 * abs(e0_new)
 
 
 def test_non_positive_definite_covariance_raises():

@@ -242,6 +242,9 @@ def test_device_contexts_are_rebuilt_when_a_baked_in_input_changes(monkeypatch):
         def close(self):
             self.closed = True
 
+        def set_prior_energy(self, e0):
+            self.e0 = e0
+
     monkeypatch.setattr(V, "Context", Recorder)
     monkeypatch.setattr(L, "Context", Recorder)
     p = build_problem("L96", "RK4", 0.2, 0.01, 12)
@@ -249,6 +252,16 @@ def test_device_contexts_are_rebuilt_when_a_baked_in_input_changes(monkeypatch):
     c0 = v._context()
     assert v._context() is c0 and len(made) == 1
     assert c0.kw["obs_h"] is None                          # default operator -> the library's diagonal fast path
+    # the prior is NOT baked in: E0 follows kl0.mu0 / kl0.tau0 on the next call, same context
+    e0_first = c0.e0
+    assert e0_first == float(p["kl0"](p["m0"], p["s0"]))
+    p["kl0"].mu0 = p["kl0"].mu0 + 0.25
+    assert v._context() is c0 and c0.e0 == float(p["kl0"](p["m0"], p["s0"])) and c0.e0 != e0_first
+    # large arrays are identified by a digest of the whole buffer, not by a few probes: a permutation is a change
+    big = np.arange(70000, dtype=float)
+    k_a = V.VarGP._fingerprint({"a": big})
+    big2 = big.copy(); big2[[5, 60000]] = big2[[60000, 5]]
+    assert V.VarGP._fingerprint({"a": big2}) != k_a and V.VarGP._fingerprint({"a": big.copy()}) == k_a
     p["model"].theta = 9.0
     c1 = v._context()
     assert c1 is not c0 and c0.closed and c1.kw["theta"][0] == 9.0

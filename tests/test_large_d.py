@@ -521,22 +521,27 @@ def test_native_sharded_fused_sweep_with_virtual_ranks(method, d, n, world):
 
 @pytest.mark.gpu
 def test_native_sharded_fused_sweep_at_config5_matrix_size():
-    """BASELINE configs[4] matrix size (D = 4096; the oracle's sweep would take minutes there): the fused sweep row-sharded
-    over 2 and over 8 virtual ranks must reproduce the one-rank run of the same kernels -- F to 1e-12, every gradient slice to
-    1e-11 -- i.e. the sharding, the gathered layouts and the sparse jumps change nothing."""
+    """BASELINE configs[4] matrix size (D = 4096, RK4, 4-point grid): the fused sweep on 1, 2 and 8 virtual ranks against
+    ORACLE anchors generated in the build container (tools/gen_d4096_anchor.py -> tests/golden/anchors_d4096.json: F, the
+    Frobenius norm / max-abs / sampled entries of every grid point's gradient) -- blocked Cholesky, triangular inverse, SYRK
+    and lde_grad at this size included -- and, on top, the sharded runs against the one-rank run at 1e-12 / 1e-11 (the sharding,
+    the gathered / exchanged layouts and the sparse jumps change nothing beyond rounding)."""
+    import json
+    import os
+    import sys
     import threading
     import torch
     from vgpa_amd.large_d import NativeShardedRecursion
-    d, n, method = 4096, 4, "rk4"
-    rng = np.random.default_rng(5)
-    m0 = 8.0 + rng.standard_normal(d)
-    a = 8.0 * np.eye(d)[None] + (0.05 / np.sqrt(d)) * rng.standard_normal((n, d, d))
-    b = 8.0 * m0[None] + rng.standard_normal((n, d))
-    x = torch.as_tensor(np.concatenate((a.ravel(), b.ravel())), device="cuda")
-    del a
-    obs_t = np.array([2], dtype=np.int64)
-    obs_y = 8.0 + rng.standard_normal((1, d))
-    sig, rdiag, s0 = np.full(d, 4.0), np.ones(d), 0.2 * np.eye(d)
+    from conftest import GOLDEN_DIR, ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_d4096_anchor import inputs, D as d, N_PTS as n, METHOD as method
+    anc = json.load(open(os.path.join(GOLDEN_DIR, "anchors_d4096.json")))
+    assert anc["D"] == d and anc["Np"] == n
+    xh, m0, s0, sig, obs_t, obs_y, rdiag = inputs()
+    x = torch.as_tensor(xh, device="cuda")
+    del xh
+    ii = [i for i, _ in anc["samples_ij"]]
+    jj = [j for _, j in anc["samples_ij"]]
 
     def sweep(world):
         comm = _CallbackComm(world)
@@ -562,10 +567,21 @@ def test_native_sharded_fused_sweep_at_config5_matrix_size():
         assert not fails, fails
         return out
 
+    def against_oracle(lo, hi, f, ga, gb):
+        assert abs(f - anc["F_minus_E0"]) <= TOL * abs(anc["F_minus_E0"]), (f, anc["F_minus_E0"])
+        for t in range(lo, hi):
+            a_t, b_t = ga[t - lo], gb[t - lo]
+            assert abs(np.linalg.norm(a_t) - anc["grad_a_fro"][t]) <= TOL * anc["grad_a_fro"][t], t
+            assert abs(np.abs(a_t).max() - anc["grad_a_absmax"][t]) <= TOL * anc["grad_a_absmax"][t], t
+            assert abs(np.linalg.norm(b_t) - anc["grad_b_norm"][t]) <= TOL * anc["grad_b_norm"][t], t
+            assert np.max(np.abs(a_t[ii, jj] - np.array(anc["grad_a_samples"][t]))) <= TOL * anc["grad_a_absmax"][t], t
+            assert np.max(np.abs(b_t[:8] - np.array(anc["grad_b_first8"][t]))) <= TOL * anc["grad_b_absmax"][t], t
+
     (_, f1, ga1, gb1), = sweep(1)
-    assert np.isfinite(f1)
+    against_oracle(0, n, f1, ga1, gb1)
     for world in (2, 8):
         for (lo, hi), f, ga, gb in sweep(world):
+            against_oracle(lo, hi, f, ga, gb)
             assert abs(f - f1) <= 1e-12 * abs(f1)
             if hi > lo:
                 assert rel_err(ga, ga1[lo:hi]) < 1e-11 and rel_err(gb, gb1[lo:hi]) < 1e-11

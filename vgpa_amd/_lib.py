@@ -29,7 +29,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_obs_energy", "vgpa_free_energy", "vgpa_gradient", "vgpa_sweep", "vgpa_energy_parts",
            "vgpa_fetch", "vgpa_sweep_dev", "vgpa_free_energy_dev", "vgpa_sweep_enqueue", "vgpa_fetch_f",
            "vgpa_dev_alloc", "vgpa_dev_free", "vgpa_memcpy_h2d", "vgpa_memcpy_d2h",
-           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming",
+           "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming", "vgpa_set_prior_energy",
            "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x",
            "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
            "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
@@ -143,6 +143,7 @@ def load():
     lib.vgpa_vec_axpby.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vgpa_set_option.argtypes = [c_void_p, c_int, c_int64]
     lib.vgpa_is_streaming.argtypes = [c_void_p]
+    lib.vgpa_set_prior_energy.argtypes = [c_void_p, c_double]
     lib.vgpa_profile_begin.argtypes = [c_void_p]
     lib.vgpa_profile_end.argtypes = [c_void_p, P_DOUBLE, P_DOUBLE, P_DOUBLE, P_DOUBLE, POINTER(c_int64)]
     if lib.vgpa_abi_version() != ABI_VERSION:
@@ -446,6 +447,10 @@ class Context:
 
     def set_option(self, option, value):
         self._check(self._lib.vgpa_set_option(self._h, int(option), int(value)))
+
+    def set_prior_energy(self, e0):
+        """E0 = KL(q0||p0) used by the following objective calls (the reference recomputes it per call, variational.py:185)."""
+        self._check(self._lib.vgpa_set_prior_energy(self._h, float(e0)))
 
     @property
     def streaming(self):

@@ -58,6 +58,7 @@ struct vgpa_ctx {
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
   bool have_state = false;
+  bool sym_units = false;        // stepping-kernel family of this context (pick_kernel_family)
   // profiling
   bool prof = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -181,16 +182,12 @@ static bool use_wave(vgpa_ctx* c) {
 // D <= 44 has two families of matrix-core stepping kernels: the symmetric-unit ones (two problems per CU, 4 waves each) win
 // once there are more problems than CUs, the role-specialised ones (one problem per CU, 8 waves) below that and for one
 // problem.  (D = 41 .. 44: one symmetric-unit workgroup per CU only -- its LDS -- so the role-specialised kernels stay.)
-static bool use_sym_units(vgpa_ctx* c) {
-  if (c->cfg.flags & VGPA_FLAG_SYM_UNITS) return true;
-  static int n_cu[64] = {0};
-  const int dev = c->cfg.device >= 0 && c->cfg.device < 64 ? c->cfg.device : 0;
-  if (!n_cu[dev]) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu[dev] = v;
-  }
-  return c->B > n_cu[dev] && (c->D + 3) / 4 <= 10;
+static bool use_sym_units(vgpa_ctx* c) { return c->sym_units; }   // decided once in vgpa_create (pick_kernel_family)
+
+static void pick_kernel_family(vgpa_ctx* c) {
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess || n_cu <= 0) n_cu = 256;
+  c->sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) != 0 || (c->B > n_cu && (c->D + 3) / 4 <= 10);
 }
 
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
@@ -518,6 +515,7 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
 #define HTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, VGPA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); vgpa_destroy(c); return VGPA_ERR_DEVICE; } } while (0)
   HTRY(hipSetDevice(cfg->device));
   HTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  pick_kernel_family(c);
   for (auto& e : c->ev) HTRY(hipEventCreate(&e));
 
   // ---- host-side constants -------------------------------------------------------------------
@@ -1035,6 +1033,14 @@ int vgpa_set_option(vgpa_ctx* c, int option, int64_t value) {
   return fail(c, VGPA_ERR_ARG, "unknown option %d", option);
 }
 
+// E0 = KL(q0||p0) is constant in x but not in the prior: the reference recomputes it on every free_energy call
+// (variational.py:185) from kl0.mu0 / kl0.tau0, which are plain attributes.  The host mirror passes the current value.
+int vgpa_set_prior_energy(vgpa_ctx* c, double e0) {
+  if (!c) return VGPA_ERR_ARG;
+  c->cfg.e0 = e0;
+  return VGPA_OK;
+}
+
 int vgpa_is_streaming(vgpa_ctx* c) { return (c && c->stream_ld) ? 1 : 0; }
 
 // ---- raw device memory ------------------------------------------------------------------------------
@@ -1048,6 +1054,10 @@ int vgpa_dev_alloc(vgpa_ctx* c, uint64_t bytes, void** out) {
 int vgpa_dev_free(vgpa_ctx* c, void* ptr) {
   if (!c) return VGPA_ERR_ARG;
   if (!ptr) return VGPA_OK;
+  // (may run from a garbage collector at any point of the calling thread: its current device is put back)
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (ptr == (const void*)c->xcur) { c->xcur = nullptr; c->have_state = false; }

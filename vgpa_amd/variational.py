@@ -32,6 +32,7 @@ class VarGP(object):
         self.device, self.flags, self.batch = device, flags, int(batch)
         self._ctx = None
         self._ctx_key = None
+        self._e0 = None
         self._stale = set()
         method_f = str(getattr(fwd_ode, "method", "")).lower()
         method_b = str(getattr(bwd_ode, "method", "")).lower()
@@ -57,7 +58,9 @@ class VarGP(object):
 
     @staticmethod
     def _fingerprint(inputs):
-        """Cheap identity of the baked-in inputs: exact bytes for small arrays, (shape, sum, trace-like probes) beyond."""
+        """Identity of the baked-in inputs: exact bytes for small arrays, a 128-bit digest of the whole buffer beyond (a D >= 257
+        sigma / s0 / obs_noise is hashed in well under a millisecond -- nothing next to a sweep at that size)."""
+        import hashlib
         key = []
         for name in sorted(inputs):
             a = inputs[name]
@@ -66,8 +69,7 @@ class VarGP(object):
             elif a.size <= 1 << 16:
                 key.append((name, a.shape, a.tobytes()))
             else:
-                flat = a.reshape(-1)
-                key.append((name, a.shape, float(flat.sum()), float(flat[0]), float(flat[-1]), float(flat[flat.size // 2])))
+                key.append((name, a.shape, hashlib.blake2b(np.ascontiguousarray(a).data, digest_size=16).digest()))
         return tuple(key)
 
     def invalidate(self):
@@ -84,11 +86,16 @@ class VarGP(object):
         key = self._fingerprint(inputs)
         if self._ctx is not None and key != self._ctx_key:
             self.invalidate()
+        # E0 depends on the prior (kl0.mu0 / kl0.tau0 are plain attributes; the reference evaluates kl0 on every
+        # free_energy call, variational.py:185): handed to the context per call, never baked in
+        prior = tuple(np.asarray(getattr(self.kl0, k, 0.0), dtype=float).tobytes() for k in ("mu0", "tau0"))
+        if self._e0 is None or self._e0[0] != (prior, key):
+            self._e0 = ((prior, key), float(np.asarray(self.kl0(self.output["m0"], self.output["s0"]))))
         if self._ctx is None:
-            e0 = float(np.asarray(self.kl0(self.output["m0"], self.output["s0"])))
             self._ctx = Context(self.model._model_id, self._method, self.dim_d, self.dim_n, float(self.fwd_ode.dt),
-                                e0=e0, device=self.device, flags=self.flags, batch=self.batch, **inputs)
+                                e0=self._e0[1], device=self.device, flags=self.flags, batch=self.batch, **inputs)
             self._ctx_key = key
+        self._ctx.set_prior_energy(self._e0[1])
         return self._ctx
 
     def initialization(self):
