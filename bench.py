@@ -11,7 +11,15 @@ parameters x.  Inputs (x) and outputs (gradient) stay resident in HBM; F comes b
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU, independent problems per rank (the path shards over problems; no data-path
-collective), barrier + device sync on both sides of the timed region, MAX over ranks, weak scaling.
+collective), barrier + device sync on both sides of the timed region, MAX over ranks, weak scaling.  Started WITHOUT a
+launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script starts its N ranks itself -- torch.distributed.run as a CHILD
+process, before this process has made any GPU call -- and exits with the child's code; a WORLD_SIZE that disagrees with --gpus is
+an error, never a silent one-GPU run.
+
+Secondary block `config5` (every N; --no-config5 skips it): BASELINE configs[4]'s matrix size -- ONE Lorenz-96 problem, D = 4096,
+RK4, short grid -- through vgpa_shard_sweep_sharded: S_t / Psi_t row-sharded over the N ranks with RCCL collectives per RK stage,
+energy / gradient phases time-parallel, x and the gradient memory-sharded.  The problem is fixed, so the per-N values of
+`config5.s_per_sweep` give STRONG scaling; the headline `value` stays the D = 40 metric.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -44,7 +52,27 @@ def parse():
     ap.add_argument("--no-single-problem", action="store_true",
                     help="skip the single-problem latency probe (so that a kernel profile of the run holds batched launches only)")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) stepping kernels")
+    ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
+    ap.add_argument("--config5-np", type=int, default=9, help="grid points of the D = 4096 block (its step rate does not depend on it)")
+    ap.add_argument("--config5-dim", type=int, default=4096)
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a child process group (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1) and hand its exit code back.  Nothing in THIS process has touched the GPU (no torch
+    import, no HIP call): a process that holds the GPU is never replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] no launcher (WORLD_SIZE unset): starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _cpu_sweep(job):
@@ -63,7 +91,8 @@ def _cpu_sweep(job):
 
 def cpu_baseline(p, x, method, d, n_pts, dt):
     """The numpy oracle on the host cores, BEFORE this process touches the GPU (the pool forks).  `value`: one sweep on one
-    core in the reference's operation order (faithful mode); `all_cores`: one such sweep per host core, concurrently --
+    core in the reference's operation order (faithful mode); `many_cores`: one such sweep per core of this job's share of the host
+    (`cores_used` workers; `host_cores` says what the machine has), concurrently --
     independent problems are how the path parallelises on a CPU (a 40 x 40 sweep has nothing for BLAS threads to do)."""
     import multiprocessing as mp
     from oracle import vgpa_oracle as vo
@@ -82,25 +111,113 @@ def cpu_baseline(p, x, method, d, n_pts, dt):
             tw = time.perf_counter()
             res = pool.map_async(_cpu_sweep, [(prob, x, True)] * cores).get(timeout=20.0 * t_faith + 60.0)
             wall = time.perf_counter() - tw
-        all_cores = {"cores": cores, "value": cores / wall, "unit": "sweeps/s", "seconds": wall,
+        all_cores = {"cores_used": cores, "value": cores / wall, "unit": "sweeps/s", "seconds": wall,
                      "how": f"{cores} concurrent single-threaded oracle processes, one faithful sweep each",
                      "slowest_worker_s": max(r[0] for r in res)}
     except Exception as exc:                                  # (a box that forbids fork: keep the one-core figure)
-        all_cores = {"cores": cores, "value": None, "error": repr(exc)}
+        all_cores = {"cores_used": cores, "value": None, "error": repr(exc)}
     return {"value": 1.0 / t_faith, "unit": "sweeps/s", "cores": 1, "kind": "port",
             "sample": f"1 full sweep of the same workload (L96 D={d} Np={n_pts}), numpy oracle in faithful mode (same "
-                      f"per-step operations as the reference), one core; all_cores: one such sweep per host core",
+                      f"per-step operations as the reference), one core; many_cores: one such sweep on each of cores_used cores",
             "seconds": t_faith, "lean_value": 1.0 / t_lean, "lean_seconds": t_lean, "host_cores": os.cpu_count(),
-            "all_cores": all_cores, "F_cpu": f_cpu}
+            "many_cores": all_cores, "F_cpu": f_cpu}
+
+
+def config5_block(args, rank, world, local_rank, rehearse):
+    """One Lorenz-96 problem at BASELINE configs[4]'s matrix size on ALL ranks of the job: the fused sweep (free energy + gradient)
+    with S_t / Psi_t row-sharded (vgpa_shard_sweep_sharded: RCCL all-to-all + pipelined gather per RK stage), x and the gradient
+    memory-sharded.  Strong scaling: the problem does not change with N.  Never raises: a failure is reported in the block."""
+    import math
+    import torch
+    import torch.distributed as dist
+    from vgpa_amd import parallel as par
+    d, n = args.config5_dim, args.config5_np
+    if d % world or (rehearse and world > 1):
+        return {"skipped": f"D={d} is not a multiple of {world} ranks" if d % world else "rehearsal mode has no RCCL communicator"}
+    try:
+        from vgpa_amd.large_d import NativeShardedRecursion
+        from vgpa_amd._lib import SHARD_OPT_TIMEOUT_MS
+        dev = torch.device("cuda", local_rank)
+        f64 = dict(dtype=torch.float64, device=dev)
+        rec = NativeShardedRecursion("rk4", 0.01, d, n, rank=rank, world=world, device=local_rank)
+        rec.set_option(SHARD_OPT_TIMEOUT_MS, 120000)
+        lo, hi = rec.time_slice
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(7)                                   # every rank draws the same problem and keeps its own grid points
+        m0 = 8.0 + torch.randn(d, generator=gen, **f64)
+        a_own = torch.empty((max(hi - lo, 1), d, d), **f64)
+        for t in range(n):
+            a_t = torch.randn((d, d), generator=gen, **f64).mul_(0.05 / math.sqrt(d))
+            a_t.diagonal().add_(8.0)
+            if lo <= t < hi:
+                a_own[t - lo] = a_t
+        del a_t
+        b_all = 8.0 * m0 + torch.randn((n, d), generator=gen, **f64)
+        obs_t = np.arange(3, n - 1, 4, dtype=np.int64)
+        obs_y = (8.0 + torch.randn((max(obs_t.size, 1), d), generator=gen, **f64)).cpu().numpy()[:obs_t.size]
+        sig, rdiag, s0, m0h = np.full(d, 4.0), np.ones(d), 0.2 * np.eye(d), m0.cpu().numpy()
+
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def once():
+            return rec.sweep_sharded(a_own[:hi - lo], b_all[lo:hi], 8.0, sig, m0h, s0, obs_t, obs_y, rdiag, 0.0)
+
+        f, ga, gb = once()                                   # warm-up: allocates the sweep's buffers
+        reps = 2
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f, ga, gb = once()
+        sync()
+        secs = par.max_over_ranks((time.perf_counter() - t0) / reps, device="cuda")
+        chk = torch.tensor([float(ga.abs().sum()), float(gb.abs().sum())], **f64)
+        if world > 1:
+            dist.all_reduce(chk)
+        a2a_ms, gather_ms = rec.time_collectives(10)
+        chunks = rec.gather_chunks
+        rec.close()
+        flop = 24.0 * d ** 3 * n                             # SURVEY 8d: nominal flop of one fused sweep
+        return {"workload": f"Lorenz96 D={d}, RK4, Np={n}: ONE problem, fused sweep (free energy + gradient), S_t / Psi_t row-sharded, "
+                            f"energy / gradient time-parallel, x and gradient memory-sharded (BASELINE configs[4] matrix size; its "
+                            f"full grid fits no node)",
+                "n_gpus": world, "rccl_ranks": world if world > 1 else 0, "scaling": "strong", "s_per_sweep": secs,
+                "recursion_steps_per_s": 2 * (n - 1) / secs, "aggregate_tflops_nominal": flop / secs / 1e12,
+                "frac_of_fp64_peak_per_gpu": flop / secs / 1e12 / world / FP64_PEAK_TFLOPS,
+                "schedule": f"pipelined gather, {chunks} sub-blocks, second stream" if chunks else
+                            ("serial (one grouped all-gather per stage)" if world > 1 else "one rank: no collective"),
+                "per_stage_collective_ms": {"all_to_all": a2a_ms, "gather": gather_ms,
+                                            "how": "vgpa_shard_time_collectives: the stage's two collectives alone, same buffers and streams"},
+                "F": f, "finite": bool(np.isfinite(f)), "checks": {"sum|gLa|": float(chk[0]), "sum|gLb|": float(chk[1])}}
+    except Exception as exc:                                 # noqa: BLE001 - the headline line must still be printed
+        return {"error": repr(exc)}
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (n_gpus in the JSON line is the number of "
+                         f"ranks that ran)")
+    if os.environ.get("VGPA_BENCH_LAUNCH_ONLY") == "1":       # CPU test of the launcher: rendezvous, report, leave (no GPU work)
+        import torch.distributed as dist
+        from vgpa_amd import parallel as par
+        par.init_from_env("gloo")
+        par.barrier()
+        seen = par.max_over_ranks(float(rank)) + 1.0
+        if rank == 0:
+            print(json.dumps({"launcher": "ok", "n_gpus": world, "ranks_seen": int(seen)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # host-side inputs first (numpy only), and with them the CPU baseline: its worker pool forks, which must happen
     # before this process initialises the GPU
@@ -113,7 +230,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(p, x_first, args.method, d, n_pts, dt)
-        print(f"[bench] cpu baseline: all cores {cpu['all_cores']}", file=sys.stderr, flush=True)
+        print(f"[bench] cpu baseline: many cores {cpu['many_cores']}", file=sys.stderr, flush=True)
 
     # torch is plumbing only (process group, barrier, device sync).  It must be imported BEFORE libvgpa_hip.so
     # is loaded so that both share one HIP runtime (same SONAME, see vgpa_amd/_lib.py).
@@ -173,14 +290,17 @@ def main():
 
     elapsed = par.max_over_ranks(elapsed, device="cpu" if rehearse else "cuda")
 
-    # ---- correctness guard inside the bench: problem 0 of rank 0 must reproduce the reference's anchor
-    check = None
+    # ---- correctness guard inside the bench: problem 0 of rank 0 must reproduce the reference's anchors -- the free energy AND
+    # the norm of the gradient the timed launches left in g_dev (per-problem dot products on the device)
+    check = check_g = None
     if rank == 0 and n_pts == 1001 and d == 40 and args.method.upper() == "RK4":
         anchors = json.load(open(os.path.join(ROOT, "tests", "golden", "anchors.json")))
-        f_ref = anchors["l96d40_rk4_full_p"]["F"]
+        f_ref, g_ref = anchors["l96d40_rk4_full_p"]["F"], anchors["l96d40_rk4_full_p"]["grad_norm"]
         check = abs(np.atleast_1d(f_last)[0] - f_ref) / abs(f_ref)
-        if check > 1e-9 and os.environ.get("VGPA_BENCH_NO_CHECK") != "1":   # (diagnostic builds only)
-            raise SystemExit(f"bench result is WRONG: F={np.atleast_1d(f_last)[0]!r} vs reference {f_ref!r}")
+        check_g = abs(float(np.sqrt(np.atleast_1d(ctx.vdot(g_dev, g_dev))[0])) - g_ref) / g_ref
+        if max(check, check_g) > 1e-9 and os.environ.get("VGPA_BENCH_NO_CHECK") != "1":   # (diagnostic builds only)
+            raise SystemExit(f"bench result is WRONG: F={np.atleast_1d(f_last)[0]!r} vs reference {f_ref!r}; "
+                             f"|grad| rel. err {check_g:.3e}")
 
     # ---- single-problem latency (what one SCG evaluation costs), rank 0, outside the timed region
     single = None
@@ -204,6 +324,13 @@ def main():
                   "bwd_ms": pr1["bwd_ms"] / reps, "grad_ms": pr1["grad_ms"] / reps}
         c1.close()
 
+    # ---- secondary block: BASELINE configs[4]'s matrix size through the row-sharded driver (every rank takes part)
+    c5 = None
+    if not args.no_config5 and not args.generic:
+        ctx.close()
+        del x_dev, g_dev
+        c5 = config5_block(args, rank, world, local_rank, rehearse)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -224,6 +351,13 @@ def main():
 
     def traffic_of(name):
         return tj.get(f"{name}_B{B}_D{d}_Np{n_pts}")
+
+    # NOT measured in this run: PMC counters need rocprofv3 passes of their own (tools/profile_bench.sh); the numbers are the
+    # committed result of the last such run of this workload
+    traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
+                      "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-single-problem "
+                             "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r02r_pmc_fetch_write_B512.csv"}
 
     kernels = {
         # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
@@ -273,7 +407,10 @@ def main():
         # use case waits for -- is latency-bound on one CU:
         "single_problem_sweeps_per_s": None if single is None else single["sweeps_per_s"],
         "whole_sweep_frac_of_hbm": sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS,
-        "roofline": dict(roof[dom], note=f"kernel with the longest launch of the sweep (batched, B={B}); energy+obs phase = "
+        # the nominal 24 D^3 flop per grid point against the fp64 matrix peak: at D = 40 the sweep is bound by the
+        # matrix pipe, not by HBM (19.6 us of fp64 work vs 8.2 us of HBM traffic per sweep), so THIS is the whole-sweep roofline
+        "whole_sweep_frac_of_fp64": 24.0 * d ** 3 * n_pts * value / world / 1e12 / FP64_PEAK_TFLOPS,
+        "roofline": dict(roof[dom], traffic_source=traffic_source, note=f"kernel with the longest launch of the sweep (batched, B={B}); energy+obs phase = "
                                          f"k_energy_l96_r + k_obs (0.1 ms); all four kernels under roofline_kernels; whole "
                                          f"sweep = {sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS:.3f} of HBM on SURVEY 8d's "
                                          f"algorithmic bytes; single problem = "
@@ -287,7 +424,10 @@ def main():
                               "reduce+grad": prof["grad_ms"] / steps},
         "single_problem": single,
         "parity_check_rel_err_F": check,
+        "parity_check_rel_err_grad_norm": check_g,
     }
+    if c5 is not None:
+        out["config5"] = c5
 
     if cpu is not None:                              # measured before the GPU work, rank 0 at N = 1 only
         f_cpu = cpu.pop("F_cpu")

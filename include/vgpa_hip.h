@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define VGPA_ABI_VERSION 1
+#define VGPA_ABI_VERSION 2
 
 typedef enum {
   VGPA_OK = 0,
@@ -50,7 +50,9 @@ typedef enum {
   VGPA_ERR_DEVICE = -2,     /* no usable HIP device, or a HIP runtime call failed (RuntimeError)   */
   VGPA_ERR_NOT_PD = -3,     /* a matrix that must be positive definite is not (LinAlgError)        */
   VGPA_ERR_STATE = -4,      /* call order violated, e.g. gradient before free_energy (RuntimeError) */
-  VGPA_ERR_UNSUPPORTED = -5 /* valid request that this build does not implement (NotImplementedError) */
+  VGPA_ERR_UNSUPPORTED = -5, /* valid request that this build does not implement (NotImplementedError) */
+  VGPA_ERR_COMM = -6        /* a collective of the row-sharded path failed or timed out; the communicator has been aborted
+                               and the shard is unusable (RuntimeError on every rank)                */
 } vgpa_status;
 
 /* model ids: dynamical_systems registry, src/var_bayes/simulation.py:20-21 */
@@ -231,20 +233,33 @@ typedef struct {
 
 int vgpa_ld_gemm(void* stream, int transa, int M, int N, int K, const double* A0, const double* A1_or_null, int lda,
                  const double* B, int ldb, double* C, int cw);
+/* (vgpa_ld_stage runs the general kernel: E0 / E1 / J / base need not be symmetric.  The drivers inside the library, whose
+ * inputs are checked to be symmetric, use a kernel that touches only the tiles on and above the diagonal.) */
 int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* args);
+/* One K-CHUNK launch of the stage product (the pipelined row-sharded stage splits a product into launches that wait for
+ * different parts of the operand): C (+)= op(A)[:, ks] . B[ks, :] over the k-set ks = seg_tiles consecutive 16-wide k-tiles out
+ * of every seg_stride k, K k's in all, starting where A0 / B point; accumulate != 0 continues the fp64 sums stored in C. */
+int vgpa_ld_gemm_chunk(void* stream, int transa, int M, int N, int K, const double* A0, int lda, const double* B, int ldb,
+                       double* C, int cw, int seg_tiles, int seg_stride, int accumulate);
 
 /* row-sharded recursion for large D on the GPUs of one node (BASELINE configs[4]) ------------------
  * One vgpa_shard per process / GPU.  Rank p of `world` owns rows [p D/world, (p+1) D/world) of S_t / Psi_t inside every
  * Runge-Kutta stage and the contiguous slice [t_lo, t_hi) of the TIME grid of the results (vgpa_shard_time_slice): the
  * whole step / stage loop of src/numerics/{euler,heun,runge_kutta2,runge_kutta4}.py:solve_fwd / solve_bwd runs inside
- * vgpa_shard_solve_* with two collectives per stage enqueued on the shard's stream between the kernels (an all-to-all of
- * the packed product blocks, one grouped all-gather of the next stage state's row blocks + vector entries) and no host
- * synchronisation.  The collectives come through a vgpa_comm table: vgpa_rccl_comm_create fills it from librccl
- * (dlopen'ed; rank 0 calls vgpa_rccl_unique_id and the host runtime -- MPI, torch.distributed, a file -- hands the 128
- * bytes to the other ranks), tests inject their own.  All pointers are DEVICE pointers; inputs are replicated on every
- * rank ([Np][D][D] / [Np][D], same meaning as vgpa_solve_fwd / vgpa_solve_bwd), outputs hold only the rank's own grid
- * points: m_own [t_hi - t_lo][D], S_own [t_hi - t_lo][D][D].  D must be a multiple of `world`; symmetric S0 / Sigma /
- * dEsde_dS / jumps as for every D > 64 path.  Calls return when the work is ENQUEUED (vgpa_shard_synchronize waits). */
+ * vgpa_shard_solve_* with two collectives per stage and no host synchronisation: an all-to-all of the packed product
+ * blocks on the compute stream and the gather of the next stage state's row blocks + vector entries -- either ONE grouped
+ * all-gather on the compute stream (serial schedule) or, when the table has send / recv, C sub-blocks on a second stream
+ * with the next stage's product split into C K-chunk launches that each wait for one sub-block only (pipelined schedule,
+ * the default: VGPA_SHARD_OPT_GATHER_CHUNKS).  The collectives come through a vgpa_comm table: vgpa_rccl_comm_create fills
+ * it from librccl (dlopen'ed; rank 0 calls vgpa_rccl_unique_id and the host runtime -- MPI, torch.distributed, a file --
+ * hands the 128 bytes to the other ranks), tests inject their own.  All pointers are DEVICE pointers; the operator-level
+ * calls take inputs replicated on every rank ([Np][D][D] / [Np][D], same meaning as vgpa_solve_fwd / vgpa_solve_bwd),
+ * outputs hold only the rank's own grid points: m_own [t_hi - t_lo][D], S_own [t_hi - t_lo][D][D].  D must be a multiple
+ * of `world`; symmetric S0 / Sigma / dEsde_dS / jumps as for every D > 64 path.  Calls return when the work is ENQUEUED
+ * (vgpa_shard_synchronize waits, at most VGPA_SHARD_OPT_TIMEOUT_MS).
+ * Errors are collective: a failing table entry, a launch failure or a time-out aborts the communicator (`abort`) and returns
+ * VGPA_ERR_COMM / VGPA_ERR_DEVICE; the shard is unusable afterwards (every later call returns VGPA_ERR_COMM).  The host
+ * runtime's restart policy is a fresh process or a non-zero exit -- never a re-exec of a process that holds the GPU. */
 typedef struct vgpa_comm {
   void* user;
   /* recv[q * count .. (q+1) * count) = send of rank q; send may be recv + rank * count (in place) */
@@ -253,6 +268,12 @@ typedef struct vgpa_comm {
   int (*all_to_all)(void* user, const double* send, double* recv, uint64_t count, void* stream);
   int (*group_begin)(void* user);      /* optional (may be NULL): fuse the calls up to group_end into one launch */
   int (*group_end)(void* user);
+  /* optional point-to-point pair (both or neither; only between group_begin and group_end, which are then required): the
+   * pipelined gather posts, per sub-block, one send to and one receive from every peer -- one xGMI link each */
+  int (*send)(void* user, const double* buf, uint64_t count, int peer, void* stream);
+  int (*recv)(void* user, double* buf, uint64_t count, int peer, void* stream);
+  /* optional: tear the communicator down after a failure so that no rank stays inside a collective (ncclCommAbort) */
+  int (*abort)(void* user);
 } vgpa_comm;
 typedef struct vgpa_shard vgpa_shard;
 int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_pts, int rank, int world, int device,
@@ -261,6 +282,14 @@ void vgpa_shard_destroy(vgpa_shard* s);
 int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi);
 void* vgpa_shard_stream(vgpa_shard* s);
 int vgpa_shard_synchronize(vgpa_shard* s);
+enum vgpa_shard_option {
+  VGPA_SHARD_OPT_GATHER_CHUNKS = 1,  /* sub-blocks of the pipelined gather: 0 = serial schedule, 1..8 (reduced to what the
+                                        row-block size allows: whole 16-row k-tiles per sub-block; 0 without send / recv).
+                                        Default 4, or the environment's VGPA_SHARD_CHUNKS.  Same value on every rank. */
+  VGPA_SHARD_OPT_TIMEOUT_MS = 2      /* bound of every host wait on the shard's streams (default 600000; <= 0: none) */
+};
+int vgpa_shard_set_option(vgpa_shard* s, int option, int64_t value);
+int vgpa_shard_get_option(const vgpa_shard* s, int option, int64_t* value);
 int vgpa_shard_solve_fwd(vgpa_shard* s, const double* lin_a, const double* off_b, const double* m0, const double* s0,
                          const double* sigma, double* m_own, double* s_own);
 int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde_dm, const double* desde_ds,
@@ -268,12 +297,20 @@ int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde
 /* The fused sweep -- free energy AND gradient of VarGP (src/var_bayes/variational.py:141-288) -- of ONE Lorenz-96 problem
  * (diagonal system noise, diagonal R, H = I: the restrictions of every D > 64 path) on the row-sharded recursion:
  *   forward recursion, row-sharded, (m_t, S_t) time-sharded  ->  observation terms and E_sde terms of the rank's own grid
- *   points (time-parallel: lorenz_96.py:316-438 per grid point)  ->  ONE grouped all-gather of dEsde_dm / dEsde_dS / E_sde(t)
- *   (+ a small one of the observation jumps)  ->  backward recursion, row-sharded  ->  gradient of the own grid points.
- * x_dev = [A_t (Np,D,D) | b_t (Np,D)] replicated on every rank (device); F comes back on every rank (host); the gradient
- * stays TIME-sharded: grad_a_own [t_hi - t_lo][D][D], grad_b_own [t_hi - t_lo][D] (device).  Memory per rank besides x: one
- * gathered (Np, D, D) array (dEsde_dS) and four time slices (S, Psi, dEsde_dS, the gradient).  Synchronises the shard's
- * stream before returning.  VGPA_ERR_NOT_PD when a marginal covariance S_t of an own grid point is not positive definite. */
+ *   points (time-parallel: lorenz_96.py:316-438 per grid point)  ->  a time -> row EXCHANGE of dEsde_dS (all-to-all: every
+ *   rank receives rows I_p of every grid point, 1/world of an all-gather's bytes) + small all-gathers of dEsde_dm / E_sde(t)
+ *   / the observation jumps  ->  backward recursion, row-sharded  ->  gradient of the own grid points.
+ * vgpa_shard_sweep:         x_dev = [A_t (Np,D,D) | b_t (Np,D)] replicated on every rank (device).
+ * vgpa_shard_sweep_sharded: x MEMORY-SHARDED like the gradient -- a_own [t_hi - t_lo][D][D], b_own [t_hi - t_lo][D] (the
+ *                           layout of variational.py:153-162 restricted to the rank's grid points); rows I_p (forward) and
+ *                           columns I_p (backward) of every A_t reach the recursions through two more exchanges.  No rank
+ *                           ever holds a complete (Np, D, D) array: per rank seven arrays of Np/world matrices (x, the two
+ *                           block copies of A, S, dEsde_dS / Psi, its row blocks, the gradient).
+ * F comes back on every rank (host); the gradient stays TIME-sharded: grad_a_own [t_hi - t_lo][D][D], grad_b_own
+ * [t_hi - t_lo][D] (device).  Synchronises the shard's streams before returning.  The return code is COLLECTIVE -- the same
+ * on every rank: VGPA_ERR_NOT_PD when a marginal covariance S_t of ANY rank's grid points is not positive definite (the
+ * reference raises LinAlgError, variational.py:380), VGPA_ERR_DEVICE when any rank could not allocate its buffers,
+ * VGPA_ERR_ARG (before any collective) for observation indices that are out of range or not strictly increasing. */
 typedef struct {
   double theta;                   /* Lorenz-96 forcing */
   const double* inv_sigma_diag;   /* [D] device: diagonal of Sigma^-1 */
@@ -281,7 +318,7 @@ typedef struct {
   const double* s0;               /* [D][D] device */
   const double* sigma;            /* [D][D] device */
   int32_t n_obs;
-  const int64_t* obs_t;           /* [n_obs] HOST: grid indices of the observations, increasing */
+  const int64_t* obs_t;           /* [n_obs] HOST: grid indices of the observations, strictly increasing */
   const double* obs_y;            /* [n_obs][D] device */
   const double* obs_rinv_diag;    /* [D] device: diagonal of R^-1 */
   double obs_const;               /* n_obs (D log(2 pi) + log det R)  (gaussian_like.py:87-92) */
@@ -289,6 +326,11 @@ typedef struct {
 } vgpa_shard_problem;
 int vgpa_shard_sweep(vgpa_shard* s, const vgpa_shard_problem* problem, const double* x_dev, double* f_host,
                      double* grad_a_own, double* grad_b_own);
+int vgpa_shard_sweep_sharded(vgpa_shard* s, const vgpa_shard_problem* problem, const double* a_own, const double* b_own,
+                             double* f_host, double* grad_a_own, double* grad_b_own);
+/* the two per-stage collectives alone (same buffers, sizes, streams and schedule as inside a stage), averaged over `reps`
+ * rounds: what bench.py reports as per-stage collective milliseconds.  Collective call. */
+int vgpa_shard_time_collectives(vgpa_shard* s, int reps, double* all_to_all_ms, double* gather_ms);
 /* RCCL behind the vgpa_comm table: collectives over xGMI; the library is dlopen'ed on first use */
 #define VGPA_RCCL_UNIQUE_ID_BYTES 128
 int vgpa_rccl_unique_id(void* out_128_bytes);

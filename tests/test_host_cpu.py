@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/vgpa_hip.h but not exported"
     from vgpa_amd._lib import SYMBOLS
     assert set(SYMBOLS) == declared
-    assert lib.vgpa_abi_version() == 1
+    assert lib.vgpa_abi_version() == 2
 
 
 def test_no_silent_cpu_fallback():

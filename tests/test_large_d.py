@@ -367,28 +367,52 @@ def test_library_gemm_backend_of_the_stage_product(method):
 class _CallbackComm:
     """`world` virtual ranks in threads of ONE process sharing one GPU: a vgpa_comm table whose collectives are
     barrier-ordered device copies (hipMemcpyAsync through ctypes).  Exercises the C++ driver's schedule, pointer
-    arithmetic and in-place gathers; RCCL itself sits behind the same table (tests/test_large_d.py::test_rccl_*)."""
+    arithmetic, in-place gathers, the point-to-point groups of the pipelined gather (send / recv between group_begin and
+    group_end, matched per peer in posting order like ncclSend / ncclRecv) and the failure path (`abort` breaks the barrier,
+    so every rank's next collective fails -- what ncclCommAbort plus the shard's bounded waits do on real hardware).
+    `fail_at = (rank, n)`: that rank's n-th table call returns an error instead of taking part.
+    `p2p=False` hands out a table without send / recv: the driver then keeps the serial schedule.
+    RCCL itself sits behind the same table (tests/test_large_d.py::test_rccl_*)."""
 
-    def __init__(self, world):
+    def __init__(self, world, fail_at=None, p2p=True):
         import threading
         self.world = world
         self.barrier = threading.Barrier(world)
         self.send = [None] * world
+        self.posted = [None] * world           # per rank: the sends of its open group, [(peer, ptr, count)]
         self.hip = ctypes_hip()
+        self.fail_at, self.p2p = fail_at, p2p
+        self.calls = [0] * world
+        self.p2p_groups = [0] * world          # groups that carried point-to-point traffic (the pipelined gather ran)
 
     def table(self, rank):
         import ctypes
-        from vgpa_amd._lib import VgpaComm, COMM_COLLECTIVE, COMM_GROUP
+        from vgpa_amd._lib import VgpaComm, COMM_COLLECTIVE, COMM_GROUP, COMM_P2P
         hip, world = self.hip, self.world
+        group = {"open": False, "sends": [], "recvs": [], "stream": None}
+
+        def guarded(fn):
+            def call(*a):
+                try:
+                    self.calls[rank] += 1
+                    if self.fail_at is not None and self.fail_at == (rank, self.calls[rank]):
+                        return 7                                  # this rank's collective fails; it never reaches the barrier
+                    return fn(*a)
+                except BaseException:                             # noqa: BLE001 - a broken barrier is a failed collective
+                    return 9
+            return call
+
+        def wait():
+            self.barrier.wait(timeout=300)
 
         def publish(send, stream):
             hip.hipStreamSynchronize(ctypes.c_void_p(stream))
             self.send[rank] = send
-            self.barrier.wait()
+            wait()
 
         def finish(stream):
             hip.hipStreamSynchronize(ctypes.c_void_p(stream))
-            self.barrier.wait()
+            wait()
 
         def all_gather(user, send, recv, count, stream):
             publish(send, stream)
@@ -407,10 +431,53 @@ class _CallbackComm:
             finish(stream)
             return 0
 
+        def group_begin(user):
+            group.update(open=True, sends=[], recvs=[], stream=None)
+            return 0
+
+        def send(user, buf, count, peer, stream):
+            assert group["open"] and 0 <= peer < world and peer != rank
+            group["sends"].append((peer, buf, count)); group["stream"] = stream
+            return 0
+
+        def recv(user, buf, count, peer, stream):
+            assert group["open"] and 0 <= peer < world and peer != rank
+            group["recvs"].append((peer, buf, count)); group["stream"] = stream
+            return 0
+
+        def group_end(user):
+            group["open"] = False
+            if not group["sends"] and not group["recvs"]:
+                return 0
+            stream = group["stream"]
+            hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+            self.posted[rank] = list(group["sends"])
+            wait()
+            taken = {}
+            for peer, buf, count in group["recvs"]:               # the k-th receive from a peer meets its k-th send to this rank
+                mine = [t for t in self.posted[peer] if t[0] == rank]
+                k = taken.get(peer, 0)
+                _, src, n = mine[k]
+                assert n == count, (n, count)
+                taken[peer] = k + 1
+                hip.hipMemcpyAsync(ctypes.c_void_p(buf), ctypes.c_void_p(src), ctypes.c_size_t(count * 8), 3, ctypes.c_void_p(stream))
+            self.p2p_groups[rank] += 1
+            finish(stream)
+            return 0
+
+        def abort(user):
+            self.barrier.abort()
+            return 0
+
         t = VgpaComm()
-        t._keep = (COMM_COLLECTIVE(all_gather), COMM_COLLECTIVE(all_to_all))      # keep the thunks alive
-        t.user, t.all_gather, t.all_to_all = None, t._keep[0], t._keep[1]
-        t.group_begin, t.group_end = COMM_GROUP(), COMM_GROUP()
+        t._keep = (COMM_COLLECTIVE(guarded(all_gather)), COMM_COLLECTIVE(guarded(all_to_all)), COMM_GROUP(guarded(group_begin)),
+                   COMM_GROUP(guarded(group_end)), COMM_P2P(guarded(send)), COMM_P2P(guarded(recv)), COMM_GROUP(abort))      # keep the thunks alive
+        t.user, t.all_gather, t.all_to_all, t.group_begin, t.group_end = None, t._keep[0], t._keep[1], t._keep[2], t._keep[3]
+        if self.p2p:
+            t.send, t.recv = t._keep[4], t._keep[5]
+        else:
+            t.send, t.recv = COMM_P2P(), COMM_P2P()
+        t.abort = t._keep[6]
         return t
 
 
@@ -428,20 +495,26 @@ def ctypes_hip():
     return ctypes.CDLL(paths[0])
 
 
-def _run_native_virtual_ranks(method, d, n, world):
+def _run_native_virtual_ranks(method, d, n, world, chunks=None):
+    """chunks: None = the library's default schedule (pipelined gather wherever the row block allows it), 0 = the serial
+    schedule, k = k sub-blocks."""
     import threading
     import torch
     from vgpa_amd.large_d import NativeShardedRecursion
+    from vgpa_amd._lib import SHARD_OPT_GATHER_CHUNKS
     a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
     mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
     lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, gs, jm, js)
     comm = _CallbackComm(world)
-    errs, fails, slices = [None] * world, [], [None] * world
+    errs, fails, slices, used = [None] * world, [], [None] * world, [None] * world
 
     def run(rank):
         try:
             torch.cuda.set_device(0)
             rec = NativeShardedRecursion(method, 0.01, d, n, rank=rank, world=world, device=0, comm=comm.table(rank))
+            if chunks is not None:
+                rec.set_option(SHARD_OPT_GATHER_CHUNKS, chunks)
+            used[rank] = rec.gather_chunks
             lo, hi = rec.time_slice
             slices[rank] = (lo, hi)
             mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
@@ -465,6 +538,11 @@ def _run_native_virtual_ranks(method, d, n, world):
     assert all(e is not None and e < TOL for e in errs), errs
     # the owners' slices tile the grid
     assert slices[0][0] == 0 and slices[-1][1] == n and all(slices[r][1] == slices[r + 1][0] for r in range(world - 1))
+    # the schedule that ran: the same on every rank, and the pipelined one really went through the point-to-point groups
+    assert len(set(used)) == 1
+    if world > 1:
+        assert (comm.p2p_groups[0] > 0) == (used[0] > 0)
+    return used[0]
 
 
 @pytest.mark.gpu
@@ -473,7 +551,94 @@ def _run_native_virtual_ranks(method, d, n, world):
 def test_native_sharded_driver_with_virtual_ranks(method, d, n, world):
     """vgpa_shard_solve_fwd / _bwd (C++ step / stage loop + collectives through vgpa_comm): every virtual rank's time slice
     must equal the unsharded oracle; also with more ranks than some slices have grid points."""
-    _run_native_virtual_ranks(method, d, n, world)
+    used = _run_native_virtual_ranks(method, d, n, world)
+    # the default schedule is the pipelined gather wherever a sub-block can hold whole 16-row k-tiles
+    assert used == {(128, 2): 4, (192, 4): 3, (96, 3): 2, (80, 1): 0}[(d, world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,n,world,chunks", [("rk4", 128, 7, 2, 0), ("rk4", 128, 7, 2, 1), ("rk4", 128, 7, 2, 2),
+                                                     ("rk2", 192, 6, 4, 0), ("heun", 192, 6, 4, 1), ("euler", 256, 5, 4, 4),
+                                                     ("rk4", 256, 5, 2, 8)])
+def test_native_sharded_driver_schedules(method, d, n, world, chunks):
+    """The serial schedule (one grouped all-gather per stage on the compute stream) and the pipelined one with 1, 2, 4, 8
+    sub-blocks (second stream, per-sub-block events, K-chunk launches of the next product): same recursion, same oracle."""
+    used = _run_native_virtual_ranks(method, d, n, world, chunks=chunks)
+    assert used == chunks
+
+
+@pytest.mark.gpu
+def test_native_sharded_driver_without_point_to_point_table_stays_serial():
+    """A vgpa_comm table without send / recv (round 2's layout): the driver keeps the serial schedule."""
+    import threading
+    import torch
+    from vgpa_amd.large_d import NativeShardedRecursion
+    d, n, world = 128, 5, 2
+    a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
+    mt_o, st_o = vo.solve_fwd("rk4", 0.01, False, a, b, m0, s0, sigma)
+    comm = _CallbackComm(world, p2p=False)
+    errs, fails = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            rec = NativeShardedRecursion("rk4", 0.01, d, n, rank=rank, world=world, device=0, comm=comm.table(rank))
+            assert rec.gather_chunks == 0
+            lo, hi = rec.time_slice
+            mt, st = rec.solve_fwd(a, b, m0, s0, sigma)
+            errs[rank] = max(rel_err(mt.cpu().numpy(), mt_o[lo:hi]), rel_err(st.cpu().numpy(), st_o[lo:hi]))
+            rec.close()
+        except BaseException as exc:      # noqa: BLE001
+            fails.append(exc)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not fails, fails
+    assert all(e is not None and e < TOL for e in errs) and comm.p2p_groups == [0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transa", [False, True])
+@pytest.mark.parametrize("M,D,world,chunks", [(512, 4096, 8, 4), (128, 1024, 8, 2), (64, 128, 2, 4), (32, 96, 3, 2)])
+def test_stage_gemm_k_chunk_launches(M, D, world, chunks, transa):
+    """vgpa_ld_gemm_chunk -- the K-chunk launches of the pipelined stage product: launch j multiplies sub-block j of every
+    rank's row block of the operand (k-tiles segmented with stride Mp) and continues the sums stored in W.  All launches
+    together = the whole product (numpy, 1e-12); one launch over every k in natural order = vgpa_ld_gemm bit for bit (the
+    accumulators continue one fp64 chain).  BASELINE configs[4]'s row block (512 x 4096 x 4096, 8 ranks, 4 sub-blocks: the
+    16-byte-load kernel) down to shapes that take the bounds-checked kernel."""
+    import ctypes
+    import torch
+    from vgpa_amd.large_d import HipStageBackend
+    be = HipStageBackend()
+    lib, st = be._lib, be._stream()
+    rng = np.random.default_rng(M + D + world)
+    a_h = rng.standard_normal((D, M) if transa else (M, D))          # op(A) = [M][K = D]
+    x_h = rng.standard_normal((D, D))
+    dev = torch.device("cuda", 0)
+    a_d, x_d = torch.as_tensor(a_h, device=dev), torch.as_tensor(x_h, device=dev)
+    w_d = torch.full((M * D,), float("nan"), dtype=torch.float64, device=dev)
+    mp = D // world
+    sub = mp // chunks
+    lda = M if transa else D
+    for j in range(chunks):
+        a_off = j * sub * lda if transa else j * sub
+        rc = lib.vgpa_ld_gemm_chunk(st, int(transa), M, D, world * sub, be._p(a_d, a_off), lda, be._p(x_d, j * sub * D), D, be._p(w_d), D,
+                                    sub // 16, mp, int(j > 0))
+        assert rc == 0
+    torch.cuda.synchronize()
+    want = (a_h.T if transa else a_h).dot(x_h)
+    assert rel_err(w_d.cpu().numpy().reshape(M, D), want) < 1e-12
+    # one segmented launch over all of K in natural order continues nothing and skips nothing: the plain product, bit for bit
+    w1, w2 = torch.zeros_like(w_d), torch.zeros_like(w_d)
+    assert lib.vgpa_ld_gemm_chunk(st, int(transa), M, D, D, be._p(a_d), lda, be._p(x_d), D, be._p(w1), D, mp // 16, mp, 0) == 0
+    assert lib.vgpa_ld_gemm(st, int(transa), M, D, D, be._p(a_d), None, lda, be._p(x_d), D, be._p(w2), D) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(w1, w2)
+    assert lib.vgpa_ld_gemm_chunk(st, int(transa), M, D, D, be._p(a_d), lda, be._p(x_d), D, be._p(w1), D, 3, 16, 0) == -1   # stride < segment
 
 
 @pytest.mark.gpu
@@ -517,6 +682,135 @@ def test_native_sharded_fused_sweep_with_virtual_ranks(method, d, n, world):
         t.join(timeout=600)
     assert not fails, fails
     assert all(e is not None and e < TOL for e in errs), errs
+
+
+def _virtual_ranks(world, body, comm=None):
+    """Runs body(rank, comm) in `world` threads; returns (results, exceptions)."""
+    import threading
+    import torch
+    comm = comm if comm is not None else _CallbackComm(world)
+    out, fails = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            out[rank] = body(rank, comm)
+        except BaseException as exc:      # noqa: BLE001 - a dead thread would leave the others at the barrier
+            fails[rank] = exc
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    return out, fails, comm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,n,world,chunks", [("rk4", 128, 11, 2, None), ("rk4", 96, 13, 3, None), ("heun", 192, 9, 4, 0),
+                                                     ("rk2", 128, 10, 4, None), ("euler", 80, 7, 1, None), ("rk4", 1024, 10, 8, None)])
+def test_native_sharded_sweep_with_memory_sharded_x(method, d, n, world, chunks):
+    """vgpa_shard_sweep_sharded: x handed over TIME-sharded like the gradient (a_own / b_own: the rank's grid points only).
+    Rows (forward) and columns (backward) of every A_t reach the row-sharded recursions through time -> block exchanges, dEsde_dS
+    through a time -> row exchange: no rank holds a complete (Np, D, D) array.  F and every gradient slice vs the oracle; slices of
+    uneven length and ranks with more grid points than an exchange batch included."""
+    from vgpa_amd.large_d import NativeShardedRecursion
+    from vgpa_amd._lib import SHARD_OPT_GATHER_CHUNKS
+    from test_gpu_edge_cases import make_problem
+    p, x = make_problem("L96", d, n, method=method)
+    f_o, g_o, _ = vo.sweep(p, x, faithful=False)
+    ga_o, gb_o = g_o[:n * d * d].reshape(n, d, d), g_o[n * d * d:].reshape(n, d)
+    a_h, b_h = x[:n * d * d].reshape(n, d, d), x[n * d * d:].reshape(n, d)
+    e0 = float(np.asarray(vo.kl0(p)))
+
+    def body(rank, comm):
+        rec = NativeShardedRecursion(method, p.dt, d, n, rank=rank, world=world, device=0, comm=comm.table(rank) if world > 1 else None)
+        if chunks is not None:
+            rec.set_option(SHARD_OPT_GATHER_CHUNKS, chunks)
+        lo, hi = rec.time_slice
+        for _ in range(2):             # twice: the buffers of the first call are reused
+            f, ga, gb = rec.sweep_sharded(a_h[lo:hi], b_h[lo:hi], p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y,
+                                          np.diag(p.obs_noise), e0)
+        e = abs(f - f_o) / abs(f_o)
+        if hi > lo:
+            e = max(e, rel_err(ga.cpu().numpy(), ga_o[lo:hi]), rel_err(gb.cpu().numpy(), gb_o[lo:hi]))
+        rec.close()
+        return e
+
+    errs, fails, _ = _virtual_ranks(world, body)
+    assert not any(fails), fails
+    assert all(e is not None and e < TOL for e in errs), errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_rank,fail_call", [(1, 3), (0, 9), (2, 30)])
+def test_native_sharded_sweep_collective_failure_reaches_every_rank(fail_rank, fail_call):
+    """One rank's collective fails (its table entry returns an error, as a dead peer or a driver fault would): that rank aborts
+    the communicator and returns VGPA_ERR_COMM; no rank stays inside a collective -- every rank comes back with an error, and the
+    shard refuses further work.  (On real hardware the peers leave through ncclCommAbort + the shard's bounded waits.)"""
+    from vgpa_amd.large_d import NativeShardedRecursion
+    from test_gpu_edge_cases import make_problem
+    d, n, world = 96, 7, 3
+    p, x = make_problem("L96", d, n, method="rk4")
+    comm = _CallbackComm(world, fail_at=(fail_rank, fail_call))
+
+    def body(rank, comm):
+        rec = NativeShardedRecursion("rk4", p.dt, d, n, rank=rank, world=world, device=0, comm=comm.table(rank))
+        try:
+            rec.sweep(x, p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), 0.0)
+        except RuntimeError as exc:
+            first = str(exc)
+            with pytest.raises(RuntimeError):           # the shard is unusable from now on
+                rec.sweep(x, p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), 0.0)
+            return first
+        finally:
+            rec._h and rec._lib.vgpa_shard_destroy(rec._h)
+            rec._h = None
+        return None
+
+    out, fails, _ = _virtual_ranks(world, body, comm)
+    assert not any(fails), fails
+    assert all(isinstance(o, str) for o in out), out          # every rank got an error, none hung, none "succeeded"
+    assert "collective" in out[fail_rank]
+
+
+@pytest.mark.gpu
+def test_native_sharded_sweep_outcome_is_collective():
+    """A covariance that loses positive definiteness on ONE rank's time slice: every rank raises LinAlgError -- the
+    reference raises it and the whole run ends (variational.py:380) -- instead of one rank leaving and the others carrying on with
+    NaN.  Then: unsorted / duplicate observation indices are refused before any collective (ValueError on every rank)."""
+    from vgpa_amd.large_d import NativeShardedRecursion
+    from test_gpu_edge_cases import make_problem
+    d, n, world = 96, 9, 3
+    p, x = make_problem("L96", d, n, method="euler")
+    xb = x.copy()
+    a = xb[:n * d * d].reshape(n, d, d)
+    a[3:] = 150.0 * np.eye(d)            # Euler: S <- (1 - 2 * 150 * dt) S + ... = -2 S from grid point 4 on: rank 0's slice [0, 3) stays fine
+
+    def body(rank, comm):
+        rec = NativeShardedRecursion("euler", p.dt, d, n, rank=rank, world=world, device=0, comm=comm.table(rank))
+        lo, hi = rec.time_slice
+        kinds = []
+        for xx, obs_t in ((xb, p.obs_t), (x, p.obs_t[::-1].copy()), (x, np.array([2, 2], dtype=np.int64))):
+            try:
+                rec.sweep(xx, p.theta, np.diag(p.sigma), p.m0, p.s0, obs_t, p.obs_y[:len(obs_t)], np.diag(p.obs_noise), 0.0)
+                kinds.append("ok")
+            except np.linalg.LinAlgError:
+                kinds.append("notpd")
+            except ValueError:
+                kinds.append("arg")
+        f, _, _ = rec.sweep(x, p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), 0.0)   # still usable
+        rec.close()
+        return (lo, hi), kinds, f
+
+    out, fails, _ = _virtual_ranks(world, body)
+    assert not any(fails), fails
+    assert out[0][0] == (0, 3)
+    assert all(o[1] == ["notpd", "arg", "arg"] for o in out), out
+    f_o, _, _ = vo.sweep(p, x, faithful=False)
+    e0 = float(np.asarray(vo.kl0(p)))
+    assert all(abs(o[2] + e0 - f_o) <= TOL * abs(f_o) for o in out)
 
 
 @pytest.mark.gpu

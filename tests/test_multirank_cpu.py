@@ -67,3 +67,32 @@ def test_two_rank_gloo_gather_and_timing(tmp_path):
         f_all = np.load(tmp_path / f"f_{rank}.npy")
         assert np.array_equal(f_all, serial)              # same problems, same order, on every rank
         assert float(np.load(tmp_path / f"t_{rank}.npy")[0]) == 2.0   # MAX over ranks of (1 + rank)
+
+
+def _bench(args, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus N` exactly as the driver types it (no torchrun, WORLD_SIZE unset): the script starts N ranks itself
+    (torch.distributed.run as a CHILD of a process that has made no GPU call), they rendezvous, and `n_gpus` is N -- never a silent
+    one-GPU run.  VGPA_BENCH_LAUNCH_ONLY=1 stops each rank after the rendezvous: no GPU in this container."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"VGPA_BENCH_LAUNCH_ONLY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"launcher": "ok", "n_gpus": 2, "ranks_seen": 2}
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    r = _bench(["--gpus", "2"], {"VGPA_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    r = _bench(["--gpus", "1"], {"VGPA_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    r = _bench(["--gpus", "0"], {})
+    assert r.returncode != 0

@@ -11,7 +11,7 @@ from ctypes import c_int, c_int32, c_int64, c_uint64, c_double, c_void_p, c_char
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvgpa_hip.so")
 
 MODEL_IDS = {"NONE": -1, "OU": 0, "DW": 1, "L63": 2, "L96": 3}
@@ -32,7 +32,8 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_profile_begin", "vgpa_profile_end", "vgpa_ld_gemm", "vgpa_ld_stage", "vgpa_gradient_dev", "vgpa_energy_full", "vgpa_set_option", "vgpa_is_streaming", "vgpa_set_prior_energy",
            "vgpa_vec_dot", "vgpa_vec_absmax", "vgpa_vec_asum", "vgpa_vec_axpby", "vgpa_release_x",
            "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
-           "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
+           "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_shard_sweep_sharded", "vgpa_shard_set_option",
+           "vgpa_shard_get_option", "vgpa_shard_time_collectives", "vgpa_ld_gemm_chunk", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
            "vgpa_rccl_comm_destroy"]
 
 P_DOUBLE = POINTER(c_double)
@@ -50,12 +51,15 @@ class LdStageArgs(ctypes.Structure):
 
 COMM_COLLECTIVE = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p)
 COMM_GROUP = ctypes.CFUNCTYPE(c_int, c_void_p)
+COMM_P2P = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int, c_void_p)
+SHARD_OPT_GATHER_CHUNKS, SHARD_OPT_TIMEOUT_MS = 1, 2
 
 
 class VgpaComm(ctypes.Structure):
     """vgpa_comm (include/vgpa_hip.h): the collectives of the row-sharded recursion as a table of function pointers."""
     _fields_ = [("user", c_void_p), ("all_gather", COMM_COLLECTIVE), ("all_to_all", COMM_COLLECTIVE),
-                ("group_begin", COMM_GROUP), ("group_end", COMM_GROUP)]
+                ("group_begin", COMM_GROUP), ("group_end", COMM_GROUP), ("send", COMM_P2P), ("recv", COMM_P2P),
+                ("abort", COMM_GROUP)]
 
 
 class VgpaShardProblem(ctypes.Structure):
@@ -133,6 +137,12 @@ def load():
     lib.vgpa_shard_solve_bwd.argtypes = [c_void_p] + [c_void_p] * 7
     lib.vgpa_shard_sweep.argtypes = [c_void_p, POINTER(VgpaShardProblem), c_void_p, P_DOUBLE, c_void_p, c_void_p]
     lib.vgpa_shard_sweep.restype = c_int
+    lib.vgpa_shard_sweep_sharded.argtypes = [c_void_p, POINTER(VgpaShardProblem), c_void_p, c_void_p, P_DOUBLE, c_void_p, c_void_p]
+    lib.vgpa_shard_set_option.argtypes = [c_void_p, c_int, c_int64]
+    lib.vgpa_shard_get_option.argtypes = [c_void_p, c_int, POINTER(c_int64)]
+    lib.vgpa_shard_time_collectives.argtypes = [c_void_p, c_int, P_DOUBLE, P_DOUBLE]
+    lib.vgpa_ld_gemm_chunk.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                       c_int, c_int, c_int]
     lib.vgpa_rccl_unique_id.argtypes = [c_void_p]
     lib.vgpa_rccl_comm_create.argtypes = [POINTER(VgpaComm), c_void_p, c_int, c_int, c_int]
     lib.vgpa_rccl_comm_destroy.argtypes = [POINTER(VgpaComm)]
@@ -164,6 +174,9 @@ def _raise(code, msg):
         raise np.linalg.LinAlgError(msg)
     if code == -5:
         raise NotImplementedError(msg)
+    if code == -6:
+        raise RuntimeError(f"libvgpa_hip: a collective of the row-sharded path failed or timed out; the communicator was aborted "
+                           f"and this shard is unusable ({msg})")
     raise RuntimeError(f"libvgpa_hip error {code}: {msg}")
 
 

@@ -19,8 +19,10 @@
 // (A lane map i = l & 15, k = l >> 4; B k = l >> 4, j = l & 15; C col = l & 15, row = (l >> 4) + 4 r -- probed,
 // profiles/r01_fp64_mfma_layout_probe.txt), LDS tiles stored k-major with leading dimensions chosen for
 // conflict-free b64 fragment reads, register-prefetched global loads, two LDS buffers, one barrier per k-step.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 
 #include "vgpa_internal.h"
 
@@ -42,6 +44,11 @@ struct GemmArgs {
   const double* B; int ldb;
   double* C;                // packed by column chunks of width cw: C[(j / cw) * M * cw + i * cw + (j % cw)]
   int cw;
+  // K-chunk launches of the pipelined row-sharded stage (shard_stage): the K tiles of THIS launch are `seg_tiles` consecutive
+  // k-tiles out of every `seg_stride` k (A0 / B point at the first one; K = k in this launch), i.e. the same sub-chunk of
+  // every rank's row block of the stage state; accumulate: the accumulators start from C instead of zero (the K-chunk
+  // launches of one product continue ONE fp64 FMA chain per element: bit-identical to a single launch over the same k order).
+  int seg_tiles = 0, seg_stride = 0, accumulate = 0;
 };
 
 // FULL: M, N, K are multiples of the tile sizes -- no bounds checks (each one is an EXEC-masked branch in the k loop)
@@ -63,6 +70,8 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
   //  B tile: 16 x 64 = 1024 doubles, 4 per thread, j = tid & 63 fastest.
   // two register sets: the operands of k-tile t+2 are in flight while tile t is multiplied and tile t+1 moves to LDS
   double ra0[AQ], rb0[4], ra1[AQ], rb1[4];
+  const int klim = g.seg_tiles ? 0x7fffffff : g.K;          // segmented launches are made of whole k-tiles
+  auto k_of = [&](int kt) { return g.seg_tiles ? (kt / g.seg_tiles) * g.seg_stride + (kt % g.seg_tiles) * BK : kt * BK; };
   auto load_tiles = [&](int k0, double (&ra)[AQ], double (&rb)[4]) {
 #pragma unroll
     for (int q = 0; q < AQ; q++) {
@@ -71,7 +80,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
       else { k = tid & 15; i = (tid >> 4) + 16 * q; }
       const int gi = i0 + i, gk = k0 + k;
       double v = 0.0;
-      if (FULL || (gi < g.M && gk < g.K)) {
+      if (FULL || (gi < g.M && gk < klim)) {
         const size_t idx = TRANSA ? ((size_t)gk * g.lda + gi) : ((size_t)gi * g.lda + gk);
         v = MID ? 0.5 * (g.A0[idx] + g.A1[idx]) : g.A0[idx];
       }
@@ -81,7 +90,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     for (int q = 0; q < 4; q++) {
       const int j = tid & 63, k = (tid >> 6) + 4 * q;
       const int gj = j0 + j, gk = k0 + k;
-      rb[q] = (FULL || (gj < g.N && gk < g.K)) ? g.B[(size_t)gk * g.ldb + gj] : 0.0;
+      rb[q] = (FULL || (gj < g.N && gk < klim)) ? g.B[(size_t)gk * g.ldb + gj] : 0.0;
     }
   };
   auto store_tiles = [&](int buf, const double (&ra)[AQ], const double (&rb)[4]) {
@@ -106,6 +115,21 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
   const int nk = (g.K + BK - 1) / BK;
+  if (g.accumulate) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+        if (gj >= g.N) continue;
+        const size_t chunk = (size_t)(gj / g.cw) * g.M * g.cw + (gj % g.cw);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
+          if (gi < g.M) acc[mt][nt][r] = g.C[chunk + (size_t)gi * g.cw];
+        }
+      }
+  }
   auto compute = [&](int cur) {
     const double* as = As[cur] + fk * LDAS + (BM / 2) * wm + fi;
     const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
@@ -128,17 +152,17 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     // latency).  Prologue: tile 0 -> LDS buffer 0, tile 1 -> register set 1.
     load_tiles(0, ra0, rb0);
     store_tiles(0, ra0, rb0);
-    if (nk > 1) load_tiles(BK, ra1, rb1);
+    if (nk > 1) load_tiles(k_of(1), ra1, rb1);
     __syncthreads();
     // iteration kt: loads of tile kt+2 are issued, tile kt is multiplied, tile kt+1 (in registers since the previous
     // iteration) goes to the other LDS buffer.  Unrolled by two so that the register sets are addressed statically.
     for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) load_tiles((kt + 2) * BK, ra0, rb0);
+      if (kt + 2 < nk) load_tiles(k_of(kt + 2), ra0, rb0);
       compute(0);
       if (kt + 1 < nk) store_tiles(1, ra1, rb1);
       __syncthreads();
       if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) load_tiles((kt + 3) * BK, ra1, rb1);
+      if (kt + 3 < nk) load_tiles(k_of(kt + 3), ra1, rb1);
       compute(1);
       if (kt + 2 < nk) store_tiles(0, ra0, rb0);
       __syncthreads();
@@ -150,7 +174,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) load_tiles((kt + 1) * BK, ra0, rb0);
+      if (kt + 1 < nk) load_tiles(k_of(kt + 1), ra0, rb0);
       compute(cur);
       if (kt + 1 < nk) store_tiles(cur ^ 1, ra0, rb0);
       __syncthreads();
@@ -181,7 +205,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
 //                             18 i (mod 32) runs over the even residues and the two k of a 32-lane group fill the odd ones
 //   TN (A stored  [k][i]):    As[k][BM + 16] as in k_gemm (k-major), b128 stores of 16 consecutive pairs
 //   B  (row-major [k][j]):    Bs[k][LDBS], b128 stores
-template <bool TRANSA, bool MID, int BM>
+template <bool TRANSA, bool MID, int BM, bool SEG = false>
 __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   constexpr int LDK = 18;                       // NN: doubles per tile row (16 + 2)
@@ -225,6 +249,11 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
     sb[q] = k * LDBS + 2 * j2;
   }
   const size_t astep = TRANSA ? (size_t)BK * g.lda : (size_t)BK, bstep = (size_t)BK * g.ldb;
+  // SEG (K-chunk launch of the pipelined sharded stage): after every seg_tiles k-tiles jump to the same sub-chunk of the next
+  // rank's row block
+  const int seg_skip_k = SEG ? g.seg_stride - g.seg_tiles * BK : 0;
+  const size_t askip = TRANSA ? (size_t)seg_skip_k * g.lda : (size_t)seg_skip_k, bskip = (size_t)seg_skip_k * g.ldb;
+  int seg_cnt = 0;
 
   d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
   auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {      // loads the NEXT k-tile (tiles are requested in order)
@@ -242,6 +271,15 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bstep; }
+    if (SEG) {
+      if (++seg_cnt == g.seg_tiles) {
+        seg_cnt = 0;
+#pragma unroll
+        for (int q = 0; q < AV; q++) { pA[q] += askip; if (MID) pA1[q] += askip; }
+#pragma unroll
+        for (int q = 0; q < 2; q++) pB[q] += bskip;
+      }
+    }
   };
   auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
 #pragma unroll
@@ -256,6 +294,22 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
+  if (SEG) {
+    if (g.accumulate) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+          const int gj = j0 + 32 * wn + 16 * nt + (lane & 15);
+          const size_t chunk = (size_t)(gj / g.cw) * g.M * g.cw + (gj % g.cw);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
+            acc[mt][nt][r] = g.C[chunk + (size_t)gi * g.cw];
+          }
+        }
+    }
+  }
   const int nk = g.K / BK;
   auto compute = [&](int cur) {
     const double* as = TRANSA ? As[cur] + fk * LDT + (BM / 2) * wm + fi : As[cur] + ((BM / 2) * wm + fi) * LDK + fk;
@@ -331,6 +385,7 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
 //     y_r = sum_k Aeff[r][k] x[k] ;  r_v = fwd ? -y + e : -e + y ;  same slot logic with vector buffers.
 struct StageArgs {
   int D, row0, Mp, cw, fwd, kstore, final, mid_e, has_j;
+  int sym_ok = 0;       // the caller guarantees symmetric E / J / base / slots: the symmetric-tile-pair kernel may serve (internal drivers)
   double cx, cf;
   const double* W;      // [q][Mp][cw] packed row block of the stage product
   const double* Wcol;   // [D][Mp]     column block of the stage product (== W when one rank owns everything)
@@ -452,7 +507,16 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
   const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
   auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   const bool vec = full && g.lda % 2 == 0 && g.ldb % 2 == 0 && al16(g.A0) && al16(g.A1) && al16(g.B) && !gemm_scalar_loads;
-  if (vec) launch_gemm_bm_v<BM>(transa, g, st);
+  const bool seg = g.seg_tiles > 0 || g.accumulate;
+  if (vec && seg && !g.A1) {        // K-chunk launch (no mid-point operand: the sharded driver forms it once per step)
+    GemmArgs h = g;
+    if (!h.seg_tiles) { h.seg_tiles = h.K / BK; h.seg_stride = h.K; }
+    dim3 grid(g.N / BN, g.M / BM);
+    if (transa) hipLaunchKernelGGL((k_gemm_v<true, false, BM, true>), grid, dim3(NT), 0, st, h);
+    else hipLaunchKernelGGL((k_gemm_v<false, false, BM, true>), grid, dim3(NT), 0, st, h);
+    return;
+  }
+  if (vec && !seg) launch_gemm_bm_v<BM>(transa, g, st);
   else if (full) launch_gemm_bm_f<BM, true>(transa, g, st);
   else launch_gemm_bm_f<BM, false>(transa, g, st);
 }
@@ -556,7 +620,7 @@ static const bool stage_sym_off = [] { const char* e = getenv("VGPA_STAGE_FULL")
 
 hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
   const int nvec = (a.Mp + (NT / 64) - 1) / (NT / 64);
-  if (a.Mp == a.D && a.row0 == 0 && a.cw == a.D && a.W == a.Wcol && !stage_sym_off) {
+  if (a.sym_ok && a.Mp == a.D && a.row0 == 0 && a.cw == a.D && a.W == a.Wcol && !stage_sym_off) {
     const int nt = (a.D + TS - 1) / TS;
     hipLaunchKernelGGL(k_stage_sym, dim3(nt * (nt + 1) / 2 + nvec), dim3(NT), 0, st, a);
     return hipGetLastError();
@@ -636,6 +700,7 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
   if (e != hipSuccess) return e;
   StageArgs a{};
   a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.sym_ok = 1;
   a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
   a.W = w.W; a.Wcol = w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
   a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
@@ -750,20 +815,37 @@ hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, c
 //     W[I_p, :]  = A_s[I_p, :] . X  (forward)   |   (A_s^T)[I_p, :] . Psi  (backward)         fp64-MFMA GEMM, packed
 //     Wcol       = all_to_all(W[I_p, :])  = W[:, I_p]                                          (D^2/world^2 per peer)
 //     X'[I_p, :] = stage kernel (R = -(W + Wcol^T) + Sigma ..., RK slots, the vector recursion in the same launch)
-//     X', x'     = all_gather of the row blocks: matrix and vector in ONE group (one RCCL launch)
-// Two collectives per stage, both enqueued on the rank's stream between the kernels: no host synchronisation inside a
-// sweep.  Every rank sees the complete S_{k+1} / Psi_{t-1} after the step's last gather and keeps it only if it owns
-// that grid point: the history is TIME-sharded (contiguous slices of the grid), which is the layout the time-parallel
-// energy / gradient phase wants, at no extra communication.  The collectives come through a small table of function
-// pointers (vgpa_comm): RCCL in production (sharded.cpp: dlopen'ed librccl, unique id through the C ABI), a test
-// double in the virtual-rank tests.
+//     X', x'     = the other ranks' row blocks of the next stage state
+// Two schedules for that last step:
+//   serial    (chunks = 0): ONE grouped all-gather (matrix rows + vector entries) on the compute stream -- every stage is
+//             GEMM -> all-to-all -> stage kernel -> all-gather, strictly in sequence (round 2);
+//   pipelined (chunks = C >= 1, needs send / recv in the vgpa_comm table): the row block travels as C sub-blocks of Mp / C rows
+//             on a SECOND stream (per sub-block one group of per-peer sends / receives, an event behind each), and the next
+//             stage's product runs as C K-chunk launches, launch j over sub-block j of EVERY rank's rows (k_gemm_v<.., SEG>:
+//             accumulators continued through W), each waiting only for event j.  xGMI is point to point -- all seven incoming
+//             blocks arrive at the same time, each on its own link -- so "the first rank's block first" would overlap nothing;
+//             with sub-blocks 1/C of every block is complete after 1/C of the transfer time and the product starts then.  The k
+//             order of a pipelined product depends on (world, C) only, never on arrival order: results are deterministic, and
+//             equal to the serial schedule's up to the order of the fp64 additions (tests: 1e-12).
+// Every rank sees the complete S_{k+1} / Psi_{t-1} after the step's last gather and keeps it only if it owns that grid point:
+// the history is TIME-sharded (contiguous slices of the grid), which is the layout the time-parallel energy / gradient phase
+// wants, at no extra communication.  The collectives come through a small table of function pointers (vgpa_comm): RCCL in
+// production (sharded_rccl.cpp: dlopen'ed librccl, unique id through the C ABI), a test double in the virtual-rank tests.
+//
+// Failure handling (the reference surfaces every error as an exception that ends the run, vgpa_main.py:126-142; a collective
+// program must end on EVERY rank): a failing collective callback marks the shard failed, calls the table's `abort` (RCCL:
+// ncclCommAbort) and returns VGPA_ERR_COMM; the fused sweep ends with an agreement step (one all-gather of a status word per
+// rank: device faults, a non-positive-definite S_t on ANY rank's time slice, allocation failures) so that all ranks return the
+// same code; host waits on the stream are bounded by VGPA_SHARD_OPT_TIMEOUT_MS (a peer that died is a time-out, not a hang).
+constexpr int kMaxChunks = 8;
+
 struct ShardWork {
-  double *Wp, *Wcol, *K1, *K23, *XA, *XB, *cur, *nxt, *mid, *xvA, *xvB, *vcur, *vnxt, *k1v, *k23v;
+  double *Wp, *Wcol, *K1, *K23, *XA, *XB, *cur, *nxt, *mid, *xvA, *xvB, *vcur, *vnxt, *k1v, *k23v, *agree;
 };
 
-size_t shard_workspace_doubles(int D, int Mp) {
+size_t shard_workspace_doubles(int D, int Mp, int world) {
   const size_t DD = (size_t)D * D, MD = (size_t)Mp * D;
-  return 5 * MD + 4 * DD + 4 * (size_t)D + 2 * (size_t)Mp + 16;
+  return 5 * MD + 4 * DD + 4 * (size_t)D + 2 * (size_t)Mp + 2 * (size_t)world + 16;
 }
 
 ShardWork carve_shard(double* ws, int D, int Mp) {
@@ -772,73 +854,172 @@ ShardWork carve_shard(double* ws, int D, int Mp) {
   w.Wp = ws; w.Wcol = w.Wp + MD; w.K1 = w.Wcol + MD; w.K23 = w.K1 + MD; w.mid = w.K23 + MD;
   w.XA = w.mid + MD; w.XB = w.XA + DD; w.cur = w.XB + DD; w.nxt = w.cur + DD;
   w.xvA = w.nxt + DD; w.xvB = w.xvA + D; w.vcur = w.xvB + D; w.vnxt = w.vcur + D;
-  w.k1v = w.vnxt + D; w.k23v = w.k1v + Mp;
+  w.k1v = w.vnxt + D; w.k23v = w.k1v + Mp; w.agree = w.k23v + Mp;
   return w;
 }
 
-// out[r][c] = 0.5 (a0[r][col0 + c] + a1[r][col0 + c]), r < rows, c < cols: the mid-point of a column block of A
+// out[r][c] = 0.5 (a0[r][c] + a1[r][c]), r < rows, c < cols, both operands with leading dimension ld: the mid-point of a row
+// block (forward) or of a column block (backward) of A
 __global__ void __launch_bounds__(256) k_mid_cols(const double* __restrict__ a0, const double* __restrict__ a1, double* __restrict__ out,
-                                                  int rows, int cols, int ld, int col0) {
+                                                  int rows, int cols, int ld) {
   const size_t n = (size_t)rows * cols;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const size_t r = i / cols, c = i - r * cols;
-    out[i] = 0.5 * (a0[r * ld + col0 + c] + a1[r * ld + col0 + c]);
+    out[i] = 0.5 * (a0[r * ld + c] + a1[r * ld + c]);
   }
 }
 
 struct ShardCtx {
-  int method, D, rank, world, row0, Mp;
-  double dt;
-  vgpa_comm comm;
-  hipStream_t st;
-  ShardWork w;
+  int method = 0, D = 0, rank = 0, world = 1, row0 = 0, Mp = 0;
+  double dt = 0.0;
+  vgpa_comm comm{};
+  hipStream_t st = nullptr;                 // compute stream (also carries the all-to-all)
+  hipStream_t cs = nullptr;                 // communication stream of the pipelined gather
+  ShardWork w{};
   const double* mid_a0 = nullptr; const double* mid_a1 = nullptr; bool mid_fwd = false;
+  int chunks = 0;                           // sub-blocks of the pipelined gather (0: serial schedule)
+  hipEvent_t ev_stage = nullptr, ev_tail = nullptr, ev_chunk[kMaxChunks] = {};
+  const double* pending = nullptr;          // stage buffer whose remote rows are still arriving on cs (ev_chunk[j] per sub-block)
+  bool cs_dirty = false;                    // work enqueued on cs that the compute stream has not joined yet
+  bool failed = false;                      // a collective failed: the communicator is gone (VGPA_ERR_COMM from now on)
+  int64_t timeout_ms = 600000;              // bound of every host wait on the streams
 };
 
-#define SH_COMM(expr) do { if ((expr) != 0) return hipErrorUnknown; } while (0)
+static void comm_failed(ShardCtx& c) {
+  if (!c.failed && c.comm.abort) (void)c.comm.abort(c.comm.user);
+  c.failed = true;
+}
+#define SH_COMM(c, expr) do { if ((expr) != 0) { comm_failed(c); return hipErrorUnknown; } } while (0)
 
-static hipError_t shard_stage(ShardCtx& c, const StageSpec& s) {
+static bool pipelined(const ShardCtx& c) { return c.world > 1 && c.chunks > 0; }
+
+// the largest number of sub-blocks <= want that the K-chunk product can use: whole k-tiles per sub-block
+static int usable_chunks(const ShardCtx& c, int want) {
+  if (c.world < 2 || !c.comm.send || !c.comm.recv || !c.comm.group_begin || !c.comm.group_end) return 0;
+  if (want > kMaxChunks) want = kMaxChunks;
+  for (int n = want; n >= 1; n--)
+    if (c.Mp % (n * BK) == 0) return n;
+  return 0;
+}
+
+// the compute stream waits for everything enqueued on the communication stream
+static hipError_t shard_join(ShardCtx& c) {
+  if (c.cs_dirty) {
+    LD_TRY(hipEventRecord(c.ev_tail, c.cs));
+    LD_TRY(hipStreamWaitEvent(c.st, c.ev_tail, 0));
+  }
+  c.cs_dirty = false; c.pending = nullptr;
+  return hipSuccess;
+}
+
+// host wait on the compute stream, bounded: a peer that never arrives must not hang this rank for ever
+static int shard_wait(ShardCtx& c) {
+  if (c.timeout_ms <= 0) return hipStreamSynchronize(c.st) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c.st);
+    if (e == hipSuccess) return VGPA_OK;
+    if (e != hipErrorNotReady) return VGPA_ERR_DEVICE;
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > c.timeout_ms) { comm_failed(c); return VGPA_ERR_COMM; }
+    if (ms > 2) std::this_thread::sleep_for(std::chrono::microseconds(ms > 50 ? 500 : 50));
+  }
+}
+
+// One stage on this rank's row block; every pointer already addresses the rank's part.
+struct ShardStage {
+  bool fwd;
+  const double *Ag0, *Ag1; int ldag;     // product operand: rows I_p of A_s [Mp][ldag] (fwd) / columns I_p of A_s [D][ldag] (bwd); Ag1: mid-point partner
+  const double *Av0, *Av1; int ldav;     // vector recursion: rows I_p of A_s [Mp][ldav]
+  const double* X; const double* xv;     // complete stage state [D][D] / [D]
+  const double *E0, *E1;                 // rows I_p of Sigma / dEsde_dS(stage)   [Mp][D]
+  const double *e0, *e1;                 // entries I_p of b / dEsde_dm(stage)
+  const double* J; const double* jv;     // rows / entries I_p of the jump, or nullptr
+  const double* base; const double* vbase;   // complete buffers of S_k / Psi_t, m_k / lam_t (the row block is taken here)
+  double* out; double* vout;             // complete buffers of the next stage state
+  int kstore, final_mode; double cx, cf;
+};
+
+static hipError_t shard_gather(ShardCtx& c, double* out, double* vout) {
+  const int D = c.D, Mp = c.Mp, row0 = c.row0, world = c.world, rank = c.rank;
+  if (!pipelined(c)) {      // complete the next stage state: row blocks of the matrix and of the vector, one group
+    if (c.comm.group_begin) SH_COMM(c, c.comm.group_begin(c.comm.user));
+    SH_COMM(c, c.comm.all_gather(c.comm.user, out + (size_t)row0 * D, out, (uint64_t)Mp * D, c.st));
+    SH_COMM(c, c.comm.all_gather(c.comm.user, vout + row0, vout, (uint64_t)Mp, c.st));
+    if (c.comm.group_end) SH_COMM(c, c.comm.group_end(c.comm.user));
+    return hipSuccess;
+  }
+  LD_TRY(hipEventRecord(c.ev_stage, c.st));
+  LD_TRY(hipStreamWaitEvent(c.cs, c.ev_stage, 0));
+  const int sub = Mp / c.chunks;
+  for (int j = 0; j < c.chunks; j++) {
+    SH_COMM(c, c.comm.group_begin(c.comm.user));
+    for (int d = 1; d < world; d++) {      // rotated peer order: every rank's d-th send meets its peer's d-th receive
+      const int to = (rank + d) % world, from = (rank - d + world) % world;
+      SH_COMM(c, c.comm.send(c.comm.user, out + ((size_t)row0 + (size_t)j * sub) * D, (uint64_t)sub * D, to, c.cs));
+      SH_COMM(c, c.comm.recv(c.comm.user, out + ((size_t)from * Mp + (size_t)j * sub) * D, (uint64_t)sub * D, from, c.cs));
+      if (j == 0) {                        // the vector travels with the first sub-block
+        SH_COMM(c, c.comm.send(c.comm.user, vout + row0, (uint64_t)Mp, to, c.cs));
+        SH_COMM(c, c.comm.recv(c.comm.user, vout + (size_t)from * Mp, (uint64_t)Mp, from, c.cs));
+      }
+    }
+    SH_COMM(c, c.comm.group_end(c.comm.user));
+    LD_TRY(hipEventRecord(c.ev_chunk[j], c.cs));
+  }
+  c.pending = out; c.cs_dirty = true;
+  return hipSuccess;
+}
+
+static hipError_t shard_stage(ShardCtx& c, const ShardStage& s) {
   const int D = c.D, Mp = c.Mp, row0 = c.row0;
   const ShardWork& w = c.w;
   GemmArgs g{};
   g.M = Mp; g.N = D; g.K = D; g.B = s.X; g.ldb = D; g.C = w.Wp; g.cw = Mp; g.A1 = nullptr;
-  if (s.Am1) {      // mid-point operand of this rank's slab, formed once per step
-    if (c.mid_a0 != s.Am0 || c.mid_a1 != s.Am1 || c.mid_fwd != s.fwd) {
+  if (s.Ag1) {      // mid-point operand of this rank's slab, formed once per step
+    if (c.mid_a0 != s.Ag0 || c.mid_a1 != s.Ag1 || c.mid_fwd != s.fwd) {
       const size_t n = (size_t)Mp * D;
       const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-      if (s.fwd) hipLaunchKernelGGL(k_mid, dim3(blocks), dim3(256), 0, c.st, s.Am0 + (size_t)row0 * D, s.Am1 + (size_t)row0 * D, w.mid, n);
-      else hipLaunchKernelGGL(k_mid_cols, dim3(blocks), dim3(256), 0, c.st, s.Am0, s.Am1, w.mid, D, Mp, D, row0);
-      c.mid_a0 = s.Am0; c.mid_a1 = s.Am1; c.mid_fwd = s.fwd;
+      if (s.fwd) hipLaunchKernelGGL(k_mid_cols, dim3(blocks), dim3(256), 0, c.st, s.Ag0, s.Ag1, w.mid, Mp, D, s.ldag);
+      else hipLaunchKernelGGL(k_mid_cols, dim3(blocks), dim3(256), 0, c.st, s.Ag0, s.Ag1, w.mid, D, Mp, s.ldag);
+      c.mid_a0 = s.Ag0; c.mid_a1 = s.Ag1; c.mid_fwd = s.fwd;
     }
     g.A0 = w.mid; g.lda = s.fwd ? D : Mp;
   } else {
-    g.A0 = s.fwd ? s.Am0 + (size_t)row0 * D : s.Am0 + row0;     // rows I_p of A / columns I_p of A (rows of A^T)
-    g.lda = D;
+    g.A0 = s.Ag0; g.lda = s.ldag;
   }
-  LD_TRY(launch_gemm(!s.fwd, g, c.st));
+  if (pipelined(c)) {
+    // K-chunk launches: launch j multiplies sub-block j of every rank's rows of X and waits only for that sub-block's event
+    const int sub = Mp / c.chunks;
+    for (int j = 0; j < c.chunks; j++) {
+      if (c.pending == s.X) LD_TRY(hipStreamWaitEvent(c.st, c.ev_chunk[j], 0));
+      GemmArgs h = g;
+      h.K = c.world * sub; h.seg_tiles = sub / BK; h.seg_stride = Mp; h.accumulate = j > 0;
+      h.A0 = g.A0 + (s.fwd ? (size_t)j * sub : (size_t)j * sub * g.lda);     // k runs along A's columns (NN) / rows (TN)
+      h.B = s.X + (size_t)j * sub * D;
+      LD_TRY(launch_gemm(!s.fwd, h, c.st));
+    }
+    if (c.pending == s.X) c.pending = nullptr;      // every sub-block's event has been waited for
+  } else {
+    LD_TRY(launch_gemm(!s.fwd, g, c.st));
+  }
   const double* wcol = w.Wp;
   if (c.world > 1) {
-    SH_COMM(c.comm.all_to_all(c.comm.user, w.Wp, w.Wcol, (uint64_t)Mp * Mp, c.st));
+    SH_COMM(c, c.comm.all_to_all(c.comm.user, w.Wp, w.Wcol, (uint64_t)Mp * Mp, c.st));
     wcol = w.Wcol;
   }
   StageArgs a{};
-  a.D = D; a.row0 = row0; a.Mp = Mp; a.cw = Mp; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.D = D; a.row0 = 0; a.Mp = Mp; a.cw = Mp; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.sym_ok = 1;
   a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
   a.W = w.Wp; a.Wcol = wcol;
-  a.E0 = s.E0 + (size_t)row0 * D; a.E1 = s.E1 ? s.E1 + (size_t)row0 * D : nullptr;
-  a.J = s.J ? s.J + (size_t)row0 * D : nullptr;
+  a.E0 = s.E0; a.E1 = s.E1; a.J = s.J;
   a.base = s.base + (size_t)row0 * D; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out + (size_t)row0 * D;
-  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
-  a.e0 = s.e0 + row0; a.e1 = s.e1 ? s.e1 + row0 : nullptr; a.mid_ev = s.e1 != nullptr;
-  a.jv = s.jv ? s.jv + row0 : nullptr; a.vbase = s.vbase + row0;
+  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = s.ldav; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
+  a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr;
+  a.jv = s.jv; a.vbase = s.vbase + row0;
   a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout + row0;
   LD_TRY(launch_stage(a, c.st));
-  if (c.world > 1) {      // complete the next stage state: row blocks of the matrix and of the vector, one group
-    if (c.comm.group_begin) SH_COMM(c.comm.group_begin(c.comm.user));
-    SH_COMM(c.comm.all_gather(c.comm.user, s.out + (size_t)row0 * D, s.out, (uint64_t)Mp * D, c.st));
-    SH_COMM(c.comm.all_gather(c.comm.user, s.vout + row0, s.vout, (uint64_t)Mp, c.st));
-    if (c.comm.group_end) SH_COMM(c.comm.group_end(c.comm.user));
-  }
+  if (c.world > 1) LD_TRY(shard_gather(c, s.out, s.vout));
   return hipSuccess;
 }
 
@@ -848,129 +1029,209 @@ static void time_slice(int Np, int rank, int world, int* lo, int* hi) {
   *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
+// Where a rank finds ITS parts of the time-indexed linear term A_t: replicated input (views into the caller's [Np][D][D]) or
+// the row / column blocks a time -> block exchange has delivered (the memory-sharded sweep).
+struct AView {
+  const double* rows; size_t rows_t; int rows_ld;     // rows I_p of A_t:    rows + t * rows_t, [Mp][rows_ld]
+  const double* cols; size_t cols_t; int cols_ld;     // columns I_p of A_t: cols + t * cols_t, [D][cols_ld]
+};
+static AView aview_replicated(const ShardCtx& c, const double* A) {
+  const size_t DD = (size_t)c.D * c.D;
+  return AView{A + (size_t)c.row0 * c.D, DD, c.D, A + c.row0, DD, c.D};
+}
+static AView aview_blocks(const ShardCtx& c, const double* a_rows, const double* a_cols) {
+  const size_t MD = (size_t)c.Mp * c.D;
+  return AView{a_rows, MD, c.D, a_cols, MD, c.Mp};
+}
+
+// a copy of a complete stage buffer into the rank's time slice: on the stream the buffer completes on
+static hipError_t shard_keep(ShardCtx& c, const double* M, const double* v, double* M_own, double* v_own) {
+  const size_t DD = (size_t)c.D * c.D;
+  hipStream_t ks = c.st;
+  if (pipelined(c) && c.pending == M) { ks = c.cs; c.cs_dirty = true; }
+  LD_TRY(hipMemcpyAsync(M_own, M, DD * sizeof(double), hipMemcpyDeviceToDevice, ks));
+  return hipMemcpyAsync(v_own, v, c.D * sizeof(double), hipMemcpyDeviceToDevice, ks);
+}
+
 // (m_t, S_t): every rank steps the whole grid, keeps the grid points [t_lo, t_hi) it owns in m_own / S_own.
-hipError_t shard_solve_fwd(ShardCtx& c, int Np, const double* A, const double* b, const double* m0, const double* S0,
+// b: complete [Np][D].
+hipError_t shard_solve_fwd(ShardCtx& c, int Np, const AView& av, const double* b, const double* m0, const double* S0,
                            const double* Sigma, double* m_own, double* S_own) {
-  const int D = c.D;
+  const int D = c.D, row0 = c.row0;
   const size_t DD = (size_t)D * D;
   const double dt = c.dt, h = 0.5 * dt;
   ShardWork& w = c.w;
   int lo, hi;
   time_slice(Np, c.rank, c.world, &lo, &hi);
   c.mid_a0 = c.mid_a1 = nullptr;
+  LD_TRY(shard_join(c));
   LD_TRY(hipMemcpyAsync(w.cur, S0, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
   LD_TRY(hipMemcpyAsync(w.vcur, m0, D * sizeof(double), hipMemcpyDeviceToDevice, c.st));
   auto keep = [&](int t, const double* S, const double* m) -> hipError_t {
     if (t < lo || t >= hi) return hipSuccess;
-    LD_TRY(hipMemcpyAsync(S_own + (size_t)(t - lo) * DD, S, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
-    return hipMemcpyAsync(m_own + (size_t)(t - lo) * D, m, D * sizeof(double), hipMemcpyDeviceToDevice, c.st);
+    return shard_keep(c, S, m, S_own + (size_t)(t - lo) * DD, m_own + (size_t)(t - lo) * D);
   };
   LD_TRY(keep(0, w.cur, w.vcur));
   for (int k = 0; k < Np - 1; k++) {
-    const double *Ak = A + k * DD, *Ak1 = Ak + DD, *bk = b + (size_t)k * D, *bk1 = bk + D;
+    const double *Ar = av.rows + k * av.rows_t, *Ar1 = Ar + av.rows_t;
+    const double *bk = b + (size_t)k * D + row0, *bk1 = bk + D;
     const double *Sk = w.cur, *mk = w.vcur;
     double *Sn = w.nxt, *mn = w.vnxt;
-    StageSpec s{};
-    s.fwd = true; s.E0 = Sigma; s.base = Sk; s.vbase = mk;
-    auto set = [&](const double* am0, const double* am1, const double* av0, const double* av1, const double* X,
+    ShardStage s{};
+    s.fwd = true; s.E0 = Sigma + (size_t)row0 * D; s.base = Sk; s.vbase = mk; s.ldag = av.rows_ld; s.ldav = av.rows_ld;
+    auto set = [&](const double* ag0, const double* ag1, int ldag, const double* av0, const double* av1, const double* X,
                    const double* xv, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
                    double cx, double cf) {
-      s.Am0 = am0; s.Am1 = am1; s.Av0 = av0; s.Av1 = av1; s.X = X; s.xv = xv; s.e0 = e0; s.e1 = e1; s.out = out;
+      s.Ag0 = ag0; s.Ag1 = ag1; s.ldag = ldag; s.Av0 = av0; s.Av1 = av1; s.X = X; s.xv = xv; s.e0 = e0; s.e1 = e1; s.out = out;
       s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
     };
+    const int la = av.rows_ld;
     if (c.method == VGPA_ODE_EULER) {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
+      set(Ar, nullptr, la, Ar, nullptr, Sk, mk, bk, nullptr, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
     } else if (c.method == VGPA_ODE_HEUN) {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
-      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(shard_stage(c, s));
+      set(Ar, nullptr, la, Ar, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ar1, nullptr, la, Ar1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 2, 0.0, h); LD_TRY(shard_stage(c, s));
     } else if (c.method == VGPA_ODE_RK2) {
-      set(Sk, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(shard_stage(c, s));
-      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
+      // covariance predictor: S_k stands in for A_k (reference quirk, runge_kutta2.py:96); mean predictor: A_k
+      set(Sk + (size_t)row0 * D, nullptr, D, Ar, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 0, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ar, Ar1, la, Ar, Ar1, w.XA, w.xvA, bk1, bk, Sn, mn, 0, 1, 0.0, dt); LD_TRY(shard_stage(c, s));
     } else {
-      set(Ak, nullptr, Ak, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(shard_stage(c, s));
-      set(Ak, Ak1, Ak, Ak1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(shard_stage(c, s));
-      set(Ak, Ak1, Ak, Ak1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
-      set(Ak1, nullptr, Ak1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(shard_stage(c, s));
+      set(Ar, nullptr, la, Ar, nullptr, Sk, mk, bk, nullptr, w.XA, w.xvA, 1, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ar, Ar1, la, Ar, Ar1, w.XA, w.xvA, bk1, bk, w.XB, w.xvB, 2, 0, h, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ar, Ar1, la, Ar, Ar1, w.XB, w.xvB, bk1, bk, w.XA, w.xvA, 3, 0, dt, 0.0); LD_TRY(shard_stage(c, s));
+      set(Ar1, nullptr, la, Ar1, nullptr, w.XA, w.xvA, bk1, nullptr, Sn, mn, 0, 3, 0.0, dt); LD_TRY(shard_stage(c, s));
     }
     LD_TRY(keep(k + 1, Sn, mn));
     double* t1 = w.cur; w.cur = w.nxt; w.nxt = t1;
     double* t2 = w.vcur; w.vcur = w.vnxt; w.vnxt = t2;
   }
-  return hipSuccess;
+  return shard_join(c);
 }
 
-// Inputs of the backward recursion.  dEsde_dm / dEsde_dS either as plain [Np] arrays (operator level) or as the all-gathered
-// time slices of the fused sweep, [world][pad_len] (slot() maps a grid point to its place); jumps either as dense [Np]
-// arrays (operator level; zero rows off the observations) or sparse: observation index per grid point (host), one
-// vector per observation, one constant matrix.
+// Inputs of the backward recursion, already reduced to what THIS rank reads: rows I_p of dEsde_dS[t] (a view into the
+// replicated operator-level array, or the row blocks the time -> row exchange of the fused sweep delivered), the complete
+// dEsde_dm [Np][D], and the jumps either dense (operator level; zero rows off the observations) or sparse: observation index
+// per grid point (host), one vector per observation, one constant matrix.
 struct BwdIn {
-  const double* gm = nullptr; const double* gs = nullptr;
-  int pad_len = 0, world = 1, Np = 0;
+  const double* gm = nullptr;                                       // [Np][D]
+  const double* g_rows = nullptr; size_t g_rows_t = 0;              // rows I_p of dEsde_dS[t]: g_rows + t * g_rows_t, [Mp][D]
   const double* jm_dense = nullptr; const double* js_dense = nullptr;
   const int32_t* obs_idx = nullptr; const double* jm_sparse = nullptr; const double* js_const = nullptr;
-  size_t slot(int t) const {
-    if (!pad_len) return (size_t)t;
-    const int base = Np / world, rem = Np % world;
-    const int q = (t < rem * (base + 1)) ? t / (base + 1) : rem + (base ? (t - rem * (base + 1)) / base : 0);
-    const int lo = q * base + (q < rem ? q : rem);
-    return (size_t)q * pad_len + (t - lo);
-  }
 };
 
 // (lam_t, Psi_t); same ownership of the grid as the forward recursion.
-hipError_t shard_solve_bwd(ShardCtx& c, int Np, const double* A, const BwdIn& in, double* lam_own, double* psi_own) {
-  const int D = c.D;
+hipError_t shard_solve_bwd(ShardCtx& c, int Np, const AView& av, const BwdIn& in, double* lam_own, double* psi_own) {
+  const int D = c.D, row0 = c.row0;
   const size_t DD = (size_t)D * D;
   const double dt = c.dt, h = 0.5 * dt;
   ShardWork& w = c.w;
   int lo, hi;
   time_slice(Np, c.rank, c.world, &lo, &hi);
   c.mid_a0 = c.mid_a1 = nullptr;
+  LD_TRY(shard_join(c));
   LD_TRY(hipMemsetAsync(w.cur, 0, DD * sizeof(double), c.st));
   LD_TRY(hipMemsetAsync(w.vcur, 0, D * sizeof(double), c.st));
   auto keep = [&](int t, const double* P, const double* l) -> hipError_t {
     if (t < lo || t >= hi) return hipSuccess;
-    LD_TRY(hipMemcpyAsync(psi_own + (size_t)(t - lo) * DD, P, DD * sizeof(double), hipMemcpyDeviceToDevice, c.st));
-    return hipMemcpyAsync(lam_own + (size_t)(t - lo) * D, l, D * sizeof(double), hipMemcpyDeviceToDevice, c.st);
+    return shard_keep(c, P, l, psi_own + (size_t)(t - lo) * DD, lam_own + (size_t)(t - lo) * D);
   };
   LD_TRY(keep(Np - 1, w.cur, w.vcur));
   for (int t = Np - 1; t > 0; t--) {
-    const double *At = A + t * DD, *Am = A + (t - 1) * DD, *Gt = in.gs + in.slot(t) * DD, *Gm = in.gs + in.slot(t - 1) * DD;
-    const double *gt = in.gm + in.slot(t) * D, *gmm = in.gm + in.slot(t - 1) * D;
+    const double *Act = av.cols + t * av.cols_t, *Acm = av.cols + (t - 1) * av.cols_t;      // product operand: columns I_p
+    const double *Art = av.rows + t * av.rows_t, *Arm = av.rows + (t - 1) * av.rows_t;      // vector recursion: rows I_p (Q3: A.lam)
+    const double *Gt = in.g_rows + t * in.g_rows_t, *Gm = in.g_rows + (t - 1) * in.g_rows_t;
+    const double *gt = in.gm + (size_t)t * D + row0, *gmm = in.gm + (size_t)(t - 1) * D + row0;
     const int nobs = in.obs_idx ? in.obs_idx[t - 1] : 0;        // sparse jumps: only behind a step that ends at an observation
     const bool has_jump = in.obs_idx ? nobs >= 0 : true;
-    const double* Jn = in.obs_idx ? in.js_const : in.js_dense + (size_t)(t - 1) * DD;
-    const double* jn = in.obs_idx ? in.jm_sparse + (size_t)(nobs >= 0 ? nobs : 0) * D : in.jm_dense + (size_t)(t - 1) * D;
+    const double* Jn = (in.obs_idx ? in.js_const : in.js_dense + (size_t)(t - 1) * DD) + (size_t)row0 * D;
+    const double* jn = (in.obs_idx ? in.jm_sparse + (size_t)(nobs >= 0 ? nobs : 0) * D : in.jm_dense + (size_t)(t - 1) * D) + row0;
     const double *Pt = w.cur, *lt = w.vcur;
     double *Pn = w.nxt, *ln = w.vnxt;
-    StageSpec s{};
-    s.fwd = false; s.base = Pt; s.vbase = lt;
-    auto set = [&](const double* a0, const double* a1, const double* X, const double* xv, const double* E0,
-                   const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks, int fin,
-                   double cx, double cf, bool jump) {
-      s.Am0 = a0; s.Am1 = a1; s.Av0 = a0; s.Av1 = a1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
+    ShardStage s{};
+    s.fwd = false; s.base = Pt; s.vbase = lt; s.ldag = av.cols_ld; s.ldav = av.rows_ld;
+    auto set = [&](const double* ag0, const double* ag1, const double* av0, const double* av1, const double* X, const double* xv,
+                   const double* E0, const double* E1, const double* e0, const double* e1, double* out, double* vout, int ks,
+                   int fin, double cx, double cf, bool jump) {
+      s.Ag0 = ag0; s.Ag1 = ag1; s.Av0 = av0; s.Av1 = av1; s.X = X; s.xv = xv; s.E0 = E0; s.E1 = E1; s.e0 = e0; s.e1 = e1;
       s.out = out; s.vout = vout; s.kstore = ks; s.final_mode = fin; s.cx = cx; s.cf = cf;
       s.J = (jump && has_jump) ? Jn : nullptr; s.jv = (jump && has_jump) ? jn : nullptr;
     };
     if (c.method == VGPA_ODE_EULER) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+      set(Act, nullptr, Art, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
     } else if (c.method == VGPA_ODE_HEUN) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
-      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(shard_stage(c, s));
+      set(Act, nullptr, Art, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Acm, nullptr, Arm, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 2, 0.0, h, true); LD_TRY(shard_stage(c, s));
     } else if (c.method == VGPA_ODE_RK2) {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
-      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+      set(Act, nullptr, Art, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 0, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Acm, Act, Arm, Art, w.XA, w.xvA, Gt, Gm, gt, gmm, Pn, ln, 0, 1, 0.0, dt, true); LD_TRY(shard_stage(c, s));
     } else {
-      set(At, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
-      set(Am, At, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
-      set(Am, At, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
-      set(Am, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(shard_stage(c, s));
+      set(Act, nullptr, Art, nullptr, Pt, lt, Gt, nullptr, gt, nullptr, w.XA, w.xvA, 1, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Acm, Act, Arm, Art, w.XA, w.xvA, Gt, Gm, gt, gmm, w.XB, w.xvB, 2, 0, h, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Acm, Act, Arm, Art, w.XB, w.xvB, Gt, Gm, gt, gmm, w.XA, w.xvA, 3, 0, dt, 0.0, false); LD_TRY(shard_stage(c, s));
+      set(Acm, nullptr, Arm, nullptr, w.XA, w.xvA, Gm, nullptr, gmm, nullptr, Pn, ln, 0, 3, 0.0, dt, true); LD_TRY(shard_stage(c, s));
     }
     LD_TRY(keep(t - 1, Pn, ln));
     double* t1 = w.cur; w.cur = w.nxt; w.nxt = t1;
     double* t2 = w.vcur; w.vcur = w.vnxt; w.vnxt = t2;
   }
-  return hipSuccess;
+  return shard_join(c);
+}
+
+// ---- time -> row / column block exchange ------------------------------------------------------------------------------------
+// A time-sharded array (rank q holds the D x D matrices of its grid points) becomes a BLOCK-sharded one (rank p holds rows I_p --
+// mode 0 -- or columns I_p -- mode 1 -- of EVERY grid point): what the row-sharded recursions read of dEsde_dS (rows), of A_t
+// (rows forward, columns backward).  Per batch of T own grid points: pack [peer][i][Mp * D] -> ONE all-to-all -> the received
+// pieces are contiguous runs of the destination.  1/world of the bytes of an all-gather, and no rank ever holds a complete
+// (Np, D, D) array.
+__global__ void __launch_bounds__(256) k_xpack(int mode, int D, int Mp, int T, int n_valid, const double* __restrict__ src,
+                                               double* __restrict__ dst) {
+  const size_t DD = (size_t)D * D, MD = (size_t)Mp * D;
+  const size_t total = (size_t)n_valid * DD;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t i = e / DD, rem = e - i * DD;
+    const int r = (int)(rem / D), col = (int)(rem - (size_t)r * D);
+    size_t o;
+    if (mode == 0) { const int q = r / Mp; o = ((size_t)q * T + i) * MD + (size_t)(r - q * Mp) * D + col; }
+    else { const int q = col / Mp; o = ((size_t)q * T + i) * MD + (size_t)r * Mp + (col - q * Mp); }
+    dst[o] = src[e];
+  }
+}
+
+static int exchange_batch(int D, double budget_bytes, int pad) {
+  const double per = 2.0 * 8.0 * (double)D * (double)D;          // send + receive staging per grid point of a batch
+  int T = (int)(budget_bytes / per);
+  if (T < 1) T = 1;
+  return T < pad ? T : (pad > 0 ? pad : 1);
+}
+
+// src_own [n_own][D][D] -> dst [Np][Mp][D] (mode 0) / [Np][D][Mp] (mode 1); xs / xr: staging of T * D * D doubles each
+static hipError_t exchange_time_to_blocks(ShardCtx& c, int Np, int mode, const double* src_own, double* dst, double* xs, double* xr,
+                                          int T) {
+  const int D = c.D, Mp = c.Mp, world = c.world;
+  const size_t DD = (size_t)D * D, MD = (size_t)Mp * D;
+  int lo, hi;
+  time_slice(Np, c.rank, world, &lo, &hi);
+  const int n_own = hi - lo, pad = (Np + world - 1) / world;
+  for (int t0 = 0; t0 < pad; t0 += T) {
+    const int n_mine = n_own - t0 < 0 ? 0 : (n_own - t0 < T ? n_own - t0 : T);
+    if (n_mine > 0) {
+      const size_t total = (size_t)n_mine * DD;
+      const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+      double* out = world > 1 ? xs : dst + (size_t)(lo + t0) * MD;      // one rank: the packed layout IS the destination
+      hipLaunchKernelGGL(k_xpack, dim3(blocks), dim3(256), 0, c.st, mode, D, Mp, world > 1 ? T : n_mine, n_mine, src_own + (size_t)t0 * DD, out);
+    }
+    if (world == 1) continue;
+    SH_COMM(c, c.comm.all_to_all(c.comm.user, xs, xr, (uint64_t)T * MD, c.st));
+    for (int q = 0; q < world; q++) {
+      int qlo, qhi;
+      time_slice(Np, q, world, &qlo, &qhi);
+      const int n_q = (qhi - qlo) - t0 < 0 ? 0 : ((qhi - qlo) - t0 < T ? (qhi - qlo) - t0 : T);
+      if (n_q > 0)
+        LD_TRY(hipMemcpyAsync(dst + (size_t)(qlo + t0) * MD, xr + (size_t)q * T * MD, (size_t)n_q * MD * sizeof(double),
+                              hipMemcpyDeviceToDevice, c.st));
+    }
+  }
+  return hipGetLastError();
 }
 
 // ---- the fused sweep of ONE Lorenz-96 problem on the row-sharded recursion -----------------------------------------------
@@ -1023,14 +1284,15 @@ __global__ void __launch_bounds__(256) k_shard_obs_sum(int D, int M, int world, 
   }
 }
 
-// e_t of the whole grid out of the gathered slices
-__global__ void __launch_bounds__(256) k_shard_unpad(int Np, int world, int pad_len, const double* __restrict__ padded, double* __restrict__ full) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= Np) return;
+// [world][pad_len][W] gathered time slices -> [Np][W]
+__global__ void __launch_bounds__(256) k_shard_unpad(int Np, int W, int world, int pad_len, const double* __restrict__ padded, double* __restrict__ full) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)Np * W) return;
+  const int t = (int)(e / W), i = (int)(e - (size_t)t * W);
   const int base = Np / world, rem = Np % world;
   const int q = (t < rem * (base + 1)) ? t / (base + 1) : rem + (base ? (t - rem * (base + 1)) / base : 0);
   const int lo = q * base + (q < rem ? q : rem);
-  full[t] = padded[(size_t)q * pad_len + (t - lo)];
+  full[e] = padded[((size_t)q * pad_len + (t - lo)) * W + i];
 }
 
 __global__ void k_diag_half(int D, const double* __restrict__ rinv, double* __restrict__ jsc) {
@@ -1038,14 +1300,45 @@ __global__ void k_diag_half(int D, const double* __restrict__ rinv, double* __re
   if (i < D) jsc[(size_t)i * D + i] = 0.5 * rinv[i];
 }
 
+// this rank's word of the agreement step: the larger of the host's local code and the device status (bit 0: S_t not PD)
+__global__ void k_shard_status(const int32_t* __restrict__ status, double local_code, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double dev = (status && (status[0] & 1)) ? 3.0 : 0.0;       // 3 = -VGPA_ERR_NOT_PD
+    out[0] = dev > local_code ? dev : local_code;
+  }
+}
+
+// Collective: every rank contributes -code (0 = fine), all receive the largest.  Synchronises the compute stream.
+static int shard_agree(ShardCtx& c, const int32_t* status_dev, int local_code) {
+  double* mine = c.w.agree + c.rank;
+  if (shard_join(c) != hipSuccess) return VGPA_ERR_DEVICE;
+  hipLaunchKernelGGL(k_shard_status, dim3(1), dim3(64), 0, c.st, status_dev, (double)(-local_code), mine);
+  if (c.world > 1) {
+    if (c.failed) return VGPA_ERR_COMM;
+    if (c.comm.all_gather(c.comm.user, mine, c.w.agree, 1, c.st) != 0) { comm_failed(c); return VGPA_ERR_COMM; }
+  }
+  std::vector<double> host((size_t)c.world, 0.0);
+  if (hipMemcpyAsync(host.data(), c.w.agree, sizeof(double) * c.world, hipMemcpyDeviceToHost, c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  const int rc = shard_wait(c);
+  if (rc != VGPA_OK) return rc;
+  double worst = 0.0;
+  for (double v : host) worst = v > worst ? v : worst;
+  return -(int)worst;
+}
+
 struct SweepBuffers {       // device memory of the fused sweep, allocated on first use
-  double *m_own = nullptr, *S_own = nullptr, *lam_own = nullptr, *psi_own = nullptr, *Ef_own = nullptr;
-  double *gm_all = nullptr, *gs_all = nullptr, *et_all = nullptr, *et_full = nullptr, *obuf = nullptr, *jm = nullptr, *jsc = nullptr;
+  double *m_own = nullptr, *S_own = nullptr, *lam_own = nullptr, *Ef_own = nullptr;
+  double *gs_own = nullptr;  // dEsde_dS of the own grid points; dead after the time -> row exchange: Psi of the own grid points lives there
+  double *g_rows = nullptr;  // [Np][Mp][D] rows I_p of dEsde_dS of every grid point
+  double *gm_all = nullptr, *gm_full = nullptr, *et_all = nullptr, *et_full = nullptr, *obuf = nullptr, *jm = nullptr, *jsc = nullptr;
+  double *xs = nullptr, *xr = nullptr;      // staging of the exchanges
+  double *a_rows = nullptr, *a_cols = nullptr, *b_all = nullptr, *b_full = nullptr;   // memory-sharded x only
   double *scal = nullptr;   // eobs, esde, f
   double* lde_ws = nullptr;
   int64_t* obs_t = nullptr;
   int32_t* status = nullptr;
-  int lde_nb = 0, M = 0;
+  int lde_nb = 0, M = -1, xT = 1;
+  bool sharded_x = false;
 };
 
 struct SweepProblem {
@@ -1054,53 +1347,87 @@ struct SweepProblem {
   int M; const int64_t* obs_t_host;
 };
 
-// fwd (row-sharded) -> observation terms + E_sde terms of the own grid points -> all-gather -> bwd (row-sharded) -> gradient
-// of the own grid points -> F.  Everything is enqueued on the shard's stream; the caller synchronises.
-hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem& p, const double* x, const std::vector<int32_t>& obs_idx,
-                       double* gA_own, double* gB_own) {
+// forward (row-sharded) -> observation terms + E_sde terms of the own grid points -> time -> row exchange of dEsde_dS ->
+// backward (row-sharded) -> gradient of the own grid points -> F.  x either replicated (x_full = [A | b] of the whole grid) or
+// memory-sharded (a_own / b_own: the own grid points only; rows and columns of A_t reach the recursions through two more
+// exchanges).  Everything is enqueued on the shard's streams; the caller runs the agreement step.
+hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem& p, const double* x_full, const double* a_own,
+                       const double* b_own, const std::vector<int32_t>& obs_idx, double* gA_own, double* gB_own) {
   const int D = c.D, world = c.world;
   const size_t DD = (size_t)D * D;
   int lo, hi;
   time_slice(Np, c.rank, world, &lo, &hi);
   const int n_own = hi - lo, pad = (Np + world - 1) / world;
-  const double* A = x;
-  const double* b = x + (size_t)Np * DD;
   hipStream_t st = c.st;
+  auto unpad = [&](int W, const double* padded, double* full) {
+    const size_t n = (size_t)Np * W;
+    hipLaunchKernelGGL(k_shard_unpad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Np, W, world, pad, padded, full);
+  };
   LD_TRY(hipMemsetAsync(B.status, 0, sizeof(int32_t), st));
-  LD_TRY(shard_solve_fwd(c, Np, A, b, p.m0, p.S0, p.Sigma, B.m_own, B.S_own));
+  AView av;
+  const double* b_full;
+  if (x_full) {
+    av = aview_replicated(c, x_full);
+    b_full = x_full + (size_t)Np * DD;
+    a_own = x_full + (size_t)lo * DD;
+    b_own = b_full + (size_t)lo * D;
+  } else if (world == 1) {
+    av = aview_replicated(c, a_own);
+    b_full = b_own;
+  } else {
+    LD_TRY(exchange_time_to_blocks(c, Np, 0, a_own, B.a_rows, B.xs, B.xr, B.xT));
+    LD_TRY(exchange_time_to_blocks(c, Np, 1, a_own, B.a_cols, B.xs, B.xr, B.xT));
+    av = aview_blocks(c, B.a_rows, B.a_cols);
+    double* mine = B.b_all + (size_t)c.rank * pad * D;
+    if (n_own > 0) LD_TRY(hipMemcpyAsync(mine, b_own, (size_t)n_own * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (world > 1) SH_COMM(c, c.comm.all_gather(c.comm.user, mine, B.b_all, (uint64_t)pad * D, st));
+    unpad(D, B.b_all, B.b_full);
+    b_full = B.b_full;
+  }
+  LD_TRY(shard_solve_fwd(c, Np, av, b_full, p.m0, p.S0, p.Sigma, B.m_own, B.S_own));
   // observation terms
   const size_t ocnt = (size_t)p.M * (D + 1);
   if (p.M > 0) {
     double* mine = B.obuf + (size_t)c.rank * ocnt;
     hipLaunchKernelGGL(k_shard_obs, dim3(p.M), dim3(256), 0, st, D, lo, hi, B.obs_t, p.obs_y, p.rinv, B.m_own, B.S_own, mine, mine + (size_t)p.M * D);
-    if (world > 1) SH_COMM(c.comm.all_gather(c.comm.user, mine, B.obuf, (uint64_t)ocnt, st));
+    if (world > 1) SH_COMM(c, c.comm.all_gather(c.comm.user, mine, B.obuf, (uint64_t)ocnt, st));
     const int blocks = (int)(((size_t)p.M * D + 255) / 256 < 1024 ? ((size_t)p.M * D + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_shard_obs_sum, dim3(blocks), dim3(256), 0, st, D, p.M, world, B.obuf, p.obs_const, B.jm, B.scal);
   } else {
     LD_TRY(hipMemsetAsync(B.scal, 0, sizeof(double), st));
   }
-  // E_sde terms of the own grid points, written into this rank's part of the gather buffers
+  // E_sde terms of the own grid points; the small per-grid-point results go into this rank's part of the gather buffers
   double* gm_mine = B.gm_all + (size_t)c.rank * pad * D;
-  double* gs_mine = B.gs_all + (size_t)c.rank * pad * DD;
   double* et_mine = B.et_all + (size_t)c.rank * pad;
   if (n_own > 0)
-    LD_TRY(lde_energy(D, n_own, p.theta, p.isg, A + (size_t)lo * DD, b + (size_t)lo * D, B.m_own, B.S_own, et_mine, B.Ef_own, nullptr,
-                      gm_mine, gs_mine, B.status, B.lde_ws, B.lde_nb, st));
+    LD_TRY(lde_energy(D, n_own, p.theta, p.isg, a_own, b_own, B.m_own, B.S_own, et_mine, B.Ef_own, nullptr, gm_mine, B.gs_own, B.status,
+                      B.lde_ws, B.lde_nb, st));
   if (world > 1) {
-    if (c.comm.group_begin) SH_COMM(c.comm.group_begin(c.comm.user));
-    SH_COMM(c.comm.all_gather(c.comm.user, gs_mine, B.gs_all, (uint64_t)pad * DD, st));
-    SH_COMM(c.comm.all_gather(c.comm.user, gm_mine, B.gm_all, (uint64_t)pad * D, st));
-    SH_COMM(c.comm.all_gather(c.comm.user, et_mine, B.et_all, (uint64_t)pad, st));
-    if (c.comm.group_end) SH_COMM(c.comm.group_end(c.comm.user));
+    if (c.comm.group_begin) SH_COMM(c, c.comm.group_begin(c.comm.user));
+    SH_COMM(c, c.comm.all_gather(c.comm.user, gm_mine, B.gm_all, (uint64_t)pad * D, st));
+    SH_COMM(c, c.comm.all_gather(c.comm.user, et_mine, B.et_all, (uint64_t)pad, st));
+    if (c.comm.group_end) SH_COMM(c, c.comm.group_end(c.comm.user));
   }
+  unpad(D, B.gm_all, B.gm_full);
+  unpad(1, B.et_all, B.et_full);
+  // dEsde_dS: every rank needs rows I_p of every grid point -- a time -> row exchange, not an all-gather; dEsde_dS of the own
+  // grid points is dead behind it and Psi of the own grid points takes its place (one rank: no exchange, Psi in the other buffer)
   BwdIn in;
-  in.gm = B.gm_all; in.gs = B.gs_all; in.pad_len = pad; in.world = world; in.Np = Np;
+  in.gm = B.gm_full;
   in.obs_idx = obs_idx.data(); in.jm_sparse = B.jm; in.js_const = B.jsc;
-  LD_TRY(shard_solve_bwd(c, Np, A, in, B.lam_own, B.psi_own));
+  double* psi_own;
+  if (world > 1) {
+    LD_TRY(exchange_time_to_blocks(c, Np, 0, B.gs_own, B.g_rows, B.xs, B.xr, B.xT));
+    in.g_rows = B.g_rows; in.g_rows_t = (size_t)c.Mp * D;
+    psi_own = B.gs_own;
+  } else {
+    in.g_rows = B.gs_own; in.g_rows_t = DD;
+    psi_own = B.g_rows;
+  }
+  LD_TRY(shard_solve_bwd(c, Np, av, in, B.lam_own, psi_own));
   if (n_own > 0)
-    LD_TRY(lde_grad(D, n_own, c.dt, p.isg, A + (size_t)lo * DD, b + (size_t)lo * D, B.m_own, B.S_own, B.lam_own, B.psi_own, B.Ef_own,
-                    gA_own, gB_own, B.lde_ws, B.lde_nb, st));
-  hipLaunchKernelGGL(k_shard_unpad, dim3((Np + 255) / 256), dim3(256), 0, st, Np, world, pad, B.et_all, B.et_full);
+    LD_TRY(lde_grad(D, n_own, c.dt, p.isg, a_own, b_own, B.m_own, B.S_own, B.lam_own, psi_own, B.Ef_own, gA_own, gB_own, B.lde_ws,
+                    B.lde_nb, st));
   ReduceArgs r{};
   r.Np = Np; r.batch = 1; r.dt = c.dt; r.pre = 1.0; r.div = 1.0; r.e0 = p.e0;
   r.e_t = B.et_full; r.eobs = B.scal; r.esde = B.scal + 1; r.f = B.scal + 2;
@@ -1127,6 +1454,15 @@ int vgpa_ld_gemm(void* stream, int transa, int M, int N, int K, const double* A0
   return ld::launch_gemm(transa != 0, g, (hipStream_t)stream) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
 }
 
+int vgpa_ld_gemm_chunk(void* stream, int transa, int M, int N, int K, const double* A0, int lda, const double* B, int ldb,
+                       double* C, int cw, int seg_tiles, int seg_stride, int accumulate) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A0 || !B || !C || cw <= 0 || (N % cw) != 0) return VGPA_ERR_ARG;
+  if (seg_tiles < 0 || (seg_tiles > 0 && (seg_stride < seg_tiles * ld::BK || K % (seg_tiles * ld::BK) != 0))) return VGPA_ERR_ARG;
+  ld::GemmArgs g{M, N, K, A0, nullptr, lda, B, ldb, C, cw};
+  g.seg_tiles = seg_tiles; g.seg_stride = seg_stride; g.accumulate = accumulate != 0;
+  return ld::launch_gemm(transa != 0, g, (hipStream_t)stream) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
 int vgpa_ld_stage(void* stream, const vgpa_ld_stage_args* p) {
   if (!p || p->D <= 0 || p->Mp <= 0 || p->cw <= 0) return VGPA_ERR_ARG;
   ld::StageArgs a{};
@@ -1150,6 +1486,16 @@ struct vgpa_shard {
   std::vector<int32_t> obs_idx;        // grid point -> observation number or -1 (host)
 };
 
+namespace {
+// a rank that stops enqueueing leaves its peers inside a collective: whatever went wrong, the communicator goes down with it
+int shard_fail(vgpa_shard* s, hipError_t e) {
+  if (e == hipSuccess) return VGPA_OK;
+  const bool comm = s->c.failed;
+  ld::comm_failed(s->c);
+  return comm ? VGPA_ERR_COMM : VGPA_ERR_DEVICE;
+}
+}  // namespace
+
 int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_pts, int rank, int world, int device,
                       const vgpa_comm* comm, void* stream) {
   if (!out || dim_d < 1 || n_pts < 2 || world < 1 || rank < 0 || rank >= world || !(dt > 0.0)) return VGPA_ERR_ARG;
@@ -1162,15 +1508,26 @@ int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_
   s->c.method = method; s->c.D = dim_d; s->c.rank = rank; s->c.world = world; s->c.dt = dt;
   s->c.Mp = dim_d / world; s->c.row0 = rank * s->c.Mp;
   if (comm) s->c.comm = *comm; else s->c.comm = vgpa_comm{};
+  bool ok = true;
   if (stream) s->c.st = (hipStream_t)stream;
   else {
-    if (hipStreamCreateWithFlags(&s->c.st, hipStreamNonBlocking) != hipSuccess) { delete s; return VGPA_ERR_DEVICE; }
-    s->own_stream = true;
+    ok = hipStreamCreateWithFlags(&s->c.st, hipStreamNonBlocking) == hipSuccess;
+    s->own_stream = ok;
   }
-  const size_t n = ld::shard_workspace_doubles(dim_d, s->c.Mp);
-  if (hipMalloc((void**)&s->ws, n * sizeof(double)) != hipSuccess) { if (s->own_stream) (void)hipStreamDestroy(s->c.st); delete s; return VGPA_ERR_DEVICE; }
+  ok = ok && hipStreamCreateWithFlags(&s->c.cs, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&s->c.ev_stage, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&s->c.ev_tail, hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; ok && j < ld::kMaxChunks; j++) ok = hipEventCreateWithFlags(&s->c.ev_chunk[j], hipEventDisableTiming) == hipSuccess;
+  const size_t n = ld::shard_workspace_doubles(dim_d, s->c.Mp, world);
+  ok = ok && hipMalloc((void**)&s->ws, n * sizeof(double)) == hipSuccess;
+  if (!ok) { vgpa_shard_destroy(s); return VGPA_ERR_DEVICE; }
   (void)hipMemsetAsync(s->ws, 0, n * sizeof(double), s->c.st);
   s->c.w = ld::carve_shard(s->ws, dim_d, s->c.Mp);
+  // default schedule: the pipelined gather with four sub-blocks wherever the table and the row-block size allow it
+  // (VGPA_SHARD_CHUNKS=0 keeps round 2's serial schedule; vgpa_shard_set_option changes it per shard)
+  int want = 4;
+  if (const char* e = getenv("VGPA_SHARD_CHUNKS")) want = atoi(e);
+  s->c.chunks = want > 0 ? ld::usable_chunks(s->c, want) : 0;
   *out = s;
   return VGPA_OK;
 }
@@ -1178,11 +1535,35 @@ int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_
 void vgpa_shard_destroy(vgpa_shard* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  (void)hipStreamSynchronize(s->c.st);
+  if (s->c.st && !s->c.failed) (void)hipStreamSynchronize(s->c.st);
+  if (s->c.cs && !s->c.failed) (void)hipStreamSynchronize(s->c.cs);
   if (s->ws) (void)hipFree(s->ws);
   for (void* q : s->sweep_allocs) (void)hipFree(q);
+  if (s->c.ev_stage) (void)hipEventDestroy(s->c.ev_stage);
+  if (s->c.ev_tail) (void)hipEventDestroy(s->c.ev_tail);
+  for (int j = 0; j < ld::kMaxChunks; j++) if (s->c.ev_chunk[j]) (void)hipEventDestroy(s->c.ev_chunk[j]);
+  if (s->c.cs) (void)hipStreamDestroy(s->c.cs);
   if (s->own_stream) (void)hipStreamDestroy(s->c.st);
   delete s;
+}
+
+int vgpa_shard_set_option(vgpa_shard* s, int option, int64_t value) {
+  if (!s) return VGPA_ERR_ARG;
+  if (option == VGPA_SHARD_OPT_GATHER_CHUNKS) {
+    if (value < 0 || value > ld::kMaxChunks) return VGPA_ERR_ARG;
+    if (hipSetDevice(s->device) != hipSuccess || ld::shard_join(s->c) != hipSuccess) return VGPA_ERR_DEVICE;
+    s->c.chunks = value > 0 ? ld::usable_chunks(s->c, (int)value) : 0;
+    return VGPA_OK;
+  }
+  if (option == VGPA_SHARD_OPT_TIMEOUT_MS) { s->c.timeout_ms = value; return VGPA_OK; }
+  return VGPA_ERR_ARG;
+}
+
+int vgpa_shard_get_option(const vgpa_shard* s, int option, int64_t* value) {
+  if (!s || !value) return VGPA_ERR_ARG;
+  if (option == VGPA_SHARD_OPT_GATHER_CHUNKS) { *value = s->c.chunks; return VGPA_OK; }
+  if (option == VGPA_SHARD_OPT_TIMEOUT_MS) { *value = s->c.timeout_ms; return VGPA_OK; }
+  return VGPA_ERR_ARG;
 }
 
 int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi) {
@@ -1196,84 +1577,160 @@ void* vgpa_shard_stream(vgpa_shard* s) { return s ? (void*)s->c.st : nullptr; }
 int vgpa_shard_synchronize(vgpa_shard* s) {
   if (!s) return VGPA_ERR_ARG;
   if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
-  return hipStreamSynchronize(s->c.st) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+  if (s->c.failed) return VGPA_ERR_COMM;
+  return ld::shard_wait(s->c);
 }
 
 int vgpa_shard_solve_fwd(vgpa_shard* s, const double* lin_a, const double* off_b, const double* m0, const double* s0,
                          const double* sigma, double* m_own, double* s_own) {
   if (!s || !lin_a || !off_b || !m0 || !s0 || !sigma || !m_own || !s_own) return VGPA_ERR_ARG;
+  if (s->c.failed) return VGPA_ERR_COMM;
   if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
-  return ld::shard_solve_fwd(s->c, s->Np, lin_a, off_b, m0, s0, sigma, m_own, s_own) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+  return shard_fail(s, ld::shard_solve_fwd(s->c, s->Np, ld::aview_replicated(s->c, lin_a), off_b, m0, s0, sigma, m_own, s_own));
 }
 
 int vgpa_shard_solve_bwd(vgpa_shard* s, const double* lin_a, const double* desde_dm, const double* desde_ds,
                          const double* deobs_dm, const double* deobs_ds, double* lam_own, double* psi_own) {
   if (!s || !lin_a || !desde_dm || !desde_ds || !deobs_dm || !deobs_ds || !lam_own || !psi_own) return VGPA_ERR_ARG;
+  if (s->c.failed) return VGPA_ERR_COMM;
   if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
   ld::BwdIn in;
-  in.gm = desde_dm; in.gs = desde_ds; in.jm_dense = deobs_dm; in.js_dense = deobs_ds; in.Np = s->Np;
-  return ld::shard_solve_bwd(s->c, s->Np, lin_a, in, lam_own, psi_own) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+  in.gm = desde_dm; in.g_rows = desde_ds + (size_t)s->c.row0 * s->c.D; in.g_rows_t = (size_t)s->c.D * s->c.D;
+  in.jm_dense = deobs_dm; in.js_dense = deobs_ds;
+  return shard_fail(s, ld::shard_solve_bwd(s->c, s->Np, ld::aview_replicated(s->c, lin_a), in, lam_own, psi_own));
 }
 
-int vgpa_shard_sweep(vgpa_shard* s, const vgpa_shard_problem* p, const double* x_dev, double* f_host, double* grad_a_own,
-                     double* grad_b_own) {
-  if (!s || !p || !x_dev || !f_host || !grad_a_own || !grad_b_own) return VGPA_ERR_ARG;
-  if (!p->inv_sigma_diag || !p->m0 || !p->s0 || !p->sigma || p->n_obs < 0) return VGPA_ERR_ARG;
-  if (p->n_obs > 0 && (!p->obs_t || !p->obs_y || !p->obs_rinv_diag)) return VGPA_ERR_ARG;
-  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
-  const int D = s->c.D, Np = s->Np, world = s->c.world, M = p->n_obs;
+namespace {
+// every device buffer of the fused sweep; false when an allocation fails (the caller's agreement step tells the peers)
+bool shard_sweep_buffers(vgpa_shard* s, int M, bool sharded_x) {
+  const int D = s->c.D, Np = s->Np, world = s->c.world;
   const size_t DD = (size_t)D * D;
   int lo, hi;
   ld::time_slice(Np, s->c.rank, world, &lo, &hi);
   const size_t n_own = (size_t)(hi - lo > 0 ? hi - lo : 1), pad = (size_t)(Np + world - 1) / world;
   ld::SweepBuffers& B = s->sb;
-  if (!B.m_own || B.M != M) {
-    for (void* q : s->sweep_allocs) (void)hipFree(q);
-    s->sweep_allocs.clear();
-    B = ld::SweepBuffers{};
-    auto alloc = [&](double** ptr, size_t n) -> bool {
-      if (hipMalloc((void**)ptr, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
-      s->sweep_allocs.push_back(*ptr);
-      return hipMemsetAsync(*ptr, 0, (n ? n : 1) * sizeof(double), s->c.st) == hipSuccess;
-    };
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    B.lde_nb = ld::lde_batch(D, std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b)));
-    if (B.lde_nb > (int)n_own) B.lde_nb = (int)n_own;
-    bool ok = alloc(&B.m_own, n_own * D) && alloc(&B.S_own, n_own * DD) && alloc(&B.lam_own, n_own * D) && alloc(&B.psi_own, n_own * DD) &&
-              alloc(&B.Ef_own, n_own * D) && alloc(&B.gm_all, (size_t)world * pad * D) && alloc(&B.gs_all, (size_t)world * pad * DD) &&
-              alloc(&B.et_all, (size_t)world * pad) && alloc(&B.et_full, (size_t)Np) && alloc(&B.obuf, (size_t)world * M * (D + 1)) &&
-              alloc(&B.jm, (size_t)M * D) && alloc(&B.jsc, DD) && alloc(&B.scal, 4) && alloc(&B.lde_ws, ld::lde_workspace_doubles(D, B.lde_nb));
-    double* tmp = nullptr;
-    ok = ok && alloc(&tmp, (size_t)M + 1);
-    B.obs_t = reinterpret_cast<int64_t*>(tmp);
-    tmp = nullptr;
-    ok = ok && alloc(&tmp, 1);
-    B.status = reinterpret_cast<int32_t*>(tmp);
-    if (!ok) return VGPA_ERR_DEVICE;
-    B.M = M;
-  }
-  // per-call problem data (cheap): observation grid, constant matrix jump 0.5 R^-1
-  s->obs_idx.assign((size_t)Np, -1);
+  if (B.m_own && B.M == M && B.sharded_x == sharded_x) return true;
+  for (void* q : s->sweep_allocs) (void)hipFree(q);
+  s->sweep_allocs.clear();
+  B = ld::SweepBuffers{};
+  auto alloc = [&](double** ptr, size_t n) -> bool {
+    if (hipMalloc((void**)ptr, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
+    s->sweep_allocs.push_back(*ptr);
+    return hipMemsetAsync(*ptr, 0, (n ? n : 1) * sizeof(double), s->c.st) == hipSuccess;
+  };
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  B.lde_nb = ld::lde_batch(D, std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b)));
+  if (B.lde_nb > (int)n_own) B.lde_nb = (int)n_own;
+  B.xT = ld::exchange_batch(D, std::fmin(2.0e9, std::fmax(2.5e8, 0.01 * (double)free_b)), (int)pad);
+  const bool xch = world > 1;               // one rank: the exchanges are identities, no staging
+  const size_t MD = (size_t)s->c.Mp * D;
+  bool ok = alloc(&B.m_own, n_own * D) && alloc(&B.S_own, n_own * DD) && alloc(&B.lam_own, n_own * D) && alloc(&B.gs_own, n_own * DD) &&
+            alloc(&B.Ef_own, n_own * D) && alloc(&B.g_rows, (size_t)Np * MD) && alloc(&B.gm_all, (size_t)world * pad * D) &&
+            alloc(&B.gm_full, (size_t)Np * D) && alloc(&B.et_all, (size_t)world * pad) && alloc(&B.et_full, (size_t)Np) &&
+            alloc(&B.obuf, (size_t)world * M * (D + 1)) && alloc(&B.jm, (size_t)M * D) && alloc(&B.jsc, DD) && alloc(&B.scal, 4) &&
+            alloc(&B.lde_ws, ld::lde_workspace_doubles(D, B.lde_nb));
+  if (xch) ok = ok && alloc(&B.xs, (size_t)B.xT * DD) && alloc(&B.xr, (size_t)B.xT * DD);
+  if (sharded_x && xch)
+    ok = ok && alloc(&B.a_rows, (size_t)Np * MD) && alloc(&B.a_cols, (size_t)Np * MD) && alloc(&B.b_all, (size_t)world * pad * D) &&
+         alloc(&B.b_full, (size_t)Np * D);
+  double* tmp = nullptr;
+  ok = ok && alloc(&tmp, (size_t)M + 1);
+  B.obs_t = reinterpret_cast<int64_t*>(tmp);
+  tmp = nullptr;
+  ok = ok && alloc(&tmp, 1);
+  B.status = reinterpret_cast<int32_t*>(tmp);
+  if (ok) { B.M = M; B.sharded_x = sharded_x; }
+  return ok;
+}
+
+int shard_sweep_entry(vgpa_shard* s, const vgpa_shard_problem* p, const double* x_full, const double* a_own, const double* b_own,
+                      double* f_host, double* grad_a_own, double* grad_b_own) {
+  if (!p->inv_sigma_diag || !p->m0 || !p->s0 || !p->sigma || p->n_obs < 0) return VGPA_ERR_ARG;
+  if (p->n_obs > 0 && (!p->obs_t || !p->obs_y || !p->obs_rinv_diag)) return VGPA_ERR_ARG;
+  if (s->c.failed) return VGPA_ERR_COMM;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  const int D = s->c.D, Np = s->Np, M = p->n_obs;
+  const size_t DD = (size_t)D * D;
+  // argument checks come BEFORE the first collective and depend on replicated data only: every rank takes the same exit
   for (int n = 0; n < M; n++) {
     const int64_t t = p->obs_t[n];
     if (t < 0 || t >= Np) return VGPA_ERR_ARG;
-    s->obs_idx[(size_t)t] = n;
+    if (n > 0 && t <= p->obs_t[n - 1]) return VGPA_ERR_ARG;       // increasing: one observation per grid point (the backward
+  }                                                               // jumps index by grid point, the energy sums every observation)
+  const bool first = !(s->sb.m_own && s->sb.M == M && s->sb.sharded_x == (x_full == nullptr));
+  const bool have = shard_sweep_buffers(s, M, x_full == nullptr);
+  ld::SweepBuffers& B = s->sb;
+  if (first || !have) {      // allocation is a local event: agree on it before any rank enters the sweep's collectives
+    const int rc = ld::shard_agree(s->c, nullptr, have ? VGPA_OK : VGPA_ERR_DEVICE);
+    if (rc != VGPA_OK) { if (!have) { s->sb = ld::SweepBuffers{}; } return rc; }
   }
+  s->obs_idx.assign((size_t)Np, -1);
+  for (int n = 0; n < M; n++) s->obs_idx[(size_t)p->obs_t[n]] = n;
+  bool ok = true;
   if (M > 0) {
-    if (hipMemcpyAsync(B.obs_t, p->obs_t, sizeof(int64_t) * M, hipMemcpyHostToDevice, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
-    if (hipMemsetAsync(B.jsc, 0, sizeof(double) * DD, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
-    hipLaunchKernelGGL(ld::k_diag_half, dim3((D + 255) / 256), dim3(256), 0, s->c.st, D, p->obs_rinv_diag, B.jsc);
+    ok = hipMemcpyAsync(B.obs_t, p->obs_t, sizeof(int64_t) * M, hipMemcpyHostToDevice, s->c.st) == hipSuccess &&
+         hipMemsetAsync(B.jsc, 0, sizeof(double) * DD, s->c.st) == hipSuccess;
+    if (ok) hipLaunchKernelGGL(ld::k_diag_half, dim3((D + 255) / 256), dim3(256), 0, s->c.st, D, p->obs_rinv_diag, B.jsc);
   }
   ld::SweepProblem sp{p->theta, p->obs_const, p->e0, p->inv_sigma_diag, p->m0, p->s0, p->sigma, p->obs_y, p->obs_rinv_diag, M, p->obs_t};
-  if (ld::shard_sweep(s->c, Np, B, sp, x_dev, s->obs_idx, grad_a_own, grad_b_own) != hipSuccess) return VGPA_ERR_DEVICE;
-  int32_t status = 0;
+  if (!ok || ld::shard_sweep(s->c, Np, B, sp, x_full, a_own, b_own, s->obs_idx, grad_a_own, grad_b_own) != hipSuccess) {
+    const bool was_comm = s->c.failed;
+    ld::comm_failed(s->c);                   // this rank stops enqueueing: its peers must not wait for it
+    return was_comm ? VGPA_ERR_COMM : VGPA_ERR_DEVICE;
+  }
   double f = 0.0;
-  if (hipMemcpyAsync(&f, B.scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
-  if (hipMemcpyAsync(&status, B.status, sizeof(int32_t), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
-  if (hipStreamSynchronize(s->c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  if (hipMemcpyAsync(&f, B.scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) { ld::comm_failed(s->c); return VGPA_ERR_DEVICE; }
+  // the outcome is collective: a covariance that lost positive definiteness on ONE rank's time slice (or a device fault there)
+  // is every rank's return code (the reference raises LinAlgError and the whole run ends, variational.py:380)
+  const int rc = ld::shard_agree(s->c, B.status, VGPA_OK);
   *f_host = f;
-  return (status & 1) ? VGPA_ERR_NOT_PD : VGPA_OK;
+  return rc;
+}
+}  // namespace
+
+int vgpa_shard_sweep(vgpa_shard* s, const vgpa_shard_problem* p, const double* x_dev, double* f_host, double* grad_a_own,
+                     double* grad_b_own) {
+  if (!s || !p || !x_dev || !f_host || !grad_a_own || !grad_b_own) return VGPA_ERR_ARG;
+  return shard_sweep_entry(s, p, x_dev, nullptr, nullptr, f_host, grad_a_own, grad_b_own);
+}
+
+int vgpa_shard_sweep_sharded(vgpa_shard* s, const vgpa_shard_problem* p, const double* a_own, const double* b_own, double* f_host,
+                             double* grad_a_own, double* grad_b_own) {
+  if (!s || !p || !a_own || !b_own || !f_host || !grad_a_own || !grad_b_own) return VGPA_ERR_ARG;
+  return shard_sweep_entry(s, p, nullptr, a_own, b_own, f_host, grad_a_own, grad_b_own);
+}
+
+// The two per-stage collectives alone, as the recursion issues them (same buffers, sizes, streams and schedule), `reps` times:
+// average milliseconds of the all-to-all of the product blocks and of the gather of the next stage state.
+int vgpa_shard_time_collectives(vgpa_shard* s, int reps, double* all_to_all_ms, double* gather_ms) {
+  if (!s || reps < 1 || !all_to_all_ms || !gather_ms) return VGPA_ERR_ARG;
+  *all_to_all_ms = *gather_ms = 0.0;
+  if (s->c.world < 2) return VGPA_OK;
+  if (s->c.failed) return VGPA_ERR_COMM;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  ld::ShardCtx& c = s->c;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return VGPA_ERR_DEVICE;
+  int rc = VGPA_OK;
+  float ms = 0.f;
+  for (int which = 0; which < 2 && rc == VGPA_OK; which++) {
+    for (int it = -2; it < reps && rc == VGPA_OK; it++) {       // two untimed rounds first
+      if (it == 0) (void)hipEventRecord(e0, c.st);
+      if (which == 0) {
+        if (c.comm.all_to_all(c.comm.user, c.w.Wp, c.w.Wcol, (uint64_t)c.Mp * c.Mp, c.st) != 0) rc = VGPA_ERR_COMM;
+      } else {
+        if (ld::shard_gather(c, c.w.XA, c.w.xvA) != hipSuccess || ld::shard_join(c) != hipSuccess) rc = VGPA_ERR_COMM;
+      }
+    }
+    if (rc != VGPA_OK) break;
+    (void)hipEventRecord(e1, c.st);
+    rc = ld::shard_wait(c);
+    if (rc == VGPA_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (which == 0 ? *all_to_all_ms : *gather_ms) = ms / reps;
+  }
+  if (rc == VGPA_ERR_COMM) ld::comm_failed(c);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
 }
 
 }  // extern "C"

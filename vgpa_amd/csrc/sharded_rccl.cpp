@@ -14,6 +14,7 @@ struct UniqueId { char internal[VGPA_RCCL_UNIQUE_ID_BYTES]; };
 typedef int (*get_unique_id_t)(UniqueId*);
 typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
 typedef int (*comm_destroy_t)(void*);
+typedef int (*comm_abort_t)(void*);
 typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*send_t)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*recv_t)(void*, size_t, int, int, void*, hipStream_t);
@@ -25,6 +26,7 @@ struct Api {
   get_unique_id_t get_unique_id = nullptr;
   comm_init_rank_t comm_init_rank = nullptr;
   comm_destroy_t comm_destroy = nullptr;
+  comm_abort_t comm_abort = nullptr;      // optional
   all_gather_t all_gather = nullptr;
   send_t send = nullptr;
   recv_t recv = nullptr;
@@ -51,6 +53,7 @@ bool load_api() {
   g_api.get_unique_id = (get_unique_id_t)dlsym(g_api.so, "ncclGetUniqueId");
   g_api.comm_init_rank = (comm_init_rank_t)dlsym(g_api.so, "ncclCommInitRank");
   g_api.comm_destroy = (comm_destroy_t)dlsym(g_api.so, "ncclCommDestroy");
+  g_api.comm_abort = (comm_abort_t)dlsym(g_api.so, "ncclCommAbort");
   g_api.all_gather = (all_gather_t)dlsym(g_api.so, "ncclAllGather");
   g_api.send = (send_t)dlsym(g_api.so, "ncclSend");
   g_api.recv = (recv_t)dlsym(g_api.so, "ncclRecv");
@@ -68,12 +71,14 @@ struct RcclComm {
 
 int rccl_all_gather(void* user, const double* send, double* recv, uint64_t count, void* stream) {
   RcclComm* c = static_cast<RcclComm*>(user);
+  if (!c->comm) return -1;
   return g_api.all_gather(send, recv, (size_t)count, kNcclFloat64, c->comm, (hipStream_t)stream);
 }
 
 // chunk q of send -> rank q: grouped point-to-point calls, one xGMI link per peer
 int rccl_all_to_all(void* user, const double* send, double* recv, uint64_t count, void* stream) {
   RcclComm* c = static_cast<RcclComm*>(user);
+  if (!c->comm) return -1;
   int rc = g_api.group_start();
   for (int q = 0; q < c->world && rc == 0; q++) {
     rc = g_api.send(send + (size_t)q * count, (size_t)count, kNcclFloat64, q, c->comm, (hipStream_t)stream);
@@ -81,6 +86,25 @@ int rccl_all_to_all(void* user, const double* send, double* recv, uint64_t count
   }
   const int rc2 = g_api.group_end();
   return rc ? rc : rc2;
+}
+
+// point-to-point pair of the pipelined gather (always inside rccl_group_begin / rccl_group_end: one launch per sub-block)
+int rccl_send(void* user, const double* buf, uint64_t count, int peer, void* stream) {
+  RcclComm* c = static_cast<RcclComm*>(user);
+  return c->comm ? g_api.send(buf, (size_t)count, kNcclFloat64, peer, c->comm, (hipStream_t)stream) : -1;
+}
+int rccl_recv(void* user, double* buf, uint64_t count, int peer, void* stream) {
+  RcclComm* c = static_cast<RcclComm*>(user);
+  return c->comm ? g_api.recv(buf, (size_t)count, kNcclFloat64, peer, c->comm, (hipStream_t)stream) : -1;
+}
+// after a failure: ncclCommAbort frees the communicator and fails the operations this rank still has in flight, so that its
+// streams drain; the peers see their own collectives fail or time out (vgpa_shard's bounded waits) and abort in turn
+int rccl_abort(void* user) {
+  RcclComm* c = static_cast<RcclComm*>(user);
+  if (!c->comm) return 0;
+  void* comm = c->comm;
+  c->comm = nullptr;
+  return g_api.comm_abort ? g_api.comm_abort(comm) : g_api.comm_destroy(comm);
 }
 
 int rccl_group_begin(void*) { return g_api.group_start(); }
@@ -113,6 +137,9 @@ int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_bytes, int rank, int wo
   out->all_to_all = rccl_all_to_all;
   out->group_begin = rccl_group_begin;
   out->group_end = rccl_group_end;
+  out->send = rccl_send;
+  out->recv = rccl_recv;
+  out->abort = rccl_abort;
   return VGPA_OK;
 }
 

@@ -363,22 +363,34 @@ class NativeShardedRecursion:
         return self._run(self._lib.vgpa_shard_solve_bwd, (lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds),
                          "vgpa_shard_solve_bwd")
 
-    def sweep(self, x, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
-        """
-        Free energy and gradient of VarGP (variational.py:141-288) for ONE Lorenz-96 problem on the row-sharded recursion
-        (vgpa_shard_sweep): F on every rank, the gradient TIME-sharded -- returns (F, gLa_own [n_own, D, D], gLb_own [n_own, D])
-        as device tensors for the grid points of `time_slice`.  x = [A_t | b_t] (host array or device tensor, replicated);
-        diagonal system noise `sigma_diag`, diagonal observation noise `obs_noise_diag`, identity observation operator.
-        """
-        import torch
+    def set_option(self, option, value):
+        """vgpa_shard_set_option: SHARD_OPT_GATHER_CHUNKS (0 = serial schedule, 1..8 sub-blocks of the pipelined gather; the same
+        value on every rank), SHARD_OPT_TIMEOUT_MS."""
+        self._check(self._lib.vgpa_shard_set_option(self._h, int(option), int(value)), "vgpa_shard_set_option")
+
+    @property
+    def gather_chunks(self):
+        """Sub-blocks of the pipelined gather actually in use (0: the serial schedule)."""
+        from ._lib import SHARD_OPT_GATHER_CHUNKS
+        v = ctypes.c_int64(0)
+        self._check(self._lib.vgpa_shard_get_option(self._h, SHARD_OPT_GATHER_CHUNKS, ctypes.byref(v)), "vgpa_shard_get_option")
+        return int(v.value)
+
+    def time_collectives(self, reps=20):
+        """(all_to_all_ms, gather_ms): the two per-stage collectives alone, as a stage issues them (collective call)."""
+        a, g = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self._lib.vgpa_shard_time_collectives(self._h, int(reps), ctypes.byref(a), ctypes.byref(g)),
+                    "vgpa_shard_time_collectives")
+        return a.value, g.value
+
+    def _problem(self, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
         from ._lib import VgpaShardProblem
         d = self.D
         sig = np.asarray(sigma_diag, dtype=np.float64).reshape(d)
         rdiag = np.asarray(obs_noise_diag, dtype=np.float64).reshape(d)
         obs_t = np.ascontiguousarray(obs_t, dtype=np.int64)
         m_obs = int(obs_t.size)
-        xd = self._dev(x)
-        keep = [xd, self._dev(1.0 / sig), self._dev(m0), self._dev(np.asarray(s0, dtype=np.float64).reshape(d, d)),
+        keep = [obs_t, self._dev(1.0 / sig), self._dev(m0), self._dev(np.asarray(s0, dtype=np.float64).reshape(d, d)),
                 self._dev(np.diag(sig)), self._dev(np.asarray(obs_y, dtype=np.float64).reshape(max(m_obs, 1), d) if m_obs else np.zeros((1, d))),
                 self._dev(1.0 / rdiag)]
         prob = VgpaShardProblem()
@@ -389,6 +401,46 @@ class NativeShardedRecursion:
         prob.obs_y, prob.obs_rinv_diag = keep[5].data_ptr(), keep[6].data_ptr()
         prob.obs_const = m_obs * (d * np.log(2.0 * np.pi) + float(np.sum(np.log(rdiag))))
         prob.e0 = float(e0)
+        return prob, keep
+
+    def sweep_sharded(self, a_own, b_own, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+        """
+        vgpa_shard_sweep_sharded: the fused sweep with x MEMORY-SHARDED like the gradient -- a_own [n_own, D, D] and b_own
+        [n_own, D] are A_t / b_t of the grid points of `time_slice` only (device tensors or host arrays).  Returns
+        (F, gLa_own, gLb_own) like `sweep`.  No rank holds a complete (Np, D, D) array.
+        """
+        import torch
+        d = self.D
+        n_own = self.time_slice[1] - self.time_slice[0]
+        ad, bd = self._dev(a_own), self._dev(b_own)
+        if n_own == 0:
+            ad, bd = self._dev(np.zeros((1, d, d))), self._dev(np.zeros((1, d)))
+        prob, keep = self._problem(theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0)
+        dev = torch.device("cuda", self.device)
+        ga = torch.empty((max(n_own, 1), d, d), dtype=torch.float64, device=dev)
+        gb = torch.empty((max(n_own, 1), d), dtype=torch.float64, device=dev)
+        f = ctypes.c_double(0.0)
+        torch.cuda.synchronize(self.device)
+        self._check(self._lib.vgpa_shard_sweep_sharded(self._h, ctypes.byref(prob), ctypes.c_void_p(ad.data_ptr()),
+                                                       ctypes.c_void_p(bd.data_ptr()), ctypes.byref(f),
+                                                       ctypes.c_void_p(ga.data_ptr()), ctypes.c_void_p(gb.data_ptr())),
+                    "vgpa_shard_sweep_sharded")
+        del keep
+        return f.value, ga[:n_own], gb[:n_own]
+
+    def sweep(self, x, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+        """
+        Free energy and gradient of VarGP (variational.py:141-288) for ONE Lorenz-96 problem on the row-sharded recursion
+        (vgpa_shard_sweep): F on every rank, the gradient TIME-sharded -- returns (F, gLa_own [n_own, D, D], gLb_own [n_own, D])
+        as device tensors for the grid points of `time_slice`.  x = [A_t | b_t] (host array or device tensor, replicated);
+        diagonal system noise `sigma_diag`, diagonal observation noise `obs_noise_diag`, identity observation operator.
+        The outcome is collective: every rank raises the same error (LinAlgError when S_t of ANY rank's grid points is not
+        positive definite).
+        """
+        import torch
+        d = self.D
+        xd = self._dev(x)
+        prob, keep = self._problem(theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0)
         n_own = self.time_slice[1] - self.time_slice[0]
         dev = torch.device("cuda", self.device)
         ga = torch.empty((max(n_own, 1), d, d), dtype=torch.float64, device=dev)
@@ -397,4 +449,5 @@ class NativeShardedRecursion:
         torch.cuda.synchronize(self.device)
         self._check(self._lib.vgpa_shard_sweep(self._h, ctypes.byref(prob), ctypes.c_void_p(xd.data_ptr()), ctypes.byref(f),
                                                ctypes.c_void_p(ga.data_ptr()), ctypes.c_void_p(gb.data_ptr())), "vgpa_shard_sweep")
+        del keep
         return f.value, ga[:n_own], gb[:n_own]
