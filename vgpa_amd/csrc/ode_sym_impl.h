@@ -112,6 +112,50 @@ __host__ __device__ constexpr int sym_run_count(int nsb) {
   return n;
 }
 
+// ---- fragment covers (round 3): NSB = 5 (D = 33 .. 40) ----------------------------------------------------------------------
+// The four blocks of one v_mfma_f64_4x4x4_4b need not form a 2x2 super-block: block q of a product takes its A operand from
+// the lanes of block q of one fragment register and its B operand from block q of another, so a fragment is described by a MAP
+// q -> block column, and ONE fragment register serves every product whose row side (or column side) uses that map.  A wave
+// holds the fragments of four maps (a0, a1 | b0, b1), of both operand buffers, and multiplies the "rectangle" of units (a0,b0),
+// (a0,b1), (a1,b0), (a1,b1): 8 fragment reads per k-pair for 16 products (runs: 12 for 16); when b0 IS a1 (`alias`: a
+// "triangle" a0-a1-b1 plus the loop unit (a1,a1)) 6 reads.  The maps below cover the 55 unordered block pairs of the upper
+// triangle of a 10 x 10 block matrix with one rectangle wave (3 units) and three triangle waves (4 units): 26 fragment reads per
+// k-pair and workgroup instead of 45, the same 15 units = 300 products per stage.  (Four triangle waves cannot do it: 16
+// triangles do not cover K_10.)  Found by simulated annealing under three side conditions: (i) a ds_read_b128 lane group -- it
+// mixes lanes of blocks 0, 3 of one row pair with blocks 1, 2 of the next -- touches every bank once
+// ({m0, m3, m1 + 2, m2 + 2} distinct mod 4 wherever the blocks differ); (ii) / (iii) the four blocks of a unit differ in
+// (row-block parity, column-block parity) as far as possible, which is what keeps the mirror / direct publish at most two-way
+// bank conflicted.  Five block pairs are covered twice; the first occurrence owns the elements.
+constexpr int kCoverPat[4][2] = {{0, 2}, {0, 3}, {1, 2}, {1, 3}};          // unit slot -> (row-side map, column-side map)
+constexpr int kCoverMaps[4][4][4] = {                                      // [wave][map a0, a1, b0, b1][block q]
+    {{1, 8, 6, 1}, {2, 6, 7, 3}, {9, 2, 5, 2}, {6, 5, 5, 4}},
+    {{9, 9, 8, 0}, {8, 1, 1, 2}, {8, 1, 1, 2}, {4, 5, 0, 5}},
+    {{6, 9, 3, 6}, {4, 0, 5, 9}, {4, 0, 5, 9}, {0, 7, 4, 3}},
+    {{8, 1, 7, 8}, {6, 7, 2, 3}, {6, 7, 2, 3}, {7, 3, 4, 0}}};
+constexpr int kCoverUnits[4] = {3, 4, 4, 4};
+constexpr bool kCoverAlias[4] = {false, true, true, true};                 // map b0 is map a1
+// does (wave w, slot s, block q) own its block pair (first occurrence in (w, s, q) order)?
+__host__ __device__ constexpr bool cover_owner(int w, int s, int q) {
+  const int I = kCoverMaps[w][kCoverPat[s][0]][q], J = kCoverMaps[w][kCoverPat[s][1]][q];
+  const int lo = I < J ? I : J, hi = I < J ? J : I;
+  for (int w2 = 0; w2 <= w; w2++)
+    for (int s2 = 0; s2 < kCoverUnits[w2]; s2++)
+      for (int q2 = 0; q2 < 4; q2++) {
+        if (w2 == w && (s2 > s || (s2 == s && q2 >= q))) return true;
+        const int I2 = kCoverMaps[w2][kCoverPat[s2][0]][q2], J2 = kCoverMaps[w2][kCoverPat[s2][1]][q2];
+        if ((I2 < J2 ? I2 : J2) == lo && (I2 < J2 ? J2 : I2) == hi) return false;
+      }
+  return true;
+}
+__host__ __device__ constexpr int cover_pairs_owned() {
+  int n = 0;
+  for (int w = 0; w < 4; w++)
+    for (int s = 0; s < kCoverUnits[w]; s++)
+      for (int q = 0; q < 4; q++) n += cover_owner(w, s, q) ? 1 : 0;
+  return n;
+}
+static_assert(cover_pairs_owned() == 55, "the fragment cover must own every block pair of the 10 x 10 upper triangle exactly once");
+
 template <int NB_>
 struct SGeo {
   static constexpr int NB = NB_;
@@ -219,6 +263,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = SGeo<NB>;
   constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = g::MAXS, LD = g::LD, NKP = g::NKP;
+  constexpr bool COVER = (GR == 0);      // fragment cover (NSB = 5) instead of runs: see kCoverMaps
+  static_assert(!COVER || (g::NSB == 5 && MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
   constexpr double sixth = 1.0 / 6.0;
@@ -240,8 +286,36 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // ---- unit slots of this lane ------------------------------------------------------------------------------------------
   const int r4 = lane >> 4, bq = (lane >> 2) & 3, c4 = lane & 3, bi = bq >> 1, bj = bq & 1;
   int colI[NR], colJ[MAXS], offD[MAXS], offM[MAXS];
+  int colm[4] = {0, 0, 0, 0};            // cover: LDS column offset of this lane's fragment element, per map
   unsigned gofs[MAXS];
   bool own[MAXS], wd[MAXS], wm[MAXS];
+  const bool cov_alias = COVER && kCoverAlias[wave];
+  const int cov_units = COVER ? kCoverUnits[wave] : 0;
+  if constexpr (COVER) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * kCoverMaps[wave][m][bq] + c4) ^ r4);
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+      const int Ib = kCoverMaps[wave][kCoverPat[s][0]][bq], Jb = kCoverMaps[wave][kCoverPat[s][1]][bq];
+      const int row = 4 * Ib + r4, col = 4 * Jb + c4;
+      bool first = false;                // (a compile-time table, looked up with the run-time wave / block)
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++)
+          if (w2 == wave && q2 == bq) first = cover_owner(w2, s, q2);
+      const bool act = s < cov_units && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
+      offD[s] = elem_off<NB>(row, col);
+      offM[s] = elem_off<NB>(col, row);
+      wd[s] = act;
+      wm[s] = act && row != col;
+      own[s] = act && row < D && col < D;
+      gofs[s] = own[s] ? 8u * (unsigned)(row * D + col) : 0u;
+      colJ[s] = 0;
+    }
+#pragma unroll
+    for (int rl = 0; rl < NR; rl++) colI[rl] = 0;
+  } else {
 #pragma unroll
   for (int rl = 0; rl < NR; rl++) {
     const Run run = sym_run(g::NSB, wave + 4 * rl, nullptr);
@@ -266,6 +340,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       own[s] = act && row < D && col < D;
       gofs[s] = own[s] ? 8u * (unsigned)(row * D + col) : 0u;
     }
+  }
   }
   ItemTab<NB> IT;
   build_items<NB>(D, tid, IT);
@@ -509,22 +584,39 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // Step t = (group, k-pair): the fragments of step t + 1 are requested before the products of step t issue -- also across
   // the group boundary (the next group's first fragments are on their way while this group's stepper runs) and across the
   // STAGE boundary: product_begin requests step 0 of the next stage right behind the barrier, in front of the vector work.
-  constexpr int NG = cdiv(NR, GR), NSL = 2 * GR, NSTEP = NG * NKP;
-  static_assert(NR % GR == 0, "a group of runs must be complete (the clamped tail group is not parity-clean)");
-  d2_t fa1[2][GR], fa2[2][GR], fb1[2][NSL], fb2[2][NSL];
+  constexpr int GRR = COVER ? 1 : GR;            // (array extents of the run layout; unused under the cover)
+  constexpr int NG = COVER ? 1 : cdiv(NR, GRR), NSL = COVER ? 4 : 2 * GRR, NSTEP = NG * NKP;
+  static_assert(COVER || NR % GRR == 0, "a group of runs must be complete (the clamped tail group is not parity-clean)");
+  d2_t fa1[2][GRR], fa2[2][GRR], fb1[2][COVER ? 1 : NSL], fb2[2][COVER ? 1 : NSL];
+  d2_t fA[2][COVER ? 4 : 1], fX[2][COVER ? 4 : 1];     // cover: fragments of the four maps, from the A operand / the stage state
   auto frag_load = [&](int buf, int t, const double* pa, const double* px) {
-    const int g0 = (t / NKP) * GR, kp = t % NKP;
+    if constexpr (COVER) {
+      const int kp = t % NKP;
 #pragma unroll
-    for (int r = 0; r < GR; r++) {
-      const int rl = g0 + r < NR ? g0 + r : NR - 1;
-      fa1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colI[rl]);
-      fa2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colI[rl]);
-    }
+      for (int m = 0; m < 4; m++) {
+        if (m == 2) continue;
+        fA[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
+        fX[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
+      }
+      if (cov_alias) { fA[buf][2] = fA[buf][1]; fX[buf][2] = fX[buf][1]; }
+      else {
+        fA[buf][2] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[2]);
+        fX[buf][2] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[2]);
+      }
+    } else {
+      const int g0 = (t / NKP) * GRR, kp = t % NKP;
 #pragma unroll
-    for (int u = 0; u < NSL; u++) {
-      const int sl = 2 * g0 + u < MAXS ? 2 * g0 + u : MAXS - 1;
-      fb1[buf][u] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colJ[sl]);
-      fb2[buf][u] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colJ[sl]);
+      for (int r = 0; r < GRR; r++) {
+        const int rl = g0 + r < NR ? g0 + r : NR - 1;
+        fa1[buf][r] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colI[rl]);
+        fa2[buf][r] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colI[rl]);
+      }
+#pragma unroll
+      for (int u = 0; u < NSL; u++) {
+        const int sl = 2 * g0 + u < MAXS ? 2 * g0 + u : MAXS - 1;
+        fb1[buf][u] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colJ[sl]);
+        fb2[buf][u] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colJ[sl]);
+      }
     }
   };
   auto product_begin = [&](const double* Aop, const double* Xc) { frag_load(0, 0, Aop + r4 * LD, Xc + r4 * LD); };
@@ -543,7 +635,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     double w[NSL];
 #pragma unroll
     for (int t = 0; t < NSTEP; t++) {
-      const int gi = t / NKP, kp = t % NKP, g0 = gi * GR, cur = t & 1;
+      const int gi = t / NKP, kp = t % NKP, g0 = gi * GRR, cur = t & 1;
       if (t + 1 < NSTEP) frag_load(cur ^ 1, t + 1, pa, px);
       if (kp == 0) {                     // accumulators start from minus the stage's forcing term
 #pragma unroll
@@ -560,12 +652,26 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
           w[u] = f;
         }
       }
+      if constexpr (COVER) {
+        // unit u = (row-side map u >> 1, column-side map 2 + (u & 1)): Aop^T X with the row side from the A operand and the
+        // column side from the stage state, X^T Aop the other way round; the rectangle wave has no fourth unit
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+          for (int u = 0; u < 3; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+          if (cov_units > 3) w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][1][hh], fX[cur][3][hh], w[3], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 3; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+          if (cov_units > 3) w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][1][hh], fA[cur][3][hh], w[3], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
         for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa1[cur][u >> 1][hh], fb1[cur][u][hh], w[u], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa2[cur][u >> 1][hh], fb2[cur][u][hh], w[u], 0, 0, 0);
+      }
       }
       if (kp == NKP - 1) {
 #pragma unroll
@@ -639,8 +745,22 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   // runs per pipeline step.  Two (four accumulators in turn, 16 MFMAs per step) spill with 256 registers and were slower with
   // 512 (D = 64: 22.0 vs 15.7 ms forward); the kernel is only exercised with one.
+  // NSB = 5 (33 <= D <= 40): the fragment cover (GR = 0; VGPA_SYM_RUNS=1 keeps the run layout for comparison)
+  static const bool runs_only = [] { const char* e = getenv("VGPA_SYM_RUNS"); return e && e[0] == '1'; }();
+  constexpr bool can_cover = SGeo<NB>::NSB == 5;
   constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
+  if constexpr (can_cover) {
+    if (!runs_only) {
+      constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
+      constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;
+      auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, 0, WPE_C> : k_ode_sym<METHOD, FWD, NB, false, 0, WPE_C>;
+      if (lds_c > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+      hipLaunchKernelGGL(kc, dim3(a.batch), dim3(256), lds_c, st, a);
+      return hipGetLastError();
+    }
+  }
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
   auto kern = dense ? k_ode_sym<METHOD, FWD, NB, true, GR, WPE> : k_ode_sym<METHOD, FWD, NB, false, GR, WPE>;
   if (lds > 48 * 1024)
