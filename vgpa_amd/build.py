@@ -23,6 +23,10 @@ CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno
           "-ffp-contract=off"]
 
 
+# experiments: extra compiler flags (e.g. -DVGPA_SYM_SPLIT_C_FWD=1) without editing the sources; never set by the package itself
+CFLAGS += os.environ.get("VGPA_EXTRA_CFLAGS", "").split()
+
+
 def _newer(src, dst, extra=()):
     if not os.path.exists(dst):
         return True

@@ -147,6 +147,20 @@ __host__ __device__ constexpr bool cover_owner(int w, int s, int q) {
       }
   return true;
 }
+// the same as a table (bit q of [wave][slot]): a run-time (wave, block) looks it up instead of evaluating the search
+struct CoverOwnerTab { unsigned char m[4][4]; };
+__host__ __device__ constexpr CoverOwnerTab cover_owner_tab() {
+  CoverOwnerTab t{};
+  for (int w = 0; w < 4; w++)
+    for (int s = 0; s < 4; s++) {
+      unsigned char bits = 0;
+      for (int q = 0; q < 4; q++)
+        if (s < kCoverUnits[w] && cover_owner(w, s, q)) bits = (unsigned char)(bits | (1u << q));
+      t.m[w][s] = bits;
+    }
+  return t;
+}
+__device__ constexpr CoverOwnerTab kCoverOwner = cover_owner_tab();
 __host__ __device__ constexpr int cover_pairs_owned() {
   int n = 0;
   for (int w = 0; w < 4; w++)
@@ -289,7 +303,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   int colm[4] = {0, 0, 0, 0};            // cover: LDS column offset of this lane's fragment element, per map
   unsigned gofs[MAXS];
   bool own[MAXS], wd[MAXS], wm[MAXS];
-  const bool cov_alias = COVER && kCoverAlias[wave];
   const int cov_units = COVER ? kCoverUnits[wave] : 0;
   if constexpr (COVER) {
 #pragma unroll
@@ -298,12 +311,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     for (int s = 0; s < MAXS; s++) {
       const int Ib = kCoverMaps[wave][kCoverPat[s][0]][bq], Jb = kCoverMaps[wave][kCoverPat[s][1]][bq];
       const int row = 4 * Ib + r4, col = 4 * Jb + c4;
-      bool first = false;                // (a compile-time table, looked up with the run-time wave / block)
-#pragma unroll
-      for (int w2 = 0; w2 < 4; w2++)
-#pragma unroll
-        for (int q2 = 0; q2 < 4; q2++)
-          if (w2 == wave && q2 == bq) first = cover_owner(w2, s, q2);
+      const bool first = (kCoverOwner.m[wave][s] >> bq) & 1u;     // (a compile-time table, looked up with the run-time wave / block)
       const bool act = s < cov_units && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
       offD[s] = elem_off<NB>(row, col);
       offM[s] = elem_off<NB>(col, row);
@@ -372,7 +380,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // ---- matrix state -----------------------------------------------------------------------------------------------------
   const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
   double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * DD;
-  double xk[MAXS], acc[MAXS], fc[MAXS], fn[MAXS], fnn[MAXS], jsc[MAXS];
+  double xk[MAXS], acc[MAXS], fc[MAXS], fn[MAXS], fnn[MAXS];
 #pragma unroll
   for (int s = 0; s < MAXS; s++) {
     fc[s] = ldg(G + (FWD ? 0 : (size_t)tidx(0) * DD), gofs[s]);
@@ -380,7 +388,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     fnn[s] = 0.0;
     xk[s] = (FWD && own[s]) ? ldg(a.S0, gofs[s]) : 0.0;
     acc[s] = 0.0;
-    jsc[s] = (!FWD && !DENSEJ && a.js_const && own[s]) ? ldg(a.js_const, gofs[s]) : 0.0;
   }
 
   // ---- vector state: every wave keeps the whole vector in its lanes < D (the other lanes compute along on element 0) ----
@@ -397,7 +404,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     if (sparse_j && __builtin_amdgcn_readfirstlane(n_obs) >= 0) return ldg(a.jm_sparse + ((size_t)prob * a.n_obs + n_obs) * D, lane8);
     return 0.0;
   };
-  double vk = FWD ? ldg(a.m0, lane8) : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  double vk = FWD ? ldg(a.m0, lane8) : 0.0, v1 = 0.0;      // v1: Heun's first slope / RK4's running sum k1 + 2 k2 + 2 k3
   double c0 = ldg(cin + vec(tidx(0)), lane8), c1 = ldg(cin + vec(tclamp(1)), lane8), c2 = 0.0;
   int n_obs_cur = sparse_j ? a.obs_idx[tclamp(1)] : -1, n_obs_next = sparse_j ? a.obs_idx[tclamp(2)] : -1, n_obs_nn = -1;
   double jm = n_steps >= 1 ? jump_vector(tidx(1), n_obs_cur) : 0.0, jm_next = 0.0;
@@ -415,7 +422,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   store_a(Rb, an);
   load_a(A + (size_t)tclamp(1) * DD);
 #pragma unroll
-  for (int s = 0; s < MAXS; s++) { settle(fc[s]); settle(fn[s]); settle(xk[s]); settle(jsc[s]); }
+  for (int s = 0; s < MAXS; s++) { settle(fc[s]); settle(fn[s]); settle(xk[s]); }
   settle(c0); settle(c1); settle(vk); settle(jm);
 #pragma unroll
   for (int q = 0; q < NITS; q++) settle(an[q]);
@@ -456,92 +463,107 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // read cannot be moved above an LDS write by the compiler, so read-compute-write pieces in sequence cost one round trip
   // each.)  Partial inner products: forward sum_k Aop[k][i] v[k], lane = (i, part of the row pairs); backward
   // sum_k Aop[i][k] v[k], lane = (row pair ip, part of the 4-column blocks, rotated by ip / 4: conflict-free).
-  auto tail = [&](int j, int step, const double* Aop, const double* Xc, double* pv) {
-    constexpr bool MID = (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4);
-    constexpr int NAV = FWD ? g::RPP : 4 * g::CBP;
-    d2_t av[NAV], xqf[FWD ? g::RPP : 1], mid[NITS], items[g::NIT];
-    double xqb[FWD ? 1 : 4 * g::CBP];
-    const int pdiv = FWD ? g::PP : g::RP;
-    const int part0 = tid / pdiv, idx = tid - part0 * pdiv;       // forward: idx = column i; backward: idx = row pair ip
-    const bool act = part0 < (FWD ? g::NPF : g::NPARTB);
-    const int part = act ? part0 : 0;
-    // ---- reads
+  // Split-phase chores: every piece of a stage that is not the product is a READ phase (LDS / HBM requests only) and a FINISH
+  // phase (arithmetic, LDS writes, HBM stores) that the time loop places one pipeline step apart -- the requests are in flight
+  // under a step of products, the finish finds its operands there.  State that lives between the two phases:
+  constexpr int NAV = FWD ? g::RPP : 4 * g::CBP;
+  constexpr int NPS = FWD ? g::NPF : g::NPARTB;
+  d2_t tb_av[NAV], tb_xqf[FWD ? g::RPP : 1];
+  double tb_xqb[FWD ? 1 : 4 * g::CBP];
+  d2_t tc_mid[NITS], tc_items[g::NIT];
+  double ta_ps[NPS];
+  const int pdiv = FWD ? g::PP : g::RP;
+  const int tb_part0 = tid / pdiv, tb_idx = tid - tb_part0 * pdiv;      // forward: idx = column i; backward: idx = row pair ip
+  const bool tb_act = tb_part0 < (FWD ? g::NPF : g::NPARTB);
+  const int tb_part = tb_act ? tb_part0 : 0;
+  // B: partial inner products of the vector recursion -> pv
+  auto tailB_read = [&](const double* Aop) {
     if (FWD) {
 #pragma unroll
       for (int r = 0; r < g::RPP; r++) {
-        const int rp0 = part * g::RPP + r;
+        const int rp0 = tb_part * g::RPP + r;
         const int rp = rp0 < g::RP ? rp0 : 0;
-        av[r] = *reinterpret_cast<const d2_t*>(Aop + unit_off<NB>(rp, idx));
-        xqf[r] = *reinterpret_cast<const d2_t*>(xvw + 2 * rp);
+        tb_av[r] = *reinterpret_cast<const d2_t*>(Aop + unit_off<NB>(rp, tb_idx));
+        tb_xqf[r] = *reinterpret_cast<const d2_t*>(xvw + 2 * rp);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < g::CBP; q++) {
-        const int cbq = part + q * g::NPARTB;
-        int cb = (cbq < g::NCB ? cbq : 0) + (idx >> 2);
+        const int cbq = tb_part + q * g::NPARTB;
+        int cb = (cbq < g::NCB ? cbq : 0) + (tb_idx >> 2);
         if (cb >= g::NCB) cb -= g::NCB;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          av[4 * q + kk] = *reinterpret_cast<const d2_t*>(Aop + idx * LD + 2 * (4 * cb + (kk ^ (idx & 3))));   // column 4 cb + kk
-          xqb[4 * q + kk] = xvw[4 * cb + kk];
+          tb_av[4 * q + kk] = *reinterpret_cast<const d2_t*>(Aop + tb_idx * LD + 2 * (4 * cb + (kk ^ (tb_idx & 3))));   // column 4 cb + kk
+          tb_xqb[4 * q + kk] = xvw[4 * cb + kk];
         }
       }
     }
-    if (j == 0 && MID) {
-#pragma unroll
-      for (int q = 0; q < NITS; q++) mid[q] = *unit_ptr(Rb, q);
-    }
-    if (j == 0) load_items(Xc, items);
-    // ---- arithmetic
+  };
+  auto tailB_finish = [&](double* pv) {
     double s0 = 0.0, s1 = 0.0;
     if (FWD) {
 #pragma unroll
       for (int r = 0; r < g::RPP; r++) {
-        const bool in = part * g::RPP + r < g::RP;
-        s0 = __builtin_fma(av[r][0], in ? xqf[r][0] : 0.0, s0);
-        s0 = __builtin_fma(av[r][1], in ? xqf[r][1] : 0.0, s0);
+        const bool in = tb_part * g::RPP + r < g::RP;
+        s0 = __builtin_fma(tb_av[r][0], in ? tb_xqf[r][0] : 0.0, s0);
+        s0 = __builtin_fma(tb_av[r][1], in ? tb_xqf[r][1] : 0.0, s0);
       }
+      *(tb_act ? pv + tb_part * g::PP + tb_idx : trash) = s0;
     } else {
 #pragma unroll
       for (int q = 0; q < g::CBP; q++) {
-        const bool in = part + q * g::NPARTB < g::NCB;
+        const bool in = tb_part + q * g::NPARTB < g::NCB;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          const double xv = in ? xqb[4 * q + kk] : 0.0;
-          s0 = __builtin_fma(av[4 * q + kk][0], xv, s0);
-          s1 = __builtin_fma(av[4 * q + kk][1], xv, s1);
+          const double xv = in ? tb_xqb[4 * q + kk] : 0.0;
+          s0 = __builtin_fma(tb_av[4 * q + kk][0], xv, s0);
+          s1 = __builtin_fma(tb_av[4 * q + kk][1], xv, s1);
         }
       }
-    }
-    if (j == 0 && MID) {
-#pragma unroll
-      for (int q = 0; q < NITS; q++) { mid[q][0] = 0.5 * (mid[q][0] + an[q][0]); mid[q][1] = 0.5 * (mid[q][1] + an[q][1]); }
-    }
-    // ---- LDS writes (operand staging: see mfma::stage_op -- M <- mid-point / end point at stage 0, R <- end point at JSEC)
-    if (FWD) {
-      *(act ? pv + part * g::PP + idx : trash) = s0;
-    } else {
       d2_t o; o[0] = s0; o[1] = s1;
-      *reinterpret_cast<d2_t*>(act ? pv + part * g::PP + 2 * idx : trash) = o;
+      *reinterpret_cast<d2_t*>(tb_act ? pv + tb_part * g::PP + 2 * tb_idx : trash) = o;
     }
+  };
+  // C: operand staging (see mfma::stage_op -- M <- mid-point / end point at stage 0, R <- end point at JSEC), the stage state of
+  // grid point `step` to HBM (stage 0) and the step's HBM loads (stage JSEC).  None of the buffers written here is read by
+  // anyone during stage j, none of the values read is written during stage j: free to run anywhere inside the stage.
+  constexpr bool MIDP = (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4);
+  auto tailC_read = [&](int j, const double* Xc) {
+    if (j == 0) {
+      if (MIDP) {
+#pragma unroll
+        for (int q = 0; q < NITS; q++) tc_mid[q] = *unit_ptr(Rb, q);
+      }
+      load_items(Xc, tc_items);
+    }
+  };
+  auto tailC_finish = [&](int j, int step) {
     if (j == 0) {
       double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
-      if (MID) store_a(dst, mid);
-      else store_a(dst, an);
+      if (MIDP) {
+#pragma unroll
+        for (int q = 0; q < NITS; q++) { tc_mid[q][0] = 0.5 * (tc_mid[q][0] + an[q][0]); tc_mid[q][1] = 0.5 * (tc_mid[q][1] + an[q][1]); }
+        store_a(dst, tc_mid);
+      } else {
+        store_a(dst, an);
+      }
+      store_items(tc_items, tidx(step));
     }
     if (j == JSEC && NS > 1) store_a(Rb, an);
-    // ---- HBM
-    if (j == 0) store_items(items, tidx(step));
-    if (j == JSEC) prefetch(step);
+    if (j == JSEC) prefetch(step);       // (overwrites an[]: behind its last use of the step)
   };
 
   // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
-  auto vector_stage = [&](int j, const double* pv) {
-    constexpr int NPS = FWD ? g::NPF : g::NPARTB;
+  auto vecA_read = [&](const double* pv) {
     const double* pl = pv + (vl ? lane : 0);
-    double vs = pl[0];
 #pragma unroll
-    for (int q = 1; q < NPS; q++) vs += pl[q * g::PP];
+    for (int q = 0; q < NPS; q++) ta_ps[q] = pl[q * g::PP];
+  };
+  auto vecA_finish = [&](int j) {
+    double vs = ta_ps[0];
+#pragma unroll
+    for (int q = 1; q < NPS; q++) vs += ta_ps[q];
     const double cmid = 0.5 * (c0 + c1);
     double vn;
     if (METHOD == VGPA_ODE_EULER) { vk = vk + (c0 - vs) * dt + jm; vn = vk; }
@@ -553,9 +575,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       else { vk = vk + dt * (cmid - vs) + jm; vn = vk; }
     } else {
       if (j == 0) { v1 = c0 - vs; vn = vk + h * v1; }
-      else if (j == 1) { v2 = cmid - vs; vn = vk + h * v2; }
-      else if (j == 2) { v3 = cmid - vs; vn = vk + dt * v3; }
-      else { vk = vk + (dt * (v1 + 2.0 * (v2 + v3) + (c1 - vs))) * sixth + jm; vn = vk; }
+      else if (j == 1) { const double f = cmid - vs; v1 = v1 + 2.0 * f; vn = vk + h * f; }
+      else if (j == 2) { const double f = cmid - vs; v1 = v1 + 2.0 * f; vn = vk + dt * f; }
+      else { vk = vk + (dt * (v1 + (c1 - vs))) * sixth + jm; vn = vk; }
     }
     *xv_mine = vn;
   };
@@ -588,20 +610,48 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   constexpr int NG = COVER ? 1 : cdiv(NR, GRR), NSL = COVER ? 4 : 2 * GRR, NSTEP = NG * NKP;
   static_assert(COVER || NR % GRR == 0, "a group of runs must be complete (the clamped tail group is not parity-clean)");
   d2_t fa1[2][GRR], fa2[2][GRR], fb1[2][COVER ? 1 : NSL], fb2[2][COVER ? 1 : NSL];
-  d2_t fA[2][COVER ? 4 : 1], fX[2][COVER ? 4 : 1];     // cover: fragments of the four maps, from the A operand / the stage state
+  // cover: fragments of the row-side maps a0, a1 (ONE buffer each: a0 is dead behind the first half of a step, a1 is not needed
+  // before the second) and of the column-side maps b0, b1 (two buffers), from the A operand (fA*) / the stage state (fX*)
+  // (HALF, backward: 48 fragment registers.  The forward kernel, whose lanes carry no G_t / G_{t-1}, can afford two buffers of
+  // all four maps -- 64 registers, one block of eight reads per step -- and measured faster that way: 8.06 vs 8.36 ms per
+  // 512-problem launch; the backward kernel spilled 22 registers with it and ran at 9.6 ms instead of 8.95.)
+#ifndef VGPA_SYM_HALF_FWD
+#define VGPA_SYM_HALF_FWD 0
+#endif
+#ifndef VGPA_SYM_HALF_BWD
+#define VGPA_SYM_HALF_BWD 1
+#endif
+  constexpr bool HALF = COVER && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
+  d2_t fAa[COVER ? 2 : 1], fXa[COVER ? 2 : 1], fAb[2][COVER ? 2 : 1], fXb[2][COVER ? 2 : 1];
+  d2_t fA[2][(COVER && !HALF) ? 4 : 1], fX[2][(COVER && !HALF) ? 4 : 1];
+  auto frag_all = [&](int buf, int kp, const double* pa, const double* px) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      fA[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
+      fX[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
+    }
+  };
+  auto frag_a = [&](int m, int kp, const double* pa, const double* px) {
+    fAa[m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
+    fXa[m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
+  };
+  auto frag_b = [&](int buf, int kp, const double* pa, const double* px) {
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      fAb[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[2 + m]);
+      fXb[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[2 + m]);
+    }
+  };
   auto frag_load = [&](int buf, int t, const double* pa, const double* px) {
     if constexpr (COVER) {
+      // (only the first step of a stage comes through here: every other fragment is requested inside the step before it)
       const int kp = t % NKP;
-#pragma unroll
-      for (int m = 0; m < 4; m++) {
-        if (m == 2) continue;
-        fA[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
-        fX[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
-      }
-      if (cov_alias) { fA[buf][2] = fA[buf][1]; fX[buf][2] = fX[buf][1]; }
-      else {
-        fA[buf][2] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[2]);
-        fX[buf][2] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[2]);
+      if constexpr (HALF) {
+        frag_a(0, kp, pa, px);
+        frag_b(buf, kp, pa, px);
+        frag_a(1, kp, pa, px);
+      } else {
+        frag_all(buf, kp, pa, px);
       }
     } else {
       const int g0 = (t / NKP) * GRR, kp = t % NKP;
@@ -622,7 +672,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   auto product_begin = [&](const double* Aop, const double* Xc) { frag_load(0, 0, Aop + r4 * LD, Xc + r4 * LD); };
 
   // products (their step-0 fragments are in flight) + stepper + publish of stage j
-  auto product_stage = [&](int j, int step, const double* Aop, const double* Xc, double* Xn) {
+  auto product_stage = [&](int j, int step, const double* Aop, const double* Xc, double* Xn, auto&& chore) {
     const double* pa = Aop + r4 * LD;
     const double* px = Xc + r4 * LD;
     const bool last = (j == NS - 1);
@@ -632,11 +682,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #pragma unroll
       for (int s = 0; s < MAXS; s++) jsd[s] = ldg(a.js_dense + ((size_t)prob * Np + tidx(step + 1)) * DD, gofs[s]);
     }
+    if (!FWD && last && !DENSEJ) {       // the constant matrix jump 0.5 H^T R^-1 H, only behind a step that ends at an observation:
+#pragma unroll                           // fetched (L2) when it is needed instead of riding in eight registers through every step
+      for (int s = 0; s < MAXS; s++) jsd[s] = 0.0;
+      if (jump_now && a.js_const) {
+#pragma unroll
+        for (int s = 0; s < MAXS; s++) jsd[s] = ldg(a.js_const, gofs[s]);
+      }
+    }
     double w[NSL];
+    chore(-1);                           // beside the first fragments' way from LDS
 #pragma unroll
     for (int t = 0; t < NSTEP; t++) {
       const int gi = t / NKP, kp = t % NKP, g0 = gi * GRR, cur = t & 1;
-      if (t + 1 < NSTEP) frag_load(cur ^ 1, t + 1, pa, px);
+      if (!COVER && t + 1 < NSTEP) frag_load(cur ^ 1, t + 1, pa, px);
       if (kp == 0) {                     // accumulators start from minus the stage's forcing term
 #pragma unroll
         for (int u = 0; u < NSL; u++) {
@@ -655,14 +714,48 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       if constexpr (COVER) {
         // unit u = (row-side map u >> 1, column-side map 2 + (u & 1)): Aop^T X with the row side from the A operand and the
         // column side from the stage state, X^T Aop the other way round; the rectangle wave has no fourth unit
+        // The wave is in-order and the register allocator, left alone, sinks the next step's fragment reads below this step's
+        // products (shorter live ranges): read -> wait -> 16 products, every LDS round trip exposed (measured on a lone
+        // workgroup: 2 680 cycles per stage against 1 280 of matrix-core work).  So the order is pinned, half step by half step:
+        //   eight products of the units (a0, b0), (a0, b1)  |  reads: a0, b0, b1 of the NEXT step (a0's registers are free now)
+        //   eight products of the units (a1, b0), (a1, b1)  |  reads: a1 of the next step
+        // -- every read has at least half a step of products in front of its first use, and only the column-side fragments need
+        // two buffers (48 fragment registers instead of 64).  Per unit the products come in the same order as before (A^T X
+        // then X^T A of the first k-step of the pair, then of the second): same bits.  Straight-line code: a branch inside the
+        // pipeline would end the scheduling region (the rectangle wave multiplies its unused fourth unit too; the triangle waves
+        // read map a1 twice -- the LDS array is not what bounds this kernel, the exposed latency of its reads was).
+        if constexpr (!HALF) {
+          // forward: unit u = (row-side map u >> 1, column-side map 2 + (u & 1)); eight products, the eight reads of the next
+          // step, eight products
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
+          for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
-          for (int u = 0; u < 3; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
-          if (cov_units > 3) w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][1][hh], fX[cur][3][hh], w[3], 0, 0, 0);
+            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
 #pragma unroll
-          for (int u = 0; u < 3; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
-          if (cov_units > 3) w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][1][hh], fA[cur][3][hh], w[3], 0, 0, 0);
+            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+            if (hh == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (t + 1 < NSTEP) frag_all(cur ^ 1, (t + 1) % NKP, pa, px);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        } else {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[2 * half + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa[half][hh], fXb[cur][m][hh], w[2 * half + m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[2 * half + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa[half][hh], fAb[cur][m][hh], w[2 * half + m], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NSTEP) {
+            frag_a(half, (t + 1) % NKP, pa, px);
+            if (half == 0) frag_b(cur ^ 1, (t + 1) % NKP, pa, px);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         }
       } else {
 #pragma unroll
@@ -673,13 +766,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         for (int u = 0; u < NSL; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa2[cur][u >> 1][hh], fb2[cur][u][hh], w[u], 0, 0, 0);
       }
       }
+      chore(t);                          // everything of the stage that is not the product rides between the products
       if (kp == NKP - 1) {
 #pragma unroll
         for (int u = 0; u < NSL; u++) {
           const int s = 2 * g0 + u;
           if (s < MAXS) {
             double js = 0.0;
-            if (!FWD && last) js = DENSEJ ? (own[s] ? jsd[s] : 0.0) : (jump_now ? jsc[s] : 0.0);
+            if (!FWD && last) js = own[s] ? jsd[s] : 0.0;
             const double xn = element(s, j, w[u], js);
             *(wd[s] ? Xn + offD[s] : trash) = xn;
             *(wm[s] ? Xn + offM[s] : trash) = xn;
@@ -699,15 +793,54 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   };
   product_begin(aop(0, 0, true), xcur(0, 0));
   VGPA_STAMP_DECL;
+  // Chores between the products (round 3).  Nothing of a stage but the stepper depends on the stage's product, so everything
+  // else is issued INSIDE the product pipeline, where its LDS and HBM latencies run under matrix-core work instead of behind it
+  // (an in-order wave that does them after the products pays every round trip in full: ~1 700 of a stage's ~3 000 cycles):
+  //   in front of the first products (TA), beside their fragments' way from LDS: the vector update of the PREVIOUS stage (its
+  //   partial sums were completed by the last barrier),
+  //   after step TB: this stage's partial inner products (they read the stage vector written at TA, same wave, in order),
+  //   after step TC: operand staging, the state's way to HBM, the step's HBM loads.
+  // slots: -1 = in front of the first products (beside their fragments' way from LDS), t >= 0 = behind pipeline step t
+  // The split placement is used by the fragment-cover kernels (D = 33 .. 40, the benchmark's size); the run layout keeps every
+  // chore in ONE slot (read and finish back to back) and no scheduling barriers: its 8-product steps unrolled 40-fold (D = 64)
+  // already fill every register the wave has, and pinning more order made the compiler spill scalars by the hundred.
+  constexpr int LAST = NSTEP - 1;
+  constexpr bool SPLIT = COVER;
+  // which chores are split is a register question (256 per lane with two workgroups per CU; a spilled value costs more than an
+  // exposed LDS round trip): forward A and C, backward -- whose lanes also carry G_t, G_{t-1} -- A only, unless overridden
+#ifndef VGPA_SYM_SPLIT_A_FWD
+#define VGPA_SYM_SPLIT_A_FWD 1
+#endif
+#ifndef VGPA_SYM_SPLIT_A_BWD
+#define VGPA_SYM_SPLIT_A_BWD 1
+#endif
+#ifndef VGPA_SYM_SPLIT_B_FWD
+#define VGPA_SYM_SPLIT_B_FWD 0
+#endif
+#ifndef VGPA_SYM_SPLIT_B_BWD
+#define VGPA_SYM_SPLIT_B_BWD 0
+#endif
+#ifndef VGPA_SYM_SPLIT_C_FWD
+#define VGPA_SYM_SPLIT_C_FWD 0
+#endif
+#ifndef VGPA_SYM_SPLIT_C_BWD
+#define VGPA_SYM_SPLIT_C_BWD 0
+#endif
+  constexpr bool SPA = SPLIT && (FWD ? VGPA_SYM_SPLIT_A_FWD : VGPA_SYM_SPLIT_A_BWD);
+  constexpr bool SPB = SPLIT && (FWD ? VGPA_SYM_SPLIT_B_FWD : VGPA_SYM_SPLIT_B_BWD);
+  constexpr bool SPC = SPLIT && (FWD ? VGPA_SYM_SPLIT_C_FWD : VGPA_SYM_SPLIT_C_BWD);
+  constexpr int TBU = NSTEP >= 5 ? NSTEP / 4 + 1 : (NSTEP > 1 ? 1 : 0), TCU = NSTEP >= 5 ? NSTEP / 2 + 1 : LAST;   // unsplit slots
+  constexpr int SA_F = 0, SA_R = SPA ? -1 : SA_F;
+  constexpr int SB_F = SPLIT ? cmin(1, LAST) : TBU, SB_R = SPB ? 0 : SB_F;
+  constexpr int SC_F = SPLIT ? cmin(2, LAST) : TCU, SC_R = SPC ? cmin(1, LAST) : SC_F;
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
-      c0 = c1; c1 = c2;
 #pragma unroll
       for (int q = 0; q < NITS; q++) settle(an[q]);
       if (!FWD) {
 #pragma unroll
         for (int s = 0; s < MAXS; s++) { fc[s] = fn[s]; fn[s] = fnn[s]; }
-        jm = jm_next; n_obs_cur = n_obs_next; n_obs_next = n_obs_nn;
+        n_obs_cur = n_obs_next; n_obs_next = n_obs_nn;
       }
     }
 #pragma unroll
@@ -715,22 +848,39 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       const double* Xc = xcur(k, j);
       double* Xn = (Xc == Xb0) ? Xb1 : Xb0;
       double* pv = pvb + (Xc == Xb0 ? 0 : g::PV);
-      product_stage(j, k, aop(k, j, true), Xc, Xn);
+      double* pv_prev = pvb + (Xc == Xb0 ? g::PV : 0);         // where the previous stage left its partial sums
+      const double* Aopv = aop(k, j, false);
+      product_stage(j, k, aop(k, j, true), Xc, Xn, [&](int t) {
+        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
+        if (t == SA_R && (j > 0 || k > 0)) vecA_read(pv_prev);
+        if (t == SA_F) {
+          if (j > 0) vecA_finish(j - 1);
+          else if (k > 0) {
+            vecA_finish(NS - 1);
+            c0 = c1; c1 = c2;                                   // the vector's forcing terms move on behind its last stage
+            if (!FWD) jm = jm_next;
+          }
+        }
+        if (t == SB_R) tailB_read(Aopv);
+        if (t == SB_F) tailB_finish(pv);
+        if (t == SC_R) tailC_read(j, Xc);
+        if (t == SC_F) tailC_finish(j, k);
+        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
+      });
       VGPA_STAMP(0, 0);
-      // the LDS / VALU phases are short and on the critical path: beside the other workgroup's products they run at a raised
-      // priority (two workgroups per CU: forward 9.33 -> 8.87 ms, backward 9.85 -> 9.77 ms per 512-problem launch)
       __builtin_amdgcn_s_setprio(VGPA_SYM_TAILPRIO);
-      tail(j, k, aop(k, j, false), Xc, pv);
-      VGPA_STAMP(0, 1);
       lds_barrier();
       VGPA_STAMP(0, 2);
       // the next stage's first fragments (Xn is complete now; past the last stage of the sweep they are read and dropped)
       const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
       product_begin(aop(kn, jn, true), Xn);
-      vector_stage(j, pv);
       __builtin_amdgcn_s_setprio(0);
       VGPA_STAMP(0, 3);
     }
+  }
+  if (n_steps > 0) {                     // the last stage's vector update
+    vecA_read(pvb + (xcur(n_steps, 0) == Xb0 ? g::PV : 0));
+    vecA_finish(NS - 1);
   }
   {
     d2_t items[g::NIT];
