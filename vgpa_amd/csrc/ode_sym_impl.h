@@ -55,6 +55,9 @@ using mfma::OP_R;
 using mfma::OP_X;
 
 constexpr int kMaxNB = 16;          // D <= 64
+#ifndef VGPA_SYM_INTERLEAVE
+#define VGPA_SYM_INTERLEAVE 1          // fragment reads between the products (sched_group_barrier) instead of in blocks
+#endif
 #ifndef VGPA_SYM_TAILPRIO
 #define VGPA_SYM_TAILPRIO 1
 #endif
@@ -623,6 +626,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #endif
   constexpr bool HALF = COVER && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
   d2_t fAa[COVER ? 2 : 1], fXa[COVER ? 2 : 1], fAb[2][COVER ? 2 : 1], fXb[2][COVER ? 2 : 1];
+  d2_t fAa1[2], fXa1[2];                 // HALF + interleave: map a1 in two buffers (read half a step earlier than it is free)
   d2_t fA[2][(COVER && !HALF) ? 4 : 1], fX[2][(COVER && !HALF) ? 4 : 1];
   auto frag_all = [&](int buf, int kp, const double* pa, const double* px) {
 #pragma unroll
@@ -634,6 +638,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   auto frag_a = [&](int m, int kp, const double* pa, const double* px) {
     fAa[m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
     fXa[m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
+  };
+  auto frag_a1 = [&](int buf, int kp, const double* pa, const double* px) {
+    fAa1[buf] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[1]);
+    fXa1[buf] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[1]);
   };
   auto frag_b = [&](int buf, int kp, const double* pa, const double* px) {
 #pragma unroll
@@ -649,7 +657,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       if constexpr (HALF) {
         frag_a(0, kp, pa, px);
         frag_b(buf, kp, pa, px);
-        frag_a(1, kp, pa, px);
+        if (VGPA_SYM_INTERLEAVE) frag_a1(buf, kp, pa, px);
+        else frag_a(1, kp, pa, px);
       } else {
         frag_all(buf, kp, pa, px);
       }
@@ -727,6 +736,28 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         if constexpr (!HALF) {
           // forward: unit u = (row-side map u >> 1, column-side map 2 + (u & 1)); eight products, the eight reads of the next
           // step, eight products
+#if VGPA_SYM_INTERLEAVE
+          // the next step's eight reads BETWEEN this step's sixteen products, one read behind every second product: a block of
+          // eight ds_read_b128 takes the LDS queue ~100 cycles to accept when eight waves of the CU do the same, and an in-order
+          // wave that sits in it issues no products meanwhile
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NSTEP) frag_all(cur ^ 1, (t + 1) % NKP, pa, px);
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+          }
+          if (t + 1 < NSTEP) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two matrix-core products
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
@@ -739,7 +770,44 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+#endif
         } else {
+#if VGPA_SYM_INTERLEAVE
+          // backward: first half = units (a0, b0), (a0, b1) with the next step's b0, b1, a1 reads between the products (a1 in
+          // two buffers: 56 fragment registers), second half = units (a1, b0), (a1, b1) with the next step's a0 reads
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NSTEP) { frag_b(cur ^ 1, (t + 1) % NKP, pa, px); frag_a1(cur ^ 1, (t + 1) % NKP, pa, px); }
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa[0][hh], fXb[cur][m][hh], w[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa[0][hh], fAb[cur][m][hh], w[m], 0, 0, 0);
+          }
+          if (t + 1 < NSTEP) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NSTEP) frag_a(0, (t + 1) % NKP, pa, px);
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa1[cur][hh], fXb[cur][m][hh], w[2 + m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa1[cur][hh], fAb[cur][m][hh], w[2 + m], 0, 0, 0);
+          }
+          if (t + 1 < NSTEP) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll
@@ -756,6 +824,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         }
       } else {
 #pragma unroll
