@@ -362,6 +362,52 @@ def test_library_gemm_backend_of_the_stage_product(method):
     own.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,method", [(96, 9, "rk4"), (128, 8, "heun"), (256, 6, "rk4"), (80, 7, "rk2"), (72, 9, "euler")])
+def test_batched_contexts_above_64(d, n, method):
+    """64 < D <= 512 with batch = 4 (one problem of that size leaves the chip idle and the reference treats every D
+    alike, src/numerics/ode_solver.py:31-95): the per-stage GEMM / stage kernels take the problems in grid.z.  Every problem's F,
+    gradient and state arrays against the oracle; a batch equals the single-problem contexts bit for bit."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    p, x = make_problem("L96", d, n, method=method)
+    rng = np.random.default_rng(d + n)
+    xb = np.stack([x + 0.01 * rng.standard_normal(x.size) for _ in range(4)])
+    ctx = gpu_context(p, batch=4)
+    fb, gb = ctx.sweep(xb)
+    mt_b, st_b, psi_b = ctx.fetch("mt"), ctx.fetch("st"), ctx.fetch("psit")
+    one = gpu_context(p)
+    for i in range(4):
+        f_o, g_o, st_o = vo.sweep(p, xb[i], faithful=False)
+        assert abs(fb[i] - f_o) <= TOL * abs(f_o), (i, fb[i], f_o)
+        assert rel_err(gb[i], g_o) < TOL
+        assert rel_err(np.asarray(mt_b)[i], st_o["mt"]) < TOL and rel_err(np.asarray(st_b)[i], st_o["st"]) < TOL
+        assert rel_err(np.asarray(psi_b)[i], st_o["psit"]) < TOL
+        f1, g1 = one.sweep(xb[i])
+        assert f1 == fb[i] and np.array_equal(g1, gb[i])
+    ctx.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_batched_operators_above_64():
+    """Operator-level calls (FwdOde / BwdOde contract) with three problems at D = 96: problem-major inputs, every problem
+    against the oracle."""
+    import vgpa_amd as va
+    d, n, nb = 96, 7, 3
+    sets = [make_inputs(d, n, seed=11 + i) for i in range(nb)]
+    ctx = va.Context("NONE", "rk4", d, n, 0.01, sigma=sets[0][4], batch=nb)
+    a = np.stack([s_[0] for s_ in sets]); b = np.stack([s_[1] for s_ in sets])
+    mt, st = ctx.solve_fwd(a, b, sets[0][2], sets[0][3], sets[0][4])
+    gm = np.stack([s_[5] for s_ in sets]); gs = np.stack([s_[6] for s_ in sets])
+    jm = np.stack([s_[7] for s_ in sets]); js = np.stack([s_[8] for s_ in sets])
+    lam, psi = ctx.solve_bwd(a, gm, gs, jm, js)
+    for i in range(nb):
+        mt_o, st_o = vo.solve_fwd("rk4", 0.01, False, a[i], b[i], sets[0][2], sets[0][3], sets[0][4])
+        lam_o, psi_o = vo.solve_bwd("rk4", 0.01, False, a[i], gm[i], gs[i], jm[i], js[i])
+        assert rel_err(mt[i], mt_o) < TOL and rel_err(st[i], st_o) < TOL
+        assert rel_err(lam[i], lam_o) < TOL and rel_err(psi[i], psi_o) < TOL
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The native driver: step / stage loop and collectives inside libvgpa_hip.so (vgpa_shard_*).
 class _CallbackComm:

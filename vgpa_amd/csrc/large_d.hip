@@ -49,11 +49,15 @@ struct GemmArgs {
   // every rank's row block of the stage state; accumulate: the accumulators start from C instead of zero (the K-chunk
   // launches of one product continue ONE fp64 FMA chain per element: bit-identical to a single launch over the same k order).
   int seg_tiles = 0, seg_stride = 0, accumulate = 0;
+  // batch of independent problems in grid.z (64 < D <= 512: one problem leaves most of the chip idle): per-problem strides
+  int nb = 1;
+  size_t zA = 0, zB = 0, zC = 0;
 };
 
 // FULL: M, N, K are multiples of the tile sizes -- no bounds checks (each one is an EXEC-masked branch in the k loop)
 template <bool TRANSA, bool MID, int BM, bool FULL>
 __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
+  if (g.nb > 1) { const size_t z = blockIdx.z; g.A0 += z * g.zA; if (MID) g.A1 += z * g.zA; g.B += z * g.zB; g.C += z * g.zC; }
   constexpr int LDAS = BM + 17;   // odd: conflict-free transposing stores (NN), near conflict-free fragment reads
   constexpr int MT = BM / 32;     // 16-row MFMA tiles per wave along M (wave tile = (BM/2) x 32)
   constexpr int AQ = BM * BK / NT;
@@ -207,6 +211,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
 //   B  (row-major [k][j]):    Bs[k][LDBS], b128 stores
 template <bool TRANSA, bool MID, int BM, bool SEG = false>
 __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
+  if (g.nb > 1) { const size_t z = blockIdx.z; g.A0 += z * g.zA; if (MID) g.A1 += z * g.zA; g.B += z * g.zB; g.C += z * g.zC; }
   typedef double d2 __attribute__((ext_vector_type(2)));
   constexpr int LDK = 18;                       // NN: doubles per tile row (16 + 2)
   constexpr int LDT = BM + 16;                  // TN: = 16 (mod 32)
@@ -385,6 +390,8 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
 //     y_r = sum_k Aeff[r][k] x[k] ;  r_v = fwd ? -y + e : -e + y ;  same slot logic with vector buffers.
 struct StageArgs {
   int D, row0, Mp, cw, fwd, kstore, final, mid_e, has_j;
+  int nb = 1;           // problems in grid.z; per-problem strides of the pointer groups below
+  size_t zW = 0, zE = 0, zJ = 0, zBase = 0, zK = 0, zOut = 0, zA = 0, zX = 0, zEv = 0, zJv = 0, zVb = 0, zKv = 0, zVo = 0;
   int sym_ok = 0;       // the caller guarantees symmetric E / J / base / slots: the symmetric-tile-pair kernel may serve (internal drivers)
   double cx, cf;
   const double* W;      // [q][Mp][cw] packed row block of the stage product
@@ -414,7 +421,22 @@ __device__ __forceinline__ double stage_combine(double r, double base, double k1
   return base + sgn * (cf * comb) + jump;
 }
 
+__device__ __forceinline__ void stage_batch_offsets(StageArgs& a) {
+  if (a.nb <= 1) return;
+  const size_t z = blockIdx.z;
+  a.W += z * a.zW; a.Wcol += z * a.zW;
+  a.E0 += z * a.zE; if (a.E1) a.E1 += z * a.zE;
+  if (a.J) a.J += z * a.zJ;
+  a.base += z * a.zBase; a.K1 += z * a.zK; a.K23 += z * a.zK; a.out += z * a.zOut;
+  a.A0 += z * a.zA; if (a.A1) a.A1 += z * a.zA;
+  a.x += z * a.zX;
+  a.e0 += z * a.zEv; if (a.e1) a.e1 += z * a.zEv;
+  if (a.jv) a.jv += z * a.zJv;
+  a.vbase += z * a.zVb; a.k1v += z * a.zKv; a.k23v += z * a.zKv; a.vout += z * a.zVo;
+}
+
 __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
+  stage_batch_offsets(a);
   __shared__ double tile[TS][TS + 1];
   const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
   const int nmat = ntx * nty;
@@ -478,7 +500,7 @@ __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
 
 template <int BM, bool FULL>
 static void launch_gemm_bm_f(bool transa, const GemmArgs& g, hipStream_t st) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nb);
   const bool mid = g.A1 != nullptr;
   if (transa) {
     if (mid) hipLaunchKernelGGL((k_gemm<true, true, BM, FULL>), grid, dim3(NT), 0, st, g);
@@ -491,7 +513,7 @@ static void launch_gemm_bm_f(bool transa, const GemmArgs& g, hipStream_t st) {
 
 template <int BM>
 static void launch_gemm_bm_v(bool transa, const GemmArgs& g, hipStream_t st) {
-  dim3 grid(g.N / BN, g.M / BM);
+  dim3 grid(g.N / BN, g.M / BM, g.nb);
   const bool mid = g.A1 != nullptr;
   if (transa) {
     if (mid) hipLaunchKernelGGL((k_gemm_v<true, true, BM>), grid, dim3(NT), 0, st, g);
@@ -511,7 +533,7 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
   if (vec && seg && !g.A1) {        // K-chunk launch (no mid-point operand: the sharded driver forms it once per step)
     GemmArgs h = g;
     if (!h.seg_tiles) { h.seg_tiles = h.K / BK; h.seg_stride = h.K; }
-    dim3 grid(g.N / BN, g.M / BM);
+    dim3 grid(g.N / BN, g.M / BM, g.nb);
     if (transa) hipLaunchKernelGGL((k_gemm_v<true, false, BM, true>), grid, dim3(NT), 0, st, h);
     else hipLaunchKernelGGL((k_gemm_v<false, false, BM, true>), grid, dim3(NT), 0, st, h);
     return;
@@ -523,8 +545,8 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
 
 hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
   // 128-row tiles reuse B twice as much; fall back to 64-row tiles when they would leave CUs without a workgroup
-  const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128);
-  const long long wg64 = (long long)((g.N + BN - 1) / BN) * ((g.M + 63) / 64);
+  const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128) * g.nb;
+  const long long wg64 = (long long)((g.N + BN - 1) / BN) * ((g.M + 63) / 64) * g.nb;
   if (wg128 >= 2 * 256) launch_gemm_bm<128>(transa, g, st);
   else if (wg64 >= 2 * 256) launch_gemm_bm<64>(transa, g, st);
   else launch_gemm_bm<32>(transa, g, st);      // D = 1024: 512 workgroups, two per CU hide each other's k-tile latency
@@ -537,6 +559,7 @@ hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
 // reads the slots), the stage state is written at (r, j) and -- through an LDS transposition, coalesced -- at (j, r).  ~36 MB
 // instead of ~64 MB per stage at D = 1024.  The vector recursion rides in the trailing blocks as in k_stage.
 __global__ void __launch_bounds__(NT) k_stage_sym(StageArgs a) {
+  stage_batch_offsets(a);
   __shared__ double ta[TS][TS + 1], tb[TS][TS + 1], tc[TS][TS + 1];
   const int nt = (a.D + TS - 1) / TS;
   const int npair = nt * (nt + 1) / 2;
@@ -622,11 +645,11 @@ hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
   const int nvec = (a.Mp + (NT / 64) - 1) / (NT / 64);
   if (a.sym_ok && a.Mp == a.D && a.row0 == 0 && a.cw == a.D && a.W == a.Wcol && !stage_sym_off) {
     const int nt = (a.D + TS - 1) / TS;
-    hipLaunchKernelGGL(k_stage_sym, dim3(nt * (nt + 1) / 2 + nvec), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL(k_stage_sym, dim3(nt * (nt + 1) / 2 + nvec, 1, a.nb), dim3(NT), 0, st, a);
     return hipGetLastError();
   }
   const int ntx = (a.D + TS - 1) / TS, nty = (a.Mp + TS - 1) / TS;
-  hipLaunchKernelGGL(k_stage, dim3(ntx * nty + nvec), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(k_stage, dim3(ntx * nty + nvec, 1, a.nb), dim3(NT), 0, st, a);
   return hipGetLastError();
 }
 
@@ -637,9 +660,19 @@ hipError_t launch_stage(const StageArgs& a, hipStream_t st) {
 // the two stages that use it; the GEMM that averages while staging its A tile streams both operands and is ~2.3x
 // slower at D = 1024 (measured: 156 us vs 67 us) -- that variant stays for the row-sharded driver.
 __global__ void __launch_bounds__(256) k_mid(const double* __restrict__ a0, const double* __restrict__ a1, double* __restrict__ out,
-                                             size_t n) {
+                                             size_t n, size_t zin = 0, size_t zout = 0) {
+  a0 += blockIdx.y * zin; a1 += blockIdx.y * zin; out += blockIdx.y * zout;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = 0.5 * (a0[i] + a1[i]);
 }
+
+// Batched single-rank drivers (64 < D <= 512 with several problems per context: the reference treats every D alike,
+// src/numerics/ode_solver.py:31-95, and ONE problem of that size leaves most of the chip idle).  The step / stage loops below
+// compute problem 0's pointers as always; which array a pointer belongs to -- hence its per-problem stride -- is looked up by
+// address in the ranges the API registered (x, the histories, the workspace ...); pointers outside every range (Sigma, the
+// constant jump, S0) are shared by the problems.
+thread_local BatchMap g_batch;
+void ld_set_batch(const BatchMap* m) { g_batch = m ? *m : BatchMap{}; }
+static inline size_t zs(const double* p) { return g_batch.nb > 1 ? g_batch.stride(p) : 0; }
 
 thread_local bool use_library_gemm = false;
 
@@ -678,13 +711,13 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
     if (mc->a0 != ga0 || mc->a1 != ga1) {
       const size_t n = (size_t)D * D;
       const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-      hipLaunchKernelGGL(k_mid, dim3(blocks), dim3(256), 0, st, ga0, ga1, w.AM, n);
+      hipLaunchKernelGGL(k_mid, dim3(blocks, g_batch.nb), dim3(256), 0, st, ga0, ga1, w.AM, n, zs(ga0), zs(w.AM));
       mc->a0 = ga0; mc->a1 = ga1;
     }
     ga0 = w.AM; ga1 = nullptr;
   }
   hipError_t e;
-  if (use_library_gemm && !ga1) {
+  if (use_library_gemm && !ga1 && g_batch.nb == 1) {
     // plain GEMM, one rank: cw = D is plain row-major.  Backward: W' = A^T.Psi would be a transposed-A product (slow in
     // the library at D = 1024); Psi is symmetric, so Z = Psi.A = W'^T is computed instead -- the stage kernel uses W'
     // and W'^T symmetrically (R = -G + W' + W'^T), only the order of its two additions changes.
@@ -695,6 +728,7 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
                           : library_gemm(true, D, D, D, ga0, D, s.X, D, w.W, D, st));
   } else {
     GemmArgs g{D, D, D, ga0, ga1, D, s.X, D, w.W, D};
+    g.nb = g_batch.nb; g.zA = zs(ga0); g.zB = zs(s.X); g.zC = zs(w.W);
     e = launch_gemm(!s.fwd, g, st);
   }
   if (e != hipSuccess) return e;
@@ -706,6 +740,11 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
   a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
   a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr; a.jv = s.jv; a.vbase = s.vbase;
   a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout;
+  if (g_batch.nb > 1) {
+    a.nb = g_batch.nb;
+    a.zW = zs(a.W); a.zE = zs(a.E0); a.zJ = zs(a.J); a.zBase = zs(a.base); a.zK = zs(a.K1); a.zOut = zs(a.out);
+    a.zA = zs(a.A0); a.zX = zs(a.x); a.zEv = zs(a.e0); a.zJv = zs(a.jv); a.zVb = zs(a.vbase); a.zKv = zs(a.k1v); a.zVo = zs(a.vout);
+  }
   return launch_stage(a, st);
 }
 }  // namespace
@@ -717,8 +756,10 @@ hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, c
   const size_t DD = (size_t)D * D;
   const Work w = carve_work(ws, D);
   const double h = 0.5 * dt;
-  LD_TRY(hipMemcpyAsync(S, S0, DD * sizeof(double), hipMemcpyDeviceToDevice, st));
-  LD_TRY(hipMemcpyAsync(m, m0, D * sizeof(double), hipMemcpyDeviceToDevice, st));
+  for (int p = 0; p < g_batch.nb; p++) {
+    LD_TRY(hipMemcpyAsync(S + p * zs(S), S0, DD * sizeof(double), hipMemcpyDeviceToDevice, st));
+    LD_TRY(hipMemcpyAsync(m + p * zs(m), m0, D * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   for (int k = 0; k < Np - 1; k++) {
     const double *Ak = A + k * DD, *Ak1 = Ak + DD, *bk = b + (size_t)k * D, *bk1 = bk + D;
     const double *Sk = S + k * DD, *mk = m + (size_t)k * D;
@@ -791,8 +832,10 @@ hipError_t ld_solve_bwd(int method, double dt, int D, int Np, const double* A, c
                         const double* jm, const double* js, double* lam, double* psi, double* ws, hipStream_t st,
                         const int32_t* obs_idx) {
   const size_t DD = (size_t)D * D;
-  LD_TRY(hipMemsetAsync(psi + (size_t)(Np - 1) * DD, 0, DD * sizeof(double), st));
-  LD_TRY(hipMemsetAsync(lam + (size_t)(Np - 1) * D, 0, D * sizeof(double), st));
+  for (int p = 0; p < g_batch.nb; p++) {
+    LD_TRY(hipMemsetAsync(psi + p * zs(psi) + (size_t)(Np - 1) * DD, 0, DD * sizeof(double), st));
+    LD_TRY(hipMemsetAsync(lam + p * zs(lam) + (size_t)(Np - 1) * D, 0, D * sizeof(double), st));
+  }
   for (int t = Np - 1; t > 0; t--) {
     const double *Jn, *jn;
     if (obs_idx) {

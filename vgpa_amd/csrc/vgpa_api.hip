@@ -196,8 +196,27 @@ static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
 
 static int ensure_ld_ws(vgpa_ctx* c) {
   if (c->d_ld_ws) return VGPA_OK;
-  return dev_alloc(c, &c->d_ld_ws, ld::ld_workspace_doubles(c->D));
+  return dev_alloc(c, &c->d_ld_ws, (size_t)c->B * ld::ld_workspace_doubles(c->D));
 }
+
+// D > 64 with several problems per context: the per-stage kernels take the batch in grid.z; the drivers look every pointer's
+// per-problem stride up by address (ld::BatchMap).  RAII: the map is thread-local state of large_d.hip.
+struct LdBatch {
+  explicit LdBatch(vgpa_ctx* c) : on(c->B > 1) {
+    if (!on) return;
+    ld::BatchMap m;
+    m.nb = c->B;
+    const size_t NpD = (size_t)c->Np * c->D, NpDD = (size_t)c->Np * c->DD;
+    m.add(c->xcur, c->len_x);
+    m.add(c->d_m, NpD); m.add(c->d_S, NpDD); m.add(c->d_lam, NpD); m.add(c->d_psi, NpDD);
+    m.add(c->d_dEm, NpD); m.add(c->d_dEs, NpDD);
+    m.add(c->d_jm, (size_t)c->M * c->D); m.add(c->d_jm_dense, NpD); m.add(c->d_js_dense, NpDD);
+    m.add(c->d_ld_ws, ld::ld_workspace_doubles(c->D));
+    ld::ld_set_batch(&m);
+  }
+  ~LdBatch() { if (on) ld::ld_set_batch(nullptr); }
+  bool on;
+};
 
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
   ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
@@ -205,6 +224,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
     if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric s0 and sigma");
     int rc = ensure_ld_ws(c);
     if (rc) return rc;
+    LdBatch batch(c);
     hipError_t e = ld::ld_solve_fwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), ctx_b(c), m0, S0, Sigma, c->d_m, c->d_S,
                                     c->d_ld_ws, c->stream);
     if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D forward sweep failed: %s", hipGetErrorString(e));
@@ -231,6 +251,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   if (c->D > kMaxSmallD) {
     if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric dEsde_ds / dEobs_ds");
     if ((rc = ensure_ld_ws(c))) return rc;
+    LdBatch batch(c);
     // operator-level calls bring dense jump arrays; the fused sweep uses the sparse ones (obs index on the host)
     hipError_t e = dense_jumps
         ? ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm_dense, c->d_js_dense,
@@ -281,9 +302,14 @@ static int run_energy(vgpa_ctx* c, double* edf) {
     if (c->cfg.model != VGPA_MODEL_L96) return fail(c, VGPA_ERR_UNSUPPORTED, "large-D energy terms exist for Lorenz-96 only");
     int rc = ensure_lde_ws(c);
     if (rc) return rc;
-    hipError_t e = ld::lde_energy(c->D, c->Np, c->theta[0], c->d_isg, ctx_A(c), ctx_b(c), c->d_m, c->d_S, c->d_et, c->d_Ef, edf,
-                                  c->d_dEm, c->d_dEs, c->d_status, c->d_lde_ws, c->lde_nb, c->stream);
-    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
+    // the energy terms are batched over grid points already: problem by problem
+    const size_t NpD = (size_t)c->Np * c->D, NpDD = (size_t)c->Np * c->DD;
+    for (int p = 0; p < c->B; p++) {
+      hipError_t e = ld::lde_energy(c->D, c->Np, c->theta[0], c->d_isg, ctx_A(c) + p * c->len_x, ctx_b(c) + p * c->len_x, c->d_m + p * NpD,
+                                    c->d_S + p * NpDD, c->d_et + (size_t)p * c->Np, c->d_Ef + p * NpD, edf ? edf + p * NpDD : nullptr,
+                                    c->d_dEm + p * NpD, c->d_dEs + p * NpDD, c->d_status + p, c->d_lde_ws, c->lde_nb, c->stream);
+      if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
+    }
     return VGPA_OK;
   }
   EnergyArgs a = energy_args(c, edf);
@@ -316,9 +342,14 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
     if (!c->sigma_diag) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D gradient needs a diagonal system noise matrix");
     int rc = ensure_lde_ws(c);
     if (rc) return rc;
-    hipError_t e = ld::lde_grad(c->D, c->Np, c->cfg.dt, c->d_isg, ctx_A(c), ctx_b(c), c->d_m, c->d_S, c->d_lam, c->d_psi, c->d_Ef,
-                                g_dev, g_dev + (size_t)c->Np * c->DD, c->d_lde_ws, c->lde_nb, c->stream);
-    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
+    const size_t NpD = (size_t)c->Np * c->D, NpDD = (size_t)c->Np * c->DD;
+    for (int p = 0; p < c->B; p++) {
+      double* gp = g_dev + p * c->len_x;
+      hipError_t e = ld::lde_grad(c->D, c->Np, c->cfg.dt, c->d_isg, ctx_A(c) + p * c->len_x, ctx_b(c) + p * c->len_x, c->d_m + p * NpD,
+                                  c->d_S + p * NpDD, c->d_lam + p * NpD, c->d_psi + p * NpDD, c->d_Ef + p * NpD, gp, gp + NpDD, c->d_lde_ws,
+                                  c->lde_nb, c->stream);
+      if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
+    }
     return VGPA_OK;
   }
   GradArgs a{};
@@ -491,7 +522,6 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   if (cfg->dim_d > kMaxSmallD && cfg->model != VGPA_MODEL_NONE && cfg->model != VGPA_MODEL_L96)
     return fail(nullptr, VGPA_ERR_UNSUPPORTED, "D=%d > %d is built for the ODE operators (model NONE) and for Lorenz-96 only",
                 cfg->dim_d, kMaxSmallD);
-  if (cfg->dim_d > kMaxSmallD && cfg->batch != 1) return fail(nullptr, VGPA_ERR_UNSUPPORTED, "large-D contexts hold one problem");
   const int need_theta = (cfg->model == VGPA_MODEL_L63) ? 3 : (cfg->model == VGPA_MODEL_NONE ? 0 : 1);
   if (cfg->n_theta != need_theta || (need_theta > 0 && !cfg->theta)) return fail(nullptr, VGPA_ERR_ARG, "model needs %d drift parameter(s)", need_theta);
   if (!cfg->sigma) return fail(nullptr, VGPA_ERR_ARG, "sigma is required");
@@ -652,6 +682,8 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
     HTRY(hipMemGetInfo(&free_b, &total_b));
     const double need = 8.0 * (double)BN * (double)DD * 4.0;        // dEs + Psi + the caller's x and g still to come
     c->stream_ld = (cfg->flags & VGPA_FLAG_STREAM_LARGE_D) != 0 || need > 0.9 * (double)free_b;
+    if (c->stream_ld && c->B > 1)
+      return fail(nullptr, VGPA_ERR_UNSUPPORTED, "the time-chunked large-D sweep holds one problem (a batch of %d does not fit resident)", c->B);
     c->lde_budget = std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b));   // workspace of the batched energy terms
     c->ld_chunk = ld::lde_batch(D, c->lde_budget) - 1;   // a chunk evaluates ld_chunk + 1 grid points: exactly one energy batch
     if (c->ld_chunk > c->Np - 1) c->ld_chunk = c->Np - 1;

@@ -120,6 +120,19 @@ hipError_t launch_edf(const EnergyArgs& a, hipStream_t st);   // dense <df/dx> o
 
 // large-D (per-stage GEMM) single-rank drivers, large_d.hip
 namespace ld {
+// address ranges of the arrays of a batched context and their per-problem strides (ld_set_batch; see large_d.hip)
+struct BatchMap {
+  int nb = 1, n = 0;
+  struct R { const double* lo; const double* hi; size_t stride; } r[16];
+  void add(const double* base, size_t per_problem) {
+    if (base && per_problem && n < 16) { r[n].lo = base; r[n].hi = base + (size_t)nb * per_problem; r[n].stride = per_problem; n++; }
+  }
+  size_t stride(const double* p) const {
+    for (int i = 0; i < n; i++) if (p >= r[i].lo && p < r[i].hi) return r[i].stride;
+    return 0;
+  }
+};
+void ld_set_batch(const BatchMap* map_or_null);      // thread-local; nullptr = one problem
 size_t ld_workspace_doubles(int D);
 hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, const double* b, const double* m0,
                         const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st);
