@@ -107,10 +107,9 @@ typedef struct {
  *   - D > 64 for OU / DW / L63 (their D is 1 / 1 / 3 by definition) -- D > 64 exists for Lorenz-96 and for the bare ODE
  *     operators (model NONE);
  *   - D > 64 with a non-symmetric s0 / sigma / dEsde_dS / dEobs_dS (the large-D path uses W + W^T; for D <= 64 the
- *     generic kernels take any input) or with a dense (non-diagonal) system noise in the gradient; batch > 1 at D > 64
+ *     generic kernels take any input).  Dense Sigma, S0, R and H are fine at every D; batch > 1 at D > 64
  *     runs the per-stage kernels with the problems in grid.z (what fills the chip for 64 < D <= 512) and is refused only
  *     by the time-chunked sweep (a batch that does not fit resident);
- *   - the hyper-parameter members of <model>.energy() (vgpa_energy_full's dEsde_dth / dEsde_dsig) for D > 64;
  *   - VGPA_FETCH_PSIT / VGPA_FETCH_DESDE_DS in the time-chunked large-D sweep (they are never resident there).
  * The matrix-core stepping kernels cover D <= 64 with symmetric inputs; non-symmetric operator-level inputs run on the
  * generic LDS kernels (same results, ~15x slower at D = 40). */

@@ -388,6 +388,46 @@ def test_batched_contexts_above_64(d, n, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,method", [(72, "rk4"), (96, "heun"), (128, "rk4")])
+def test_dense_noise_matrices_above_64(d, method):
+    """D > 64 with a DENSE system noise Sigma (the gradient takes any Sigma^-1, variational.py:320,332: one more batched product),
+    dense S0, dense observation noise R and a non-identity observation operator H: fused sweep and state arrays vs the oracle."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    rng = np.random.default_rng(d)
+    h = np.eye(d) + 0.1 * rng.standard_normal((d, d)) / np.sqrt(d)
+    p, x = make_problem("L96", d, 8, method=method, dense=True, h_op=h)
+    f_o, g_o, st_o = vo.sweep(p, x, faithful=False)
+    ctx = gpu_context(p)
+    f, g = ctx.sweep(x)
+    assert abs(f - f_o) <= TOL * abs(f_o), (f, f_o)
+    assert rel_err(g, g_o) < TOL
+    for key in ("mt", "st", "lamt", "psit"):
+        assert rel_err(np.asarray(ctx.fetch(key)).reshape(np.shape(st_o[key])), st_o[key]) < TOL, key
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [72, 100])
+def test_hyper_parameter_members_above_64(d):
+    """dEsde_dth / dEsde_dSig of Lorenz96.energy (lorenz_96.py:421-434: computed by the reference, consumed by nothing) at D > 64,
+    through the mirror of the reference's model class."""
+    from helpers import make_model
+    from test_gpu_edge_cases import make_problem
+    p, x = make_problem("L96", d, 7, method="rk4")
+    a, b = p.split(x)
+    mt, st = vo.solve_fwd("rk4", p.dt, False, a, b, p.m0, p.s0, p.sigma)
+    want = vo.energy_l96(p.theta, p.inverse_sigma, p.dt, a, b, mt, st, list(p.obs_t), faithful=False)
+    model = make_model("L96", d)
+    model.sigma = p.sigma
+    model.sample_path, model.time_window = np.zeros((7, d)), np.arange(7) * p.dt
+    esde, (ef, edf), (dm, ds, dth, dsig) = model.energy(a, b, mt, st, list(p.obs_t))
+    assert abs(esde - want[0]) <= TOL * abs(want[0])
+    assert rel_err(ef, want[1][0]) < TOL and rel_err(dm, want[2][0]) < TOL and rel_err(ds, want[2][1]) < TOL
+    assert rel_err(np.asarray(dth), want[2][2]) < TOL
+    assert rel_err(np.asarray(dsig), want[2][3]) < TOL
+
+
+@pytest.mark.gpu
 def test_batched_operators_above_64():
     """Operator-level calls (FwdOde / BwdOde contract) with three problems at D = 96: problem-major inputs, every problem
     against the oracle."""

@@ -327,7 +327,7 @@ class Context:
         return self._squeeze(lam), self._squeeze(psi)
 
     def energy(self, lin_a, off_b, mt, st, want_edf=True, want_hyper=False):
-        """(Esde, Ef, Edf, dEsde_dm, dEsde_ds[, dEsde_dth, dEsde_dSig]) -- the last two with want_hyper (D <= 64)."""
+        """(Esde, Ef, Edf, dEsde_dm, dEsde_ds[, dEsde_dth, dEsde_dSig]) -- the last two with want_hyper."""
         a, b, m, s = (_c64(v) for v in (lin_a, off_b, mt, st))
         esde = np.empty(self.B)
         ef, dm = np.empty(self._shape_v()), np.empty(self._shape_v())

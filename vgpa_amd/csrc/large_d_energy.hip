@@ -472,6 +472,45 @@ __global__ void __launch_bounds__(NT) k_finish(int D, double theta, const double
   }
 }
 
+// Integrands of the hyper-parameter members of Lorenz96.energy (lorenz_96.py:421-434; computed by the reference, consumed by
+// nothing): hyp[t][i] = <f>_i + (A m)_i - b_i  (dEsde_dtheta) and hyp[t][D + i] = m_bar_i, the unscented mean of the squared
+// residual of component i (dEsde_dSigma) -- the same residuals as k_resid, summed over the sigma points instead of over the
+// components: thread = component, sequential over the 2D + 1 sigma points.  Flat roll (quirk Q1): the neighbours of flat index
+// f = p D + i are f + 1, f - 1, f - 2 modulo M D.
+__global__ void __launch_bounds__(NT) k_hyper(int D, double theta, const double* L, const double* G, long long sW, const double* m,
+                                              const double* b, long long sb, const double* am, const double* Ef, double* hyp) {
+  const int M = 2 * D + 1;
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= D) return;
+  const int t = blockIdx.y;
+  const double* Lm = L + (long long)t * sW;
+  const double* Gm = G + (long long)t * sW;
+  const double* mv = m + (long long)t * D;
+  const double kappa = 1.05 * D, c = D + kappa, w0 = kappa / c, w1 = 1.0 / (2.0 * c);
+  auto chi = [&](long long f) {          // element of the flattened sigma-point matrix
+    const long long MD = (long long)M * D;
+    if (f < 0) f += MD;
+    if (f >= MD) f -= MD;
+    const int q = (int)(f / D), ii = (int)(f - (long long)q * D);
+    const int col = q == 0 ? 0 : (q <= D ? q - 1 : q - 1 - D);
+    const double sg = q == 0 ? 0.0 : (q <= D ? 1.0 : -1.0);
+    return mv[ii] + sg * Lm[(long long)ii * D + col];
+  };
+  const double bi = b[(long long)t * sb + i], ami = am[(long long)t * D + i];
+  double acc = 0.0;
+  for (int p = 0; p < M; p++) {
+    const long long f = (long long)p * D + i;
+    const int col = p == 0 ? 0 : (p <= D ? p - 1 : p - 1 - D);
+    const double sg = p == 0 ? 0.0 : (p <= D ? 1.0 : -1.0);
+    const double lin = ami + sg * Gm[(long long)i * D + col];
+    const double res = ((chi(f + 1) - chi(f - 2)) * chi(f - 1) - chi(f) + theta) + lin - bi;
+    acc += (p == 0 ? w0 : w1) * (res * res);
+  }
+  double* h = hyp + (long long)t * 2 * D;
+  h[i] = Ef[(long long)t * D + i] + ami - bi;
+  h[D + i] = acc;
+}
+
 // Y[k][j] = q_k X[k][j]
 __global__ void __launch_bounds__(NT) k_scale_rows(int D, const double* X, const double* q, double* Y, long long sW) {
   const double* x = X + (long long)blockIdx.y * sW;
@@ -518,6 +557,45 @@ __global__ void __launch_bounds__(NT) k_grad_q(int D, const double* isg, const d
   }
 }
 
+// dense Sigma^-1 (variational.py:320,332 take any inverse noise matrix): T = <df/dx>(m) + A and Q0 = -2 Psi, so that one
+// batched product Q = Sigma^-1 T + Q0 finishes Q; w = -Ef - A m + b, so that u = Sigma^-1 w + lam
+__global__ void __launch_bounds__(NT) k_grad_q_dense(int D, const double* A, const double* m, const double* psi, double* T, double* Q) {
+  const long long DD = (long long)D * D;
+  const double* a = A + (long long)blockIdx.y * DD;
+  const double* ps = psi + (long long)blockIdx.y * DD;
+  const double* mv = m + (long long)blockIdx.y * D;
+  double* tq = T + (long long)blockIdx.y * DD;
+  double* q = Q + (long long)blockIdx.y * DD;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int k = (int)(e / D), j = (int)(e - (long long)k * D);
+    const int kp1 = wrapi(k + 1, D), km1 = wrapi(k - 1, D), km2 = wrapi(k - 2, D);
+    double ed = 0.0;
+    if (j == k) ed = -1.0;
+    if (j == kp1) ed = mv[km1];
+    if (j == km2) ed = -mv[km1];
+    if (j == km1) ed = mv[kp1] - mv[km2];
+    tq[e] = ed + a[e];
+    q[e] = -2.0 * ps[e];
+  }
+}
+__global__ void __launch_bounds__(NT) k_grad_w(int D, const double* am, const double* b, const double* Ef, double* w) {
+  const long long vo = (long long)blockIdx.y * D;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < D; i += gridDim.x * NT) w[vo + i] = -Ef[vo + i] - am[vo + i] + b[vo + i];
+}
+// gA = dt (QS - u m^T) in place on QS ; gB = dt u ; u = u0 + lam with u0 = Sigma^-1 w
+__global__ void __launch_bounds__(NT) k_grad_fin_dense(int D, double dt, const double* u0, const double* m, const double* lam, double* gA,
+                                                       double* gB) {
+  const long long DD = (long long)D * D;
+  const long long vo = (long long)blockIdx.y * D;
+  double* g = gA + (long long)blockIdx.y * DD;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < DD; e += (long long)gridDim.x * NT) {
+    const int i = (int)(e / D), j = (int)(e - (long long)i * D);
+    const double u = u0[vo + i] + lam[vo + i];
+    g[e] = dt * (g[e] - u * m[vo + j]);
+    if (j == 0) gB[vo + i] = dt * u;
+  }
+}
+
 // gA = dt (QS - u m^T) in place on QS ; gB = dt u ; u_i = isg_i (-Ef_i - (A m)_i + b_i) + lam_i
 __global__ void __launch_bounds__(NT) k_grad_fin(int D, double dt, const double* isg, const double* am, const double* b,
                                                  const double* m, const double* lam, const double* Ef, double* gA, double* gB) {
@@ -554,7 +632,7 @@ int lde_batch(int D, double budget_bytes) {
 // Energy terms of Np grid points of ONE problem.  Edf may be nullptr.
 hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
                       const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
-                      double* ws, int nbmax, hipStream_t st) {
+                      double* ws, int nbmax, hipStream_t st, double* hyp) {
   using namespace lde;
   const long long DD = (long long)D * D;
   const int T = (D + NBLK - 1) / NBLK, M = 2 * D + 1;
@@ -624,6 +702,9 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
                        isg, vv, (long long)M);
     hipLaunchKernelGGL(k_finish, dim3(nb), dim3(NT), 0, st, D, theta, vv, (long long)M, St, mt, e_t + t0, dl, qq,
                        Ef + (size_t)t0 * D);
+    if (hyp)
+      hipLaunchKernelGGL(k_hyper, dim3((D + NT - 1) / NT, nb), dim3(NT), 0, st, D, theta, C, G, DD, mt, bt, (long long)D, am,
+                         Ef + (size_t)t0 * D, hyp + (size_t)t0 * 2 * D);
     // ---- dE/dm = c/2 X^T delta ; dE/dS = c/2 X^T diag(q) X
     hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 1, X, DD, dl, (long long)D,
                        dEm + (size_t)t0 * D, (long long)D, 0.5 * c);
@@ -643,14 +724,36 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
 //   Q = Sigma^-1 (Edf + A) - 2 Psi ;  gLa = dt (Q S - u m^T) ;  u = Sigma^-1 (-Ef - A m + b) + lam ;  gLb = dt u
 hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A, const double* b, const double* m,
                     const double* S, const double* lam, const double* psi, const double* Ef, double* gA, double* gB,
-                    double* ws, int nbmax, hipStream_t st) {
+                    double* ws, int nbmax, hipStream_t st, const double* isig_dense) {
   using namespace lde;
   const long long DD = (long long)D * D;
   for (int t0 = 0; t0 < Np; t0 += nbmax) {
     const int nb = (Np - t0 < nbmax) ? (Np - t0) : nbmax;
     double* Q = ws;                                    // [nb][D][D]
-    double* am = Q + (size_t)nb * DD;                  // [nb][D]
+    double* T = Q + (size_t)nb * DD;                   // [nb][D][D]  dense Sigma^-1 only
+    double* am = T + (size_t)nb * DD;                  // [nb][D]
+    double* wv = am + (size_t)nb * D;                  // [nb][D]     dense only
+    double* u0 = wv + (size_t)nb * D;                  // [nb][D]     dense only
     const int eg = (int)((DD + NT * 8 - 1) / (NT * 8));
+    if (isig_dense) {
+      hipLaunchKernelGGL(k_grad_q_dense, dim3(eg, nb), dim3(NT), 0, st, D, A + (size_t)t0 * DD, m + (size_t)t0 * D, psi + (size_t)t0 * DD, T, Q);
+      GemmB q{};     // Q = Sigma^-1 T - 2 Psi   (Sigma^-1 shared by the grid points: stride 0)
+      q.M = D; q.N = D; q.K = D; q.A = isig_dense; q.lda = D; q.sA = 0; q.B = T; q.ldb = D; q.sB = DD; q.C = Q; q.ldc = D; q.sC = DD;
+      q.alpha = 1.0; q.beta = 1.0;
+      LDE_TRY(gemm_b(false, false, q, nb, st));
+      hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, A + (size_t)t0 * DD, DD, m + (size_t)t0 * D,
+                         (long long)D, am, (long long)D, 1.0);
+      hipLaunchKernelGGL(k_grad_w, dim3((D + NT - 1) / NT, nb), dim3(NT), 0, st, D, am, b + (size_t)t0 * D, Ef + (size_t)t0 * D, wv);
+      hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, isig_dense, 0LL, wv, (long long)D, u0, (long long)D, 1.0);
+      GemmB g{};
+      g.M = D; g.N = D; g.K = D; g.A = Q; g.lda = D; g.sA = DD; g.B = S + (size_t)t0 * DD; g.ldb = D; g.sB = DD;
+      g.C = gA + (size_t)t0 * DD; g.ldc = D; g.sC = DD; g.alpha = 1.0; g.beta = 0.0;
+      LDE_TRY(gemm_b(false, false, g, nb, st));
+      hipLaunchKernelGGL(k_grad_fin_dense, dim3(eg, nb), dim3(NT), 0, st, D, dt, u0, m + (size_t)t0 * D, lam + (size_t)t0 * D,
+                         gA + (size_t)t0 * DD, gB + (size_t)t0 * D);
+      LDE_TRY(hipGetLastError());
+      continue;
+    }
     hipLaunchKernelGGL(k_grad_q, dim3(eg, nb), dim3(NT), 0, st, D, isg, A + (size_t)t0 * DD, m + (size_t)t0 * D,
                        psi + (size_t)t0 * DD, Q);
     hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, A + (size_t)t0 * DD, DD, m + (size_t)t0 * D,

@@ -307,7 +307,8 @@ static int run_energy(vgpa_ctx* c, double* edf) {
     for (int p = 0; p < c->B; p++) {
       hipError_t e = ld::lde_energy(c->D, c->Np, c->theta[0], c->d_isg, ctx_A(c) + p * c->len_x, ctx_b(c) + p * c->len_x, c->d_m + p * NpD,
                                     c->d_S + p * NpDD, c->d_et + (size_t)p * c->Np, c->d_Ef + p * NpD, edf ? edf + p * NpDD : nullptr,
-                                    c->d_dEm + p * NpD, c->d_dEs + p * NpDD, c->d_status + p, c->d_lde_ws, c->lde_nb, c->stream);
+                                    c->d_dEm + p * NpD, c->d_dEs + p * NpDD, c->d_status + p, c->d_lde_ws, c->lde_nb, c->stream,
+                                    c->hyp_on ? c->d_hyp + (size_t)p * c->Np * 2 * c->D : nullptr);
       if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
     }
     return VGPA_OK;
@@ -339,7 +340,6 @@ static int run_reduce(vgpa_ctx* c) {
 
 static int run_grad(vgpa_ctx* c, double* g_dev) {
   if (c->D > kMaxSmallD) {
-    if (!c->sigma_diag) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D gradient needs a diagonal system noise matrix");
     int rc = ensure_lde_ws(c);
     if (rc) return rc;
     const size_t NpD = (size_t)c->Np * c->D, NpDD = (size_t)c->Np * c->DD;
@@ -347,7 +347,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
       double* gp = g_dev + p * c->len_x;
       hipError_t e = ld::lde_grad(c->D, c->Np, c->cfg.dt, c->d_isg, ctx_A(c) + p * c->len_x, ctx_b(c) + p * c->len_x, c->d_m + p * NpD,
                                   c->d_S + p * NpDD, c->d_lam + p * NpD, c->d_psi + p * NpDD, c->d_Ef + p * NpD, gp, gp + NpDD, c->d_lde_ws,
-                                  c->lde_nb, c->stream);
+                                  c->lde_nb, c->stream, c->sigma_diag ? nullptr : c->d_isig);
       if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
     }
     return VGPA_OK;
@@ -381,7 +381,6 @@ static int stream_pass(vgpa_ctx* c, double* g_dev) {
   if ((rc = ensure_ld_ws(c))) return rc;
   if ((rc = ensure(c, &c->d_dEs_c, (size_t)(C + 1) * DD))) return rc;
   if (g_dev && (rc = ensure(c, &c->d_psi_c, (size_t)(C + 1) * DD))) return rc;
-  if (g_dev && !c->sigma_diag) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D gradient needs a diagonal system noise matrix");
   const double *A = ctx_A(c), *b = ctx_b(c);
   hipStream_t st = c->stream;
   int t1 = Np - 1;
@@ -414,7 +413,7 @@ static int stream_pass(vgpa_ctx* c, double* g_dev) {
       double* gB = g_dev + (size_t)Np * DD + (size_t)g0 * D;
       e = ld::lde_grad(D, gn, c->cfg.dt, c->d_isg, A + (size_t)g0 * DD, b + (size_t)g0 * D, c->d_m + (size_t)g0 * D,
                        c->d_S + (size_t)g0 * DD, c->d_lam + (size_t)g0 * D, c->d_psi_c + (size_t)(g0 - t0) * DD,
-                       c->d_Ef + (size_t)g0 * D, gA, gB, c->d_lde_ws, c->lde_nb, st);
+                       c->d_Ef + (size_t)g0 * D, gA, gB, c->d_lde_ws, c->lde_nb, st, c->sigma_diag ? nullptr : c->d_isig);
       if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D gradient failed: %s", hipGetErrorString(e));
     }
     if (t0 == 0) break;
@@ -763,7 +762,6 @@ int vgpa_energy_full(vgpa_ctx* c, const double* lin_a, const double* off_b, cons
   if ((desde_dth != nullptr) != (desde_dsig != nullptr)) return fail(c, VGPA_ERR_ARG, "dEsde_dth and dEsde_dsig come together");
   const bool hyper = desde_dth != nullptr;
   if (hyper && c->cfg.model == VGPA_MODEL_NONE) return fail(c, VGPA_ERR_STATE, "context has no stochastic model");
-  if (hyper && c->D > kMaxSmallD) return fail(c, VGPA_ERR_UNSUPPORTED, "hyper-parameter gradients are built for D <= %d", kMaxSmallD);
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const int D = c->D;
   const int H = c->single ? 1 : 2 * D;

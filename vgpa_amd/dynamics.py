@@ -132,9 +132,6 @@ class StochasticProcess(object):
             return esde, (ef.reshape(n), edf.reshape(n)), (dm.reshape(n), ds.reshape(n), dth, dsg)
         n, d = m.shape
         ctx = self._ctx_for(n, d)
-        if d > 64:     # the hyper-parameter members (unused by VarGP) are not built for the large-D path
-            esde, ef, edf, dm, ds = ctx.energy(linear_a, offset_b, m, s)
-            return esde, (ef, edf), (dm, ds, None, None)
         esde, ef, edf, dm, ds, dth, dsg = ctx.energy(linear_a, offset_b, m, s, want_hyper=True)
         return esde, (ef, edf), (dm, ds, dth, dsg)
 
