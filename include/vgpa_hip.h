@@ -106,10 +106,10 @@ typedef struct {
 /* What the library does NOT build (VGPA_ERR_UNSUPPORTED; the reference's numpy handles these at its own speed):
  *   - D > 64 for OU / DW / L63 (their D is 1 / 1 / 3 by definition) -- D > 64 exists for Lorenz-96 and for the bare ODE
  *     operators (model NONE);
- *   - D > 64 with a non-symmetric s0 / sigma / dEsde_dS / dEobs_dS (the large-D path uses W + W^T; for D <= 64 the
- *     generic kernels take any input).  Dense Sigma, S0, R and H are fine at every D; batch > 1 at D > 64
- *     runs the per-stage kernels with the problems in grid.z (what fills the chip for 64 < D <= 512) and is refused only
- *     by the time-chunked sweep (a batch that does not fit resident);
+ *   - batch > 1 in the TIME-CHUNKED large-D sweep (a batch that does not fit resident).  Everything else of D > 64 is built:
+ *     dense Sigma / S0 / R / H, several problems per context (the per-stage kernels take them in grid.z: what fills the chip
+ *     for 64 < D <= 512), the hyper-parameter members, non-symmetric operator-level inputs (both products of the slope
+ *     formed literally; the fused sweep and the row-sharded drivers assume the symmetric S0 / Sigma every real run has);
  *   - VGPA_FETCH_PSIT / VGPA_FETCH_DESDE_DS in the time-chunked large-D sweep (they are never resident there).
  * The matrix-core stepping kernels cover D <= 64 with symmetric inputs; non-symmetric operator-level inputs run on the
  * generic LDS kernels (same results, ~15x slower at D = 40). */

@@ -428,6 +428,31 @@ def test_hyper_parameter_members_above_64(d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+@pytest.mark.parametrize("d", [80, 130])
+def test_non_symmetric_operator_inputs_above_64(d, method):
+    """Operator-level calls with a non-symmetric S0 / dEsde_dS / matrix jump at D > 64 follow A.S + S.A^T and Psi.A + A^T.Psi
+    literally (ode_solver.py:60,94) -- no symmetry shortcut, like the generic kernels at D <= 64."""
+    import vgpa_amd as va
+    rng = np.random.default_rng(d)
+    n = 9
+    a = 2.0 * np.eye(d) + 0.3 * rng.standard_normal((n, d, d)) / np.sqrt(d)
+    b = rng.standard_normal((n, d))
+    s0 = 0.2 * np.eye(d) + 0.02 * rng.standard_normal((d, d)) / np.sqrt(d)
+    sigma = np.diag(1.0 + rng.random(d))
+    mt, st = va.FwdOde(0.01, method, False)(a, b, np.zeros(d), s0, sigma)
+    mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, np.zeros(d), s0, sigma)
+    assert rel_err(mt, mt_o) < TOL and rel_err(st, st_o) < TOL
+    assert rel_err(st, np.swapaxes(st, 1, 2)) > 1e-6                     # the result really is non-symmetric
+    g = rng.standard_normal((n, d, d)) / np.sqrt(d)
+    js = np.zeros((n, d, d)); js[4] = rng.standard_normal((d, d)) / np.sqrt(d)
+    gm, jm = rng.standard_normal((n, d)), np.zeros((n, d))
+    lam, psi = va.BwdOde(0.01, method, False)(a, gm, g, jm, js)
+    lam_o, psi_o = vo.solve_bwd(method, 0.01, False, a, gm, g, jm, js)
+    assert rel_err(lam, lam_o) < TOL and rel_err(psi, psi_o) < TOL
+
+
+@pytest.mark.gpu
 def test_batched_operators_above_64():
     """Operator-level calls (FwdOde / BwdOde contract) with three problems at D = 96: problem-major inputs, every problem
     against the oracle."""

@@ -675,12 +675,35 @@ void ld_set_batch(const BatchMap* m) { g_batch = m ? *m : BatchMap{}; }
 static inline size_t zs(const double* p) { return g_batch.nb > 1 ? g_batch.stride(p) : 0; }
 
 thread_local bool use_library_gemm = false;
+// Non-symmetric operator-level inputs (S0, dEsde_dS, jumps that are not symmetric): the shortcut S A^T = (A S)^T does not hold,
+// so the second product of ode_solver.py:60,94 is formed literally -- Z = A_s X^T (forward) / A_s^T Psi^T (backward) from a
+// transposed copy of the stage state, handed to the stage kernel as its column operand: Z[j][r] = (X A^T)[r][j] / (Psi A)[r][j].
+thread_local bool literal_products = false;
+void ld_set_literal_products(bool on) { literal_products = on; }
 
-size_t ld_workspace_doubles(int D) { return (size_t)6 * D * D + 4 * (size_t)D; }
+size_t ld_workspace_doubles(int D) { return (size_t)8 * D * D + 4 * (size_t)D; }
+
+__global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ X, double* __restrict__ Xt, int D, size_t zin, size_t zout) {
+  __shared__ double tile[32][33];
+  X += blockIdx.z * zin; Xt += blockIdx.z * zout;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int r = r0 + ty + 8 * q, c = c0 + tx;
+    tile[ty + 8 * q][tx] = (r < D && c < D) ? X[(size_t)r * D + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int r = c0 + ty + 8 * q, c = r0 + tx;
+    if (r < D && c < D) Xt[(size_t)r * D + c] = tile[tx][ty + 8 * q];
+  }
+}
 
 namespace {
 struct Work {
-  double *W, *K1, *K23, *XA, *XB, *AM, *xvA, *xvB, *k1v, *k23v;
+  double *W, *K1, *K23, *XA, *XB, *AM, *XT, *W2, *xvA, *xvB, *k1v, *k23v;
 };
 // which pair of operands the mid-point buffer AM currently averages (valid inside one step)
 struct MidCache { const double* a0 = nullptr; const double* a1 = nullptr; };
@@ -688,8 +711,8 @@ Work carve_work(double* ws, int D) {
   const size_t DD = (size_t)D * D;
   Work w;
   w.W = ws; w.K1 = w.W + DD; w.K23 = w.K1 + DD; w.XA = w.K23 + DD; w.XB = w.XA + DD;
-  w.AM = w.XB + DD;
-  w.xvA = w.AM + DD; w.xvB = w.xvA + D; w.k1v = w.xvB + D; w.k23v = w.k1v + D;
+  w.AM = w.XB + DD; w.XT = w.AM + DD; w.W2 = w.XT + DD;
+  w.xvA = w.W2 + DD; w.xvB = w.xvA + D; w.k1v = w.xvB + D; w.k23v = w.k1v + D;
   return w;
 }
 
@@ -717,7 +740,7 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
     ga0 = w.AM; ga1 = nullptr;
   }
   hipError_t e;
-  if (use_library_gemm && !ga1 && g_batch.nb == 1) {
+  if (use_library_gemm && !ga1 && g_batch.nb == 1 && !literal_products) {
     // plain GEMM, one rank: cw = D is plain row-major.  Backward: W' = A^T.Psi would be a transposed-A product (slow in
     // the library at D = 1024); Psi is symmetric, so Z = Psi.A = W'^T is computed instead -- the stage kernel uses W'
     // and W'^T symmetrically (R = -G + W' + W'^T), only the order of its two additions changes.
@@ -732,11 +755,19 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
     e = launch_gemm(!s.fwd, g, st);
   }
   if (e != hipSuccess) return e;
+  if (literal_products) {
+    const int nt = (D + 31) / 32;
+    hipLaunchKernelGGL(k_transpose, dim3(nt, nt, g_batch.nb), dim3(256), 0, st, s.X, w.XT, D, zs(s.X), zs(w.XT));
+    GemmArgs g2{D, D, D, ga0, ga1, D, w.XT, D, w.W2, D};
+    g2.nb = g_batch.nb; g2.zA = zs(ga0); g2.zB = zs(w.XT); g2.zC = zs(w.W2);
+    e = launch_gemm(!s.fwd, g2, st);
+    if (e != hipSuccess) return e;
+  }
   StageArgs a{};
   a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
-  a.sym_ok = 1;
+  a.sym_ok = literal_products ? 0 : 1;
   a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
-  a.W = w.W; a.Wcol = w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
+  a.W = w.W; a.Wcol = literal_products ? w.W2 : w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
   a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
   a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr; a.jv = s.jv; a.vbase = s.vbase;
   a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout;

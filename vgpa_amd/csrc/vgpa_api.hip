@@ -201,6 +201,11 @@ static int ensure_ld_ws(vgpa_ctx* c) {
 
 // D > 64 with several problems per context: the per-stage kernels take the batch in grid.z; the drivers look every pointer's
 // per-problem stride up by address (ld::BatchMap).  RAII: the map is thread-local state of large_d.hip.
+struct LdLiteral {
+  explicit LdLiteral(bool on_) : on(on_) { if (on) ld::ld_set_literal_products(true); }
+  ~LdLiteral() { if (on) ld::ld_set_literal_products(false); }
+  bool on;
+};
 struct LdBatch {
   explicit LdBatch(vgpa_ctx* c) : on(c->B > 1) {
     if (!on) return;
@@ -221,10 +226,10 @@ struct LdBatch {
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
   ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
   if (c->D > kMaxSmallD) {
-    if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric s0 and sigma");
     int rc = ensure_ld_ws(c);
     if (rc) return rc;
     LdBatch batch(c);
+    LdLiteral literal(!sym);             // non-symmetric s0 / sigma: both products of the slope literally (ode_solver.py:60)
     hipError_t e = ld::ld_solve_fwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), ctx_b(c), m0, S0, Sigma, c->d_m, c->d_S,
                                     c->d_ld_ws, c->stream);
     if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D forward sweep failed: %s", hipGetErrorString(e));
@@ -249,9 +254,9 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   if ((rc = ensure(c, &c->d_psi, (size_t)c->B * c->Np * c->DD))) return rc;
   if ((rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD))) return rc;
   if (c->D > kMaxSmallD) {
-    if (!sym) return fail(c, VGPA_ERR_UNSUPPORTED, "the large-D path needs symmetric dEsde_ds / dEobs_ds");
     if ((rc = ensure_ld_ws(c))) return rc;
     LdBatch batch(c);
+    LdLiteral literal(!sym);             // non-symmetric dEsde_ds / dEobs_ds (ode_solver.py:94)
     // operator-level calls bring dense jump arrays; the fused sweep uses the sparse ones (obs index on the host)
     hipError_t e = dense_jumps
         ? ld::ld_solve_bwd(c->cfg.method, c->cfg.dt, c->D, c->Np, ctx_A(c), c->d_dEm, c->d_dEs, c->d_jm_dense, c->d_js_dense,

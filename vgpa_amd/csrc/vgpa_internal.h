@@ -133,6 +133,7 @@ struct BatchMap {
   }
 };
 void ld_set_batch(const BatchMap* map_or_null);      // thread-local; nullptr = one problem
+void ld_set_literal_products(bool on);               // thread-local: non-symmetric inputs, both products of the slope literally
 size_t ld_workspace_doubles(int D);
 hipError_t ld_solve_fwd(int method, double dt, int D, int Np, const double* A, const double* b, const double* m0,
                         const double* S0, const double* Sigma, double* m, double* S, double* ws, hipStream_t st);
