@@ -924,6 +924,64 @@ def test_native_sharded_sweep_outcome_is_collective():
     assert all(abs(o[2] + e0 - f_o) <= TOL * abs(f_o) for o in out)
 
 
+def _spawn_ranks(world, d, n, method, out_dir, fail=False, timeout=300):
+    """`world` worker PROCESSES (tests/_shard_worker.py) on GPU 0; returns their exit codes."""
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), str(r), str(world), str(port), str(d),
+                               str(n), method, str(out_dir)] + (["fail"] if fail else []), env=env) for r in range(world)]
+    codes = []
+    for pr in procs:
+        try:
+            codes.append(pr.wait(timeout=timeout))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            codes.append(-9)
+    return codes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,d,n,world", [("rk4", 128, 9, 2), ("heun", 192, 7, 3)])
+def test_native_sharded_sweep_with_real_processes(method, d, n, world, tmp_path):
+    """The native driver as it is deployed -- ONE PROCESS PER RANK -- on the one GPU of the test box: `vgpa_shard_sweep_sharded` in
+    2 / 3 separate processes whose vgpa_comm table is HostStagedComm (gloo, data staged through the host; several ranks on one
+    GPU cannot form an RCCL communicator).  Pipelined schedule (point-to-point groups -> batch_isend_irecv), exchanges, the
+    agreement step: F on every rank and every rank's gradient slice vs the oracle."""
+    from test_gpu_edge_cases import make_problem
+    p, x = make_problem("L96", d, n, method=method)
+    f_o, g_o, _ = vo.sweep(p, x, faithful=False)
+    ga_o, gb_o = g_o[:n * d * d].reshape(n, d, d), g_o[n * d * d:].reshape(n, d)
+    codes = _spawn_ranks(world, d, n, method, tmp_path)
+    assert codes == [0] * world, codes
+    covered = []
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert "error" not in z.files, str(z["error"]) if "error" in z.files else ""
+        lo, hi = int(z["lo"]), int(z["hi"])
+        covered.extend(range(lo, hi))
+        assert int(z["chunks"]) > 0                                    # the pipelined gather ran
+        assert abs(float(z["f"]) - f_o) <= TOL * abs(f_o)
+        if hi > lo:
+            assert rel_err(z["ga"], ga_o[lo:hi]) < TOL and rel_err(z["gb"], gb_o[lo:hi]) < TOL
+    assert covered == list(range(n))
+
+
+@pytest.mark.gpu
+def test_native_sharded_sweep_a_dead_process_is_a_timeout_not_a_hang(tmp_path):
+    """One of three rank processes exits before the sweep.  The survivors' collectives cannot complete; their bounded waits
+    (VGPA_SHARD_OPT_TIMEOUT_MS = 20 s here) and the failing gloo calls turn that into VGPA_ERR_COMM -> RuntimeError on every
+    surviving rank, and the processes end by themselves."""
+    import time
+    t0 = time.perf_counter()
+    codes = _spawn_ranks(3, 96, 7, "rk4", tmp_path, fail=True, timeout=240)
+    assert time.perf_counter() - t0 < 200
+    assert codes[2] == 3 and codes[0] == 0 and codes[1] == 0, codes
+    for r in (0, 1):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert "error" in z.files and "collective" in str(z["error"])
+
+
 @pytest.mark.gpu
 def test_native_sharded_fused_sweep_at_config5_matrix_size():
     """BASELINE configs[4] matrix size (D = 4096, RK4, 4-point grid): the fused sweep on 1, 2 and 8 virtual ranks against

@@ -254,6 +254,120 @@ class ShardedRecursion:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _hip_runtime():
+    """ctypes handle of the HIP runtime this process already uses (torch bundles its own copy: a second one would not know
+    the streams of the first)."""
+    import torch  # noqa: F401
+    load()
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    if not paths:
+        raise RuntimeError("HIP runtime not loaded")
+    return ctypes.CDLL(paths[0])
+
+
+class HostStagedComm:
+    """
+    A `vgpa_comm` table on ANY torch.distributed backend (gloo in particular), with the data staged through the host: device ->
+    host copy, CPU collective, host -> device copy, every call synchronous.  Orders of magnitude slower than RCCL over xGMI and
+    never used for a measurement -- it exists so that the native row-sharded driver (`vgpa_shard_*`: one PROCESS per rank) can be
+    exercised with real processes where RCCL cannot be (several ranks on one GPU: tests, `VGPA_BENCH_REHEARSE=1`).  Point-to-point
+    groups map to `batch_isend_irecv`; `abort` marks the table dead (every later call fails) -- the peers leave through their own
+    time-outs, as with a dead RCCL peer.
+    """
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        from ._lib import VgpaComm, COMM_COLLECTIVE, COMM_GROUP, COMM_P2P
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.hip = _hip_runtime()
+        self.dead = False
+        self._ops = None
+        t = VgpaComm()
+        self._keep = (COMM_COLLECTIVE(self._guard(self._all_gather)), COMM_COLLECTIVE(self._guard(self._all_to_all)),
+                      COMM_GROUP(self._guard(self._group_begin)), COMM_GROUP(self._guard(self._group_end)),
+                      COMM_P2P(self._guard(self._send)), COMM_P2P(self._guard(self._recv)), COMM_GROUP(self._abort))
+        t.user, t.all_gather, t.all_to_all, t.group_begin, t.group_end, t.send, t.recv, t.abort = (None, *self._keep)
+        self.table = t
+
+    def _guard(self, fn):
+        def call(*a):
+            if self.dead:
+                return 5
+            try:
+                return fn(*a)
+            except BaseException:            # noqa: BLE001 - nothing may unwind through the C caller
+                return 9
+        return call
+
+    def _to_host(self, ptr, count, stream):
+        import torch
+        self.hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+        h = torch.empty(int(count), dtype=torch.float64)
+        if count:
+            self.hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(8 * int(count)), 2)
+        return h
+
+    def _to_device(self, ptr, h):
+        if h.numel():
+            self.hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(h.data_ptr()), ctypes.c_size_t(8 * h.numel()), 1)
+
+    def _all_gather(self, user, send, recv, count, stream):
+        import torch
+        mine = self._to_host(send, count, stream)
+        out = [torch.empty(int(count), dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, mine, group=self.group)
+        for q in range(self.world):
+            self._to_device(recv + 8 * q * count, out[q])
+        return 0
+
+    def _all_to_all(self, user, send, recv, count, stream):
+        import torch
+        mine = self._to_host(send, count * self.world, stream)
+        out = [torch.empty(int(count) * self.world, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, mine, group=self.group)         # (gloo has no all-to-all of its own on every build)
+        for q in range(self.world):
+            self._to_device(recv + 8 * q * count, out[q][self.rank * count:(self.rank + 1) * count].contiguous())
+        return 0
+
+    def _group_begin(self, user):
+        self._ops = []
+        return 0
+
+    def _send(self, user, buf, count, peer, stream):
+        self._ops.append(("s", buf, int(count), int(peer), stream))
+        return 0
+
+    def _recv(self, user, buf, count, peer, stream):
+        self._ops.append(("r", buf, int(count), int(peer), stream))
+        return 0
+
+    def _group_end(self, user):
+        import torch
+        ops, self._ops = self._ops or [], None
+        if not ops:
+            return 0
+        p2p, landing = [], []
+        for kind, buf, count, peer, stream in ops:
+            gpeer = peer if self.group is None else self.dist.get_global_rank(self.group, peer)
+            if kind == "s":
+                p2p.append(self.dist.P2POp(self.dist.isend, self._to_host(buf, count, stream), gpeer, group=self.group))
+            else:
+                h = torch.empty(count, dtype=torch.float64)
+                landing.append((buf, h))
+                p2p.append(self.dist.P2POp(self.dist.irecv, h, gpeer, group=self.group))
+        for w in self.dist.batch_isend_irecv(p2p):
+            w.wait()
+        for buf, h in landing:
+            self._to_device(buf, h)
+        return 0
+
+    def _abort(self, user):
+        self.dead = True
+        return 0
+
+
 class NativeShardedRecursion:
     """
     The row-sharded recursion with the whole step / stage loop AND its collectives inside libvgpa_hip.so
