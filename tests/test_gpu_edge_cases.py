@@ -203,8 +203,11 @@ def test_state_errors():
     p72, x72 = make_problem("L96", 72, 5, dense=True)
     c72 = gpu_context(p72)
     c72.free_energy(x72)
-    with pytest.raises(NotImplementedError):
-        c72.gradient(None)                         # D > 64: the gradient needs a diagonal system noise matrix (for now)
+    g72 = c72.gradient(None)                       # D > 64 with a dense system noise matrix: built since round 3
+    assert rel_err(g72, vo.sweep(p72, x72, faithful=False)[1]) < TOL
+    with pytest.raises(NotImplementedError):       # what the large-D path still refuses: a batch in the time-chunked sweep
+        from vgpa_amd._lib import FLAG_STREAM_LARGE_D
+        gpu_context(make_problem("L96", 72, 5)[0], batch=2, flags=FLAG_STREAM_LARGE_D)
 
 
 @pytest.mark.parametrize("d", [2, 3, 4])
