@@ -363,7 +363,7 @@ def main():
     traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
                       "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-single-problem "
                              "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
-                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r02r_pmc_fetch_write_B512.csv"}
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r03_pmc_fetch_write_B512.csv"}
 
     kernels = {
         # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
@@ -384,7 +384,8 @@ def main():
     n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym"
     wpe = 2 if nb_blocks <= 10 else 1
-    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, 1, {wpe}>") if sym_units else \
+    cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
                "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma<{nb_blocks}> (+ k_reduce)"}
