@@ -205,6 +205,59 @@ __device__ __forceinline__ double lane_value(double v, int j) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(x) for x > 0: the operation sequence of the device library's rsqrt (v_rsq_f64 and one corrected Newton step, ~1 ulp)
+// without its class test for 0 / inf -- the callers flag non-positive pivots themselves
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(y * -x, y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+
+// The four pivots of Cholesky panel j0 .. j0+3 (lane = row; the panel already holds S - L[:, :j0] L[j0:j0+4, :j0]^T).  Every lane
+// factors the 4x4 diagonal block itself from ten broadcast LDS reads and then solves its own row against it: the same operations in
+// the same order as the lane-j-broadcasts-its-pivot form of rounds 1-2 (bit-identical factor), but the 40-pivot chain has no
+// cross-lane step (v_readlane -> SGPR -> VALU hazards) and one predicated region per panel instead of eight.  myrd collects 1 / L[l][l]:
+// a pivot that is not positive and finite leaves inf / NaN there (and NaN in the rest of the factor), which the caller tests once
+// after the loop.
+template <int LD>
+__device__ __forceinline__ void chol_panel_pivots(double* Lm, double& myrd, int j0, int l, int li, bool pad) {
+  const double* dg = Lm + j0 * LD + j0;
+  const double* rowi = Lm + li * LD + j0;
+  // Statement order = issue order, pinned by scheduling barriers: the block's columns and the row's entries are read one step ahead
+  // of their use instead of all at the top (the kernel runs at its register limit, 168 for three waves per SIMD; a spill there is a
+  // memory round trip per use).
+  const double a00 = dg[0], a10 = dg[LD], a20 = dg[2 * LD], a30 = dg[3 * LD];
+  const double a11 = dg[LD + 1], a21 = dg[2 * LD + 1], a31 = dg[3 * LD + 1];
+  __builtin_amdgcn_sched_barrier(0);
+  const double r0 = rsqrt_pos(a00);
+  const double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+  const double a22 = dg[2 * LD + 2], a32 = dg[3 * LD + 2], s0 = rowi[0], s1 = rowi[1];
+  __builtin_amdgcn_sched_barrier(0);
+  const double p1 = __builtin_fma(-l10, l10, a11);
+  const double r1 = rsqrt_pos(p1);
+  const double l21 = __builtin_fma(-l20, l10, a21) * r1, l31 = __builtin_fma(-l30, l10, a31) * r1;
+  const double x0 = s0 * r0;
+  const double x1 = __builtin_fma(-x0, l10, s1) * r1;
+  myrd = (l == j0) ? r0 : ((l == j0 + 1) ? r1 : myrd);
+  const double a33 = dg[3 * LD + 3], s2 = rowi[2], s3 = rowi[3];
+  __builtin_amdgcn_sched_barrier(0);
+  const double p2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, a22));
+  const double r2 = rsqrt_pos(p2);
+  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, a32)) * r2;
+  const double x2 = __builtin_fma(-x1, l21, __builtin_fma(-x0, l20, s2)) * r2;
+  const double p3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a33)));
+  const double r3 = rsqrt_pos(p3);
+  const double x3 = __builtin_fma(-x2, l32, __builtin_fma(-x1, l31, __builtin_fma(-x0, l30, s3))) * r3;
+  myrd = (l == j0 + 2) ? r2 : ((l == j0 + 3) ? r3 : myrd);
+  if (pad) {                                   // rows above the pivot: the strict upper triangle is zeroed on the way
+    double* wr = Lm + l * LD + j0;
+    wr[0] = (l >= j0) ? x0 : 0.0;
+    wr[1] = (l >= j0 + 1) ? x1 : 0.0;
+    wr[2] = (l >= j0 + 2) ? x2 : 0.0;
+    wr[3] = (l >= j0 + 3) ? x3 : 0.0;
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -367,6 +420,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
   // scalar bookkeeping -- this kernel is bound by instructions issued per grid point.  A non-positive pivot makes the
   // rest of the factor NaN, which is harmless: the flag is checked after the loop.)
   bool bad = false;
+  double myrd = 1.0;                       // 1 / L[l][l] (padding rows: 1), stored once after the loop
   const double* lrow_b = S.Lm + (4 * b + c4) * LD + r4;      // + 4 (p + 4u) LD: A-operand rows of block b
   double* lout_b = S.Lm + (4 * b + r4) * LD + c4;            // + 4 (p + 4u) LD + 4p: output position of block b
 #pragma unroll
@@ -387,23 +441,12 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
       }
       wave_sync();
     }
-    const double* rowi = S.Lm + li * LD;
-    double lq[4], sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int j = j0 + q;
-      double s = sq[q];
-#pragma unroll
-      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
-      const double piv = lane_value(s, j);
-      if (!(piv > 0.0)) bad = true;
-      const double rdv = rsqrt(piv), d = piv * rdv;       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
-      lq[q] = (l > j) ? s * rdv : 0.0;
-      if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
-      if (l == j) S.rd[j] = rdv;
-    }
+    chol_panel_pivots<LD>(S.Lm, myrd, j0, l, li, pad);       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
     wave_sync();
   }
+  if (pad) S.rd[l] = myrd;
+  wave_sync();
+  bad = __any(!(myrd > 0.0 && myrd < __builtin_inf()));
   if (bad) {
     // S_t is not positive definite: the reference raises LinAlgError from chol_inv(S_t) (variational.py:380)
     // after its diagonal fallback (utilities.py:279); report and stop.
@@ -638,38 +681,64 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
 
   // ---- A-operand fragments of A, straight from HBM: unit u = block-rows 4u + b, fragment [i = c4][k = r4]
+  // (the last unit's fragments are requested after the Cholesky instead: with them in flight the factorisation would not fit the
+  //  168 registers of three waves per SIMD, and a spilled fragment is a load that is WAITED for at entry; they arrive during the
+  //  first pass of phase 2)
+#ifndef VGPA_ENERGY_EARLY_UNITS
+#define VGPA_ENERGY_EARLY_UNITS 0
+#endif
+  constexpr int NUE = VGPA_ENERGY_EARLY_UNITS < NUU ? VGPA_ENERGY_EARLY_UNITS : NUU;
   double af[NUU][NB];
-#pragma unroll
-  for (int u = 0; u < NUU; u++) {
+  const int klim = (D - r4 + 3) >> 2;                       // 4K + r4 < D  <=>  K < klim: nothing per K stays alive until the late loads
+  auto load_af = [&](int u) {
     const int row = 16 * u + (l & 15);
+    const double* ap = At + row * D + r4;
+    const int kl = row < D ? klim : 0;
 #pragma unroll
-    for (int K = 0; K < NB; K++) {
-      const int col = 4 * K + r4;
-      af[u][K] = (row < D && col < D) ? At[row * D + col] : 0.0;
-    }
-  }
+    for (int K = 0; K < NB; K++) af[u][K] = (K < kl) ? ap[4 * K] : 0.0;
+  };
+#ifndef VGPA_ENERGY_LOAD_AT_PANEL
+#pragma unroll
+  for (int u = 0; u < NUE; u++) load_af(u);
+#endif
 
   // the two entries of S_t that <f>_i needs at the very end (E96_drift): requested now -- at the end they would cost a
   // full memory round trip per wave
-  double sxa = 0.0, sxb = 0.0;
-  if (act) {
-    const int ip1 = wrap(l + 1, D), im1 = wrap(l - 1, D), im2 = wrap(l - 2, D);
-    sxa = St[ip1 * D + im1];
-    sxb = St[im2 * D + im1];
-  }
+  double sxa = 0.0, sxb = 0.0, v_m = 0.0, v_b = 0.0, v_sg = 0.0;
+  auto load_vectors = [&]() {
+    if (act) {
+      const int ip1 = wrap(l + 1, D), im1 = wrap(l - 1, D), im2 = wrap(l - 2, D);
+      sxa = St[ip1 * D + im1];
+      sxb = St[im2 * D + im1];
+      v_m = a.m[o * D + l];
+      v_b = a.b[(size_t)prob * a.strideB + (size_t)t * D + l];
+      v_sg = a.isg[l];
+    }
+  };
 
   // ---- stage c*S into LDS (coalesced); padding: identity.  Every HBM load of the wave (the vectors too) is requested
-  //      before the first one is consumed: a lone wave pays each dependent round trip in full.
-  const double v_m = act ? a.m[o * D + l] : 0.0;
-  const double v_b = act ? a.b[(size_t)prob * a.strideB + (size_t)t * D + l] : 0.0;
-  const double v_sg = act ? a.isg[l] : 0.0;
-
-  if (D < Dp) {
+  //      before the first one is consumed: a lone wave pays each dependent round trip in full.  S_t's requests go first.
+  if (D == Dp) {
+    // no padding (D = 40 of the headline): one row per load, lane = column -- every HBM and LDS offset is an immediate, no index
+    // arithmetic per element; rows in flight per round trip are bounded by the registers (the A fragments are not in flight yet)
+    constexpr int RCH = Dp <= 44 ? Dp : 32;
+    const double* sp = St + li;
+#pragma unroll
+    for (int q0 = 0; q0 < Dp; q0 += RCH) {
+      double sv[RCH];
+#pragma unroll
+      for (int u = 0; u < RCH; u++) sv[u] = (q0 + u < Dp) ? sp[(q0 + u) * Dp] : 0.0;   // (idle lanes re-read column Dp-1: no predicate)
+      if (q0 == 0) load_vectors();
+      if (pad) {
+#pragma unroll
+        for (int u = 0; u < RCH; u++)
+          if (q0 + u < Dp) S.Lm[(q0 + u) * LD + l] = c * sv[u];
+      }
+    }
+  } else {
+    load_vectors();
     for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
-  }
-  if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.am[l] = 0.0; S.rd[l] = 1.0; }
-  wave_sync();
-  {
+    wave_sync();
     constexpr int EPL = (Dp * Dp + 63) / 64;
     constexpr int CH = (NB <= 11) ? EPL : 13;                // loads in flight per round trip (registers)
     const int DD = D * D;
@@ -694,14 +763,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     }
   }
   if (l >= D && pad) S.Lm[l * LD + l] = 1.0;
+  // (the vectors go to LDS after the matrix: their stores wait for their loads, which must not hold back the requests for S_t)
+  if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.am[l] = 0.0; }
   wave_sync();
 
   // ---- 1. Cholesky (identical to k_energy_l96)
   bool bad = false;
+  double myrd = 1.0;                       // 1 / L[l][l] (padding rows: 1), stored once after the loop
   const double* lrow_b = S.Lm + (4 * b + c4) * LD + r4;
   double* lout_b = S.Lm + (4 * b + r4) * LD + c4;
 #pragma unroll
   for (int p = 0; p < NB; p++) {
+#ifdef VGPA_ENERGY_LOAD_AT_PANEL
+    if (p == (VGPA_ENERGY_LOAD_AT_PANEL < NB ? VGPA_ENERGY_LOAD_AT_PANEL : NB - 1)) {
+#pragma unroll
+      for (int u = 0; u < NUE; u++) load_af(u);
+    }
+#endif
     const int j0 = 4 * p;
     if (p > 0) {
       const double* brow = S.Lm + (j0 + c4) * LD + r4;
@@ -718,27 +796,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
       }
       wave_sync();
     }
-    const double* rowi = S.Lm + li * LD;
-    double lq[4], sq[4] = {rowi[j0], rowi[j0 + 1], rowi[j0 + 2], rowi[j0 + 3]};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int j = j0 + q;
-      double s = sq[q];
-#pragma unroll
-      for (int q2 = 0; q2 < q; q2++) s = __builtin_fma(-lq[q2], lane_value(lq[q2], j), s);
-      const double piv = lane_value(s, j);
-      if (!(piv > 0.0)) bad = true;
-      const double rdv = rsqrt(piv), d = piv * rdv;
-      lq[q] = (l > j) ? s * rdv : 0.0;
-      if (pad) S.Lm[l * LD + j] = (l > j) ? lq[q] : ((l == j) ? d : 0.0);
-      if (l == j) S.rd[j] = rdv;
-    }
+    chol_panel_pivots<LD>(S.Lm, myrd, j0, l, li, pad);       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
     wave_sync();
   }
+  if (pad) S.rd[l] = myrd;
+  wave_sync();
+  bad = __any(!(myrd > 0.0 && myrd < __builtin_inf()));
   if (bad) {
     if (l == 0) atomicOr(a.status + prob, 1);
     return;
   }
+#pragma unroll
+  for (int u = NUE; u < NUU; u++) load_af(u);
 
   // ---- 2. A.m and G = A.L on the matrix cores, results stay in the accumulators (row 16u + 4b + r4, column 4J + c4)
   double amr[NUU], gacc[NUU][NB];
@@ -749,16 +818,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     for (int J = 0; J < NB; J++) gacc[u][J] = 0.0;
   }
 #pragma unroll
-  for (int K = 0; K < NB; K++) {
-    const double mk = S.mv[4 * K + r4];                       // B-operand [k = r4][j]: m in every column
+  for (int pass = 0; pass < (NUE < NUU ? 2 : 1); pass++) {    // units 0 .. NUE-1, then the late unit (its own reads of L)
+    const int u0 = pass == 0 ? 0 : NUE, u1 = pass == 0 ? NUE : NUU;
 #pragma unroll
-    for (int u = 0; u < NUU; u++) amr[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], mk, amr[u], 0, 0, 0);
-    const double* lk = S.Lm + (4 * K + r4) * LD + c4;          // B-operand [k = r4][j = c4] = L[4K + r4][4J + c4], K >= J
+    for (int K = 0; K < NB; K++) {
+      const double mk = S.mv[4 * K + r4];                       // B-operand [k = r4][j]: m in every column
 #pragma unroll
-    for (int J = 0; J <= K; J++) {
-      const double lf = lk[4 * J];
+      for (int u = u0; u < u1; u++) amr[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], mk, amr[u], 0, 0, 0);
+      const double* lk = S.Lm + (4 * K + r4) * LD + c4;          // B-operand [k = r4][j = c4] = L[4K + r4][4J + c4], K >= J
 #pragma unroll
-      for (int u = 0; u < NUU; u++) gacc[u][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], lf, gacc[u][J], 0, 0, 0);
+      for (int J = 0; J <= K; J++) {
+        const double lf = lk[4 * J];
+#pragma unroll
+        for (int u = u0; u < u1; u++) gacc[u][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[u][K], lf, gacc[u][J], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
