@@ -653,12 +653,23 @@ __host__ __device__ inline size_t l96r_lds_doubles(int D) {
   return dp * l96_ld(D) + 6 * dp + 9 * dp;       // L + 6 vectors + scratch (4 + 4 partial rows, 1 row of G; later xdiag)
 }
 
+#ifdef VGPA_ENERGY_TRACE
+// diagnostic build only: cycles per phase of k_energy_l96_r summed over all waves (tools/trace_energy.py)
+__device__ unsigned long long g_energy_trace[16];
+#define VGPA_TRACE_STAMP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); if (l == 0) atomicAdd(&g_energy_trace[k], tn_ - tprev_); tprev_ = tn_; } while (0)
+#else
+#define VGPA_TRACE_STAMP(k) do { } while (0)
+#endif
+
 template <int NB>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 10 ? 3 : 2, NB <= 10 ? 3 : 2))) k_energy_l96_r(EnergyArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int D = a.D, M = 2 * D + 1;
   constexpr int Dp = 4 * NB, LD = Dp + 1, NUU = (NB + 3) / 4;
   const int l = threadIdx.x;
+#ifdef VGPA_ENERGY_TRACE
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
   const long long wid = blockIdx.x;
   const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
   const size_t o = (size_t)prob * a.Np + t;
@@ -697,10 +708,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
 #pragma unroll
     for (int K = 0; K < NB; K++) af[u][K] = (K < kl) ? ap[4 * K] : 0.0;
   };
-#ifndef VGPA_ENERGY_LOAD_AT_PANEL
 #pragma unroll
   for (int u = 0; u < NUE; u++) load_af(u);
-#endif
 
   // the two entries of S_t that <f>_i needs at the very end (E96_drift): requested now -- at the end they would cost a
   // full memory round trip per wave
@@ -767,6 +776,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   if (pad) { S.mv[l] = v_m; S.bv[l] = v_b; S.am[l] = 0.0; }
   wave_sync();
 
+  VGPA_TRACE_STAMP(0);
   // ---- 1. Cholesky (identical to k_energy_l96)
   bool bad = false;
   double myrd = 1.0;                       // 1 / L[l][l] (padding rows: 1), stored once after the loop
@@ -774,12 +784,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   double* lout_b = S.Lm + (4 * b + r4) * LD + c4;
 #pragma unroll
   for (int p = 0; p < NB; p++) {
-#ifdef VGPA_ENERGY_LOAD_AT_PANEL
-    if (p == (VGPA_ENERGY_LOAD_AT_PANEL < NB ? VGPA_ENERGY_LOAD_AT_PANEL : NB - 1)) {
-#pragma unroll
-      for (int u = 0; u < NUE; u++) load_af(u);
-    }
-#endif
     const int j0 = 4 * p;
     if (p > 0) {
       const double* brow = S.Lm + (j0 + c4) * LD + r4;
@@ -809,6 +813,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
 #pragma unroll
   for (int u = NUE; u < NUU; u++) load_af(u);
 
+  VGPA_TRACE_STAMP(1);
   // ---- 2. A.m and G = A.L on the matrix cores, results stay in the accumulators (row 16u + 4b + r4, column 4J + c4)
   double amr[NUU], gacc[NUU][NB];
 #pragma unroll
@@ -840,6 +845,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     if (c4 == 0 && i < D) { S.am[i] = amr[u]; if (a.Am) a.Am[o * D + i] = amr[u]; }
   }
 
+  VGPA_TRACE_STAMP(2);
   // ---- 3. residuals of the sigma points m +- L[:, j] in accumulator layout, rows 2 .. D-2
   // park rows 0, 1, D-1 of G for the boundary pass first (only the units that can hold them: compile-time test), so
   // that the residual loop below is ONE basic block (with branches in between, the compiler sinks all the arithmetic
@@ -909,6 +915,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     }
   }
   wave_sync();
+  VGPA_TRACE_STAMP(3);
 
   double vplus = 0.0, vminus = 0.0, v0 = 0.0;
   {
@@ -994,6 +1001,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   }
   wave_sync();
 
+  VGPA_TRACE_STAMP(4);
   // ---- 4. X = L^-1 IN PLACE by blocked forward substitution on the matrix cores (see k_energy_l96): block-row I of X
   //         overwrites block-row I of L, which only step I reads; LDS operations of one wave execute in order.
   const double* l4_a = S.Lm + c4 * LD + r4;
@@ -1029,6 +1037,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     wave_sync();
   }
 
+  VGPA_TRACE_STAMP(5);
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
@@ -1047,6 +1056,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     }
   }
 
+  VGPA_TRACE_STAMP(6);
   // ---- <f> and optionally dense <df/dx>
   if (act) {
     const int i = l, ip1 = wrap(i + 1, D), im1 = wrap(i - 1, D), im2 = wrap(i - 2, D);
@@ -1066,6 +1076,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
       ed[e] = v;
     }
   }
+  VGPA_TRACE_STAMP(7);
 }
 
 // dense <df/dx> only (used by vgpa_fetch(EDF) when the fused sweep skipped it)
@@ -1143,3 +1154,14 @@ hipError_t launch_edf(const EnergyArgs& a, hipStream_t st) {
 }
 
 }  // namespace vgpa
+
+#ifdef VGPA_ENERGY_TRACE
+extern "C" int vgpa_debug_energy_trace(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vgpa::g_energy_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vgpa::g_energy_trace), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
