@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-single-problem", action="store_true",
                     help="skip the single-problem latency probe (so that a kernel profile of the run holds batched launches only)")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) stepping kernels")
+    ap.add_argument("--keep-psi", action="store_true", help="comparison runs: VGPA_FLAG_KEEP_PSI (the backward kernel stores Psi_t, "
+                    "the gradient assembly re-reads A_t) instead of the default Q''_t stream")
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
     ap.add_argument("--config5-np", type=int, default=9, help="grid points of the D = 4096 block (its step rate does not depend on it)")
     ap.add_argument("--config5-dim", type=int, default=4096)
@@ -254,7 +256,7 @@ def main():
     par.init_from_env("gloo" if rehearse else "nccl", None if rehearse else local_rank)   # RCCL; no-op at WORLD_SIZE == 1
 
     import vgpa_amd as va
-    from vgpa_amd._lib import FLAG_FORCE_GENERIC
+    from vgpa_amd._lib import FLAG_FORCE_GENERIC, FLAG_KEEP_PSI
 
     def barrier():
         if world > 1:
@@ -265,7 +267,7 @@ def main():
     assert v.dim_n == n_pts, (v.dim_n, n_pts)
     len_x = x0.size
     B = args.batch
-    flags = FLAG_FORCE_GENERIC if args.generic else 0
+    flags = (FLAG_FORCE_GENERIC if args.generic else 0) | (FLAG_KEEP_PSI if args.keep_psi else 0)
     e0 = float(p["kl0"](p["m0"], p["s0"]))
     ctx = va.Context("L96", args.method, d, n_pts, dt, sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"],
                      obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=B,
@@ -385,7 +387,9 @@ def main():
     sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym"
     wpe = 2 if nb_blocks <= 10 else 1
     cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
-    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}>") if sym_units else \
+    # (last parameter: the backward cover kernels of RK2 / RK4 store Q''_t = Sigma^-1 A_t - 2 Psi_t for the gradient assembly)
+    q_out = lambda fwd: "true" if (fwd == "false" and cover == 0 and method_id in (2, 3) and not args.keep_psi) else "false"
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
                "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma<{nb_blocks}> (+ k_reduce)"}

@@ -74,8 +74,12 @@ enum {
   VGPA_FLAG_STREAM_LARGE_D = 4, /* D > 64: time-chunked sweep that keeps only x, S_t and the gradient resident (Psi_t and
                                   dEsde_dS_t live in chunk buffers; VGPA_FETCH_PSIT is unavailable).  Chosen automatically
                                   when the resident arrays would not fit into free device memory. */
-  VGPA_FLAG_SYM_UNITS = 16     /* 5 <= D <= 44: the symmetric-unit stepping kernels (ode_sym_impl.h; two problems per CU, the
+  VGPA_FLAG_SYM_UNITS = 16,    /* 5 <= D <= 44: the symmetric-unit stepping kernels (ode_sym_impl.h; two problems per CU, the
                                   default for 44 < D <= 64) instead of the role-specialised ones.  Same results to rounding. */
+  VGPA_FLAG_KEEP_PSI = 32      /* batched symmetric-unit sweeps (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I): by default the backward
+                                  kernel leaves Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- all the gradient assembly
+                                  needs of the two, one HBM stream less -- and VGPA_FETCH_PSIT recovers Psi_t from it
+                                  ((Sigma^-1 A_t - Q''_t) / 2, equal to rounding).  This flag stores Psi_t itself. */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;

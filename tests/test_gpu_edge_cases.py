@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import vgpa_amd as va
-from vgpa_amd._lib import FLAG_FORCE_GENERIC, FLAG_SYM_UNITS
+from vgpa_amd._lib import FLAG_FORCE_GENERIC, FLAG_KEEP_PSI, FLAG_SYM_UNITS
 from conftest import rel_err
 from oracle import vgpa_oracle as vo
 
@@ -113,6 +113,28 @@ def test_symmetric_unit_steppers_dense_inputs_and_batches(model, d):
         assert abs(fb[i] - f_ref) <= TOL * abs(f_ref)
         assert rel_err(gb[i], g_ref) < TOL
     ctx.close()
+
+
+@pytest.mark.parametrize("d,method", [(40, "rk4"), (36, "rk2"), (33, "rk4")])
+def test_q_stream_of_the_batched_sweeps(d, method):
+    """33 <= D <= 40, RK2 / RK4 on the symmetric-unit kernels: the backward kernel leaves Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t
+    would be (the gradient assembly then reads one matrix stream less) and VGPA_FETCH_PSIT recovers Psi_t.  Against the same
+    sweep with VGPA_FLAG_KEEP_PSI (Psi_t stored, A_t re-read): F identical, gradient and Psi_t equal to rounding; a second fetch
+    and a gradient(eval_fun=False) after the recovery still see consistent data."""
+    p, x = make_problem("L96", d, 21, method=method)
+    ctx_q = gpu_context(p, flags=FLAG_SYM_UNITS)
+    ctx_k = gpu_context(p, flags=FLAG_SYM_UNITS | FLAG_KEEP_PSI)
+    f_q, g_q = ctx_q.sweep(x)
+    f_k, g_k = ctx_k.sweep(x)
+    assert f_q == f_k
+    assert rel_err(g_q, g_k) < 1e-13
+    psi_q, psi_k = ctx_q.fetch("psit"), ctx_k.fetch("psit")
+    assert rel_err(psi_q, psi_k) < 1e-13
+    assert np.array_equal(ctx_q.fetch("psit"), psi_q)                      # recovered once, in place
+    assert rel_err(ctx_q.gradient(None), g_k) < 1e-13                      # assembled from the recovered Psi_t now
+    _, g_ref, st = vo.sweep(p, x, faithful=False)
+    assert rel_err(g_q, g_ref) < TOL and rel_err(np.asarray(psi_q).reshape(np.shape(st["psit"])), st["psit"]) < TOL
+    ctx_q.close(); ctx_k.close()
 
 
 @pytest.mark.parametrize("method", ["rk4", "heun"])

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
     const int e = tid + q * NT;
     const bool in = e < DD;
     const int i = (int)(((unsigned)(in ? e : 0) * magic) >> 20);
-    sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0; av[q] = in ? At[e] : 0.0;
+    sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0; av[q] = (in && !a.psi_is_q) ? At[e] : 0.0;
     ig[q] = in ? a.isig[i * D + i] : 0.0;
     ev[q] = (in && Edf) ? Edf[e] : 0.0;
   }
@@ -293,7 +293,8 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
       const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
       const double ed = Edf ? ev[q] : edf_entry(a.model, a.theta, D, i, j, mv, s00);
       Ss[i * LD + j] = sv[q];
-      QT[j * LD + i] = ig[q] * (ed + av[q]) - 2.0 * pv[q];
+      // (psi_is_q: the backward kernel left Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- one stream less)
+      QT[j * LD + i] = a.psi_is_q ? __builtin_fma(ig[q], ed, pv[q]) : ig[q] * (ed + av[q]) - 2.0 * pv[q];
     }
   }
   if (vt) {
@@ -476,6 +477,22 @@ hipError_t launch_obs(const ObsArgs& a, hipStream_t st) {
 hipError_t launch_obs_dense(const ObsArgs& a, const double* js_const, double* jm_dense, double* js_dense,
                             hipStream_t st) {
   if (a.n_obs > 0) hipLaunchKernelGGL(k_obs_dense, dim3(a.n_obs, a.batch), dim3(NT), 0, st, a, js_const, jm_dense, js_dense);
+  return hipGetLastError();
+}
+
+// Psi_t back from Q''_t = diag(isg) A_t - 2 Psi_t (the fused batched sweeps, OdeArgs::q_isg), in place: VGPA_FETCH_PSIT
+__global__ void __launch_bounds__(NT) k_psi_from_q(int Np, int D, size_t strideA, const double* A, const double* isg, double* pq) {
+  const int t = blockIdx.x, prob = blockIdx.y, DD = D * D;
+  const double* At = A + (size_t)prob * strideA + (size_t)t * DD;
+  double* q = pq + ((size_t)prob * Np + t) * DD;
+  for (int e = threadIdx.x; e < DD; e += NT) {
+    const int i = e / D;
+    q[e] = 0.5 * __builtin_fma(isg[i], At[e], -q[e]);
+  }
+}
+
+hipError_t launch_psi_from_q(int batch, int Np, int D, size_t strideA, const double* A, const double* isg, double* psi_q, hipStream_t st) {
+  hipLaunchKernelGGL(k_psi_from_q, dim3(Np, batch), dim3(NT), 0, st, Np, D, strideA, A, isg, psi_q);
   return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ bool ode_mfma_supported(int method, bool, int D) {
   return false;
 }
 
+bool sym_stores_q(int method, int D) { return sym::stores_q(method, D); }
+
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st) {
   switch (method) {
     case VGPA_ODE_EULER: return mfma_method_launch<VGPA_ODE_EULER>(fwd, a, st);

@@ -30,6 +30,22 @@
 // + vectors + the constant matrix jump 13 KB: 82 KB.
 #pragma once
 #include "vgpa_internal.h"
+#include <cstdlib>
+
+namespace vgpa {
+namespace sym {
+// VGPA_SYM_RUNS=1 keeps the run layout of the symmetric-unit kernels where the fragment cover exists (comparison runs)
+inline bool runs_only_env() {
+  static const bool r = [] { const char* e = getenv("VGPA_SYM_RUNS"); return e && e[0] == '1'; }();
+  return r;
+}
+// the backward kernels that can store Q''_t = Sigma^-1 A_t - 2 Psi_t instead of Psi_t (OdeArgs::q_on): the fragment-cover
+// kernels (ode_sym_impl.h, 33 <= D <= 40) of the mid-point methods with sparse jumps
+inline bool stores_q(int method, int D) {
+  return (method == VGPA_ODE_RK2 || method == VGPA_ODE_RK4) && D >= 33 && D <= 40 && !runs_only_env();
+}
+}  // namespace sym
+}  // namespace vgpa
 
 namespace vgpa {
 namespace mfma {

@@ -277,7 +277,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // use of ANY value loaded in the previous iteration becomes s_waitcnt vmcnt(0) -- it waits for every load and store issued so
 // far.  So a step issues all its HBM loads at ONE point (behind the staging of stage min(1, NS-1): A, the forcing terms, the
 // jumps of two steps ahead) and consumes them at ONE point (the rotation at the top of the next step, >= 1 stage later).
-template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE>   // WPE: waves per SIMD the register budget allows for
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false>   // WPE: waves per SIMD the register budget allows for
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -313,6 +313,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   }
 #endif
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += 256) smem[i] = 0.0;
+  // QOUT (backward, mid-point methods, Sigma = sigma^2 I): the state store writes Q''_t = A_t / sigma^2 - 2 Psi_t in place of Psi_t --
+  // the only combination of A_t and Psi_t the gradient assembly reads (assemble.hip), which then streams one matrix less.  (A
+  // general diagonal would need its entries per row pair here: with them the kernel no longer fits its 256 registers.)
+  static_assert(!QOUT || (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)), "Q'' is stored by the backward mid-point kernels");
   auto tidx =[&](int i) { return FWD ? i : Np - 1 - i; };
   auto tclamp = [&](int i) { return tidx(i <= n_steps ? i : n_steps); };
 
@@ -557,9 +561,21 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       load_items(Xc, tc_items);
     }
   };
+  // QOUT: items of Psi_t -> items of Q''_t, with the start-point operand A_t in the same row-pair items
+  auto to_q = [&](d2_t (&items)[g::NIT], const d2_t (&a0)[NITS]) {
+    if constexpr (QOUT) {
+      const double qs = a.q_scale;
+#pragma unroll
+      for (int q = 0; q < g::NIT; q++) {
+        items[q][0] = __builtin_fma(qs, a0[q][0], -2.0 * items[q][0]);
+        items[q][1] = __builtin_fma(qs, a0[q][1], -2.0 * items[q][1]);
+      }
+    }
+  };
   auto tailC_finish = [&](int j, int step) {
     if (j == 0) {
       double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
+      if constexpr (QOUT) to_q(tc_items, tc_mid);
       if (MIDP) {
 #pragma unroll
         for (int q = 0; q < NITS; q++) { tc_mid[q][0] = 0.5 * (tc_mid[q][0] + an[q][0]); tc_mid[q][1] = 0.5 * (tc_mid[q][1] + an[q][1]); }
@@ -970,9 +986,16 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   {
     d2_t items[g::NIT];
     load_items(xcur(n_steps, 0), items);
+    if constexpr (QOUT) {                // the end point's operand is in R (staged at stage JSEC of the last step, or by the prologue)
+      d2_t a0[NITS];
+#pragma unroll
+      for (int q = 0; q < NITS; q++) a0[q] = *unit_ptr(Rb, q);
+      to_q(items, a0);
+    }
     store_items(items, tidx(n_steps));
   }
 }
+
 
 template <int METHOD, bool FWD, int NB>
 hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
@@ -981,7 +1004,7 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   // runs per pipeline step.  Two (four accumulators in turn, 16 MFMAs per step) spill with 256 registers and were slower with
   // 512 (D = 64: 22.0 vs 15.7 ms forward); the kernel is only exercised with one.
   // NSB = 5 (33 <= D <= 40): the fragment cover (GR = 0; VGPA_SYM_RUNS=1 keeps the run layout for comparison)
-  static const bool runs_only = [] { const char* e = getenv("VGPA_SYM_RUNS"); return e && e[0] == '1'; }();
+  const bool runs_only = runs_only_env();
   constexpr bool can_cover = SGeo<NB>::NSB == 5;
   constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
@@ -989,6 +1012,17 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
     if (!runs_only) {
       constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
       constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;
+      if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
+        if (a.q_on) {
+          if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)
+          constexpr size_t lds_q = lds_c;
+          auto kq = k_ode_sym<METHOD, FWD, NB, false, 0, WPE_C, true>;
+          if (lds_q > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+          hipLaunchKernelGGL(kq, dim3(a.batch), dim3(256), lds_q, st, a);
+          return hipGetLastError();
+        }
+      }
       auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, 0, WPE_C> : k_ode_sym<METHOD, FWD, NB, false, 0, WPE_C>;
       if (lds_c > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);

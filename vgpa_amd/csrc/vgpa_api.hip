@@ -37,6 +37,9 @@ struct vgpa_ctx {
   bool stream_ld = false;
   int ld_chunk = 0;
   double *d_dEs_c = nullptr, *d_psi_c = nullptr;
+  bool psi_is_q = false;       // d_psi holds Q''_t = A_t / sigma^2 - 2 Psi_t (fused batched sweeps, OdeArgs::q_on)
+  bool isg_iso = false;        // Sigma = sigma^2 I
+  double isg0 = 1.0;           // 1 / sigma^2 then
   std::vector<int32_t> h_obs_idx; // host copy of obs_idx [Np]
   bool obs_diag = false;          // diagonal R and H = I: Q, K are diagonal
   double* d_obs_part = nullptr;   // [B][M] per-observation energy terms (large-D observation kernel)
@@ -253,6 +256,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   int rc;
   if ((rc = ensure(c, &c->d_psi, (size_t)c->B * c->Np * c->DD))) return rc;
   if ((rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD))) return rc;
+  c->psi_is_q = false;
   if (c->D > kMaxSmallD) {
     if ((rc = ensure_ld_ws(c))) return rc;
     LdBatch batch(c);
@@ -273,6 +277,12 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
   else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
+  // fused sweeps on the fragment-cover kernels: Q''_t instead of Psi_t (the gradient assembly then does not read A_t; see
+  // VGPA_FLAG_KEEP_PSI).  Same condition as the kernel choice below and as run_grad's matrix-core assembly.
+  c->psi_is_q = !dense_jumps && a.sym_units && !use_lane(c) && !use_wave(c) && use_mfma(c, false, sym) && c->sigma_diag && c->isg_iso &&
+                c->cfg.model == VGPA_MODEL_L96 && !(c->cfg.flags & VGPA_FLAG_KEEP_PSI) && sym_stores_q(c->cfg.method, c->D);
+  a.q_on = c->psi_is_q ? 1 : 0;
+  a.q_scale = c->isg0;
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, false, a, c->stream)
                  : use_wave(c) ? launch_ode_wave(c->cfg.method, false, a, c->stream)
                  : use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
@@ -364,6 +374,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.strideA = a.strideB = c->len_x;
   a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
+  a.psi_is_q = c->psi_is_q ? 1 : 0;
   a.Am = c->d_Am;                                  // written by the L96 energy kernel of the same sweep (else null)
   a.scalar_product = (c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) ? 1 : 0;
   hipError_t e = launch_grad(a, c->stream);
@@ -616,6 +627,9 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   c->h_isig = isig;
   TRY(upload(c, c->d_isig, isig.data(), DD));
   TRY(upload(c, c->d_isg, isg.data(), (size_t)D));
+  c->isg0 = isg[0];
+  c->isg_iso = true;
+  for (int i = 1; i < D; i++) c->isg_iso = c->isg_iso && isg[i] == isg[0];
   if (cfg->m0) TRY(upload(c, c->d_m0, cfg->m0, (size_t)D));
   if (cfg->s0) TRY(upload(c, c->d_S0, cfg->s0, DD));
 
@@ -967,6 +981,11 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
     case VGPA_FETCH_LAMT: rc = download(c, out, c->d_lam, BN * c->D); break;
     case VGPA_FETCH_PSIT:
       if (!c->d_psi || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "Psi_t is not kept by the time-chunked large-D sweep");
+      if (c->psi_is_q) {               // recover Psi_t = (Sigma^-1 A_t - Q''_t) / 2 in place: from here on d_psi holds Psi_t again
+        hipError_t e = launch_psi_from_q(c->B, c->Np, c->D, c->len_x, ctx_A(c), c->d_isg, c->d_psi, c->stream);
+        if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "Psi_t recovery launch failed: %s", hipGetErrorString(e));
+        c->psi_is_q = false;
+      }
       rc = download(c, out, c->d_psi, BN * c->DD); break;
     case VGPA_FETCH_EFX: rc = download(c, out, c->d_Ef, BN * c->D); break;
     case VGPA_FETCH_DESDE_DM: rc = download(c, out, c->d_dEm, BN * c->D); break;

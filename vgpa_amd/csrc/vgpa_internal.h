@@ -38,6 +38,10 @@ struct OdeArgs {
   int n_obs;
   double* lam;           // [B][Np][D]
   double* psi;           // [B][Np][D][D]
+  // fused sweeps of the batched symmetric-unit kernels (sym::stores_q) with Sigma = sigma^2 I: q_on = 1 and q_scale = 1 / sigma^2, and
+  // `psi` receives Q''_t = q_scale A_t - 2 Psi_t (what the gradient assembly needs of A_t and Psi_t) instead of Psi_t
+  int q_on;
+  double q_scale;
 };
 
 struct EnergyArgs {
@@ -87,6 +91,7 @@ struct GradArgs {
   const double* A; const double* b;
   const double* m; const double* S;
   const double* lam; const double* psi;
+  int psi_is_q;             // `psi` holds Q''_t = Sigma^-1 A_t - 2 Psi_t (OdeArgs::q_on): A is not read
   const double* Ef;
   const double* Am;         // [B][Np][D] A_t m_t left by the energy kernel, or nullptr (then recomputed)
   const double* Edf;        // dense [B][Np][D][D] or nullptr (then recomputed from the model)
@@ -108,6 +113,9 @@ hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t 
 hipError_t launch_ode_wave(int method, bool fwd, const OdeArgs& a, hipStream_t st);      // 2 <= D <= kMaxLaneD, few problems
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
+bool sym_stores_q(int method, int D);      // the backward kernel launch_ode_mfma picks for sym_units honours OdeArgs::q_on
+// Psi_t = (diag(isg) A_t - Q''_t) / 2 in place (A: problem stride strideA, grid-point stride D*D)
+hipError_t launch_psi_from_q(int batch, int Np, int D, size_t strideA, const double* A, const double* isg, double* psi_q, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
 hipError_t launch_obs(const ObsArgs& a, hipStream_t st);   // uses the grid-parallel variant when a.part != nullptr
 hipError_t launch_obs_dense(const ObsArgs& a, const double* js_const, double* jm_dense, double* js_dense,
