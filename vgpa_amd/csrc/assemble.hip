@@ -491,6 +491,19 @@ __global__ void __launch_bounds__(NT) k_psi_from_q(int Np, int D, size_t strideA
   }
 }
 
+__global__ void __launch_bounds__(NT) k_mirror_upper(int D, double* m) {
+  double* q = m + (size_t)blockIdx.x * D * D;
+  for (int e = threadIdx.x; e < D * D; e += NT) {
+    const int i = e / D, j = e - i * D;
+    if (i > j) q[e] = q[j * D + i];
+  }
+}
+
+hipError_t launch_mirror_upper(size_t n_mat, int D, double* m, hipStream_t st) {
+  hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)n_mat), dim3(NT), 0, st, D, m);
+  return hipGetLastError();
+}
+
 hipError_t launch_psi_from_q(int batch, int Np, int D, size_t strideA, const double* A, const double* isg, double* psi_q, hipStream_t st) {
   hipLaunchKernelGGL(k_psi_from_q, dim3(Np, batch), dim3(NT), 0, st, Np, D, strideA, A, isg, psi_q);
   return hipGetLastError();

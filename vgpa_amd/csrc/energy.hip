@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
     for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
       int row, col; bool ok;
       wave_gemm_elem<NB>(u, row, col, ok);
-      if (ok && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[u];
+      if (ok && row < D && col < D && (row <= col || !a.ds_upper)) ds[row * D + col] = 0.5 * c * acc[u];
     }
   }
 
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
       int row, col; bool ok;
       wave_gemm_elem<NB>(u, row, col, ok);
-      if (ok && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[u];
+      if (ok && row < D && col < D && (row <= col || !a.ds_upper)) ds[row * D + col] = 0.5 * c * acc[u];
     }
   }
 

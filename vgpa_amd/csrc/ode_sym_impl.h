@@ -341,7 +341,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       wd[s] = act;
       wm[s] = act && row != col;
       own[s] = act && row < D && col < D;
-      gofs[s] = own[s] ? 8u * (unsigned)(row * D + col) : 0u;
+      gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? row * D + col : col * D + row) : 0u;     // (the upper triangle: all that EnergyArgs::ds_upper writes)
       colJ[s] = 0;
     }
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       wd[s] = act;
       wm[s] = act && row != col;
       own[s] = act && row < D && col < D;
-      gofs[s] = own[s] ? 8u * (unsigned)(row * D + col) : 0u;
+      gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? row * D + col : col * D + row) : 0u;     // (the upper triangle: all that EnergyArgs::ds_upper writes)
     }
   }
   }

@@ -38,6 +38,7 @@ struct vgpa_ctx {
   int ld_chunk = 0;
   double *d_dEs_c = nullptr, *d_psi_c = nullptr;
   bool psi_is_q = false;       // d_psi holds Q''_t = A_t / sigma^2 - 2 Psi_t (fused batched sweeps, OdeArgs::q_on)
+  bool des_upper = false;      // d_dEs holds the upper triangles only (EnergyArgs::ds_upper)
   bool isg_iso = false;        // Sigma = sigma^2 I
   double isg0 = 1.0;           // 1 / sigma^2 then
   std::vector<int32_t> h_obs_idx; // host copy of obs_idx [Np]
@@ -291,8 +292,9 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   return VGPA_OK;
 }
 
-static EnergyArgs energy_args(vgpa_ctx* c, double* edf) {
+static EnergyArgs energy_args(vgpa_ctx* c, double* edf, bool ds_upper = false) {
   EnergyArgs a{};
+  a.ds_upper = ds_upper ? 1 : 0;
   a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
   a.sigma1 = c->sigma1; a.isg = c->d_isg;
@@ -311,7 +313,8 @@ static int ensure_lde_ws(vgpa_ctx* c) {
   return dev_alloc(c, &c->d_lde_ws, ld::lde_workspace_doubles(c->D, c->lde_nb));
 }
 
-static int run_energy(vgpa_ctx* c, double* edf) {
+static int run_energy(vgpa_ctx* c, double* edf, bool ds_upper = false) {
+  c->des_upper = false;
   { int rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD); if (rc) return rc; }
   if (c->D > kMaxSmallD) {
     if (c->cfg.model != VGPA_MODEL_L96) return fail(c, VGPA_ERR_UNSUPPORTED, "large-D energy terms exist for Lorenz-96 only");
@@ -328,7 +331,8 @@ static int run_energy(vgpa_ctx* c, double* edf) {
     }
     return VGPA_OK;
   }
-  EnergyArgs a = energy_args(c, edf);
+  c->des_upper = ds_upper && c->cfg.model == VGPA_MODEL_L96 && c->D >= 5;       // (the L96 kernels of 5 <= D <= 64 honour it)
+  EnergyArgs a = energy_args(c, edf, c->des_upper);
   hipError_t e = launch_energy(a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "energy launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;
@@ -475,7 +479,10 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   prof_mark(c, 1);
   hipError_t e = launch_obs(obs_args(c), c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
-  if ((rc = run_energy(c, nullptr))) return rc;
+  // (a symmetric-unit backward kernel reads the upper triangle of dEsde_dS only: the energy kernel writes nothing else then)
+  const bool sym_bwd = use_sym_units(c) && !use_lane(c) && !use_wave(c) && use_mfma(c, false, c->sym_inputs) && c->D <= kMaxSmallD &&
+                       !(c->cfg.flags & VGPA_FLAG_KEEP_PSI);
+  if ((rc = run_energy(c, nullptr, sym_bwd))) return rc;
   prof_mark(c, 2);
   if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
   prof_mark(c, 3);
@@ -991,6 +998,11 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
     case VGPA_FETCH_DESDE_DM: rc = download(c, out, c->d_dEm, BN * c->D); break;
     case VGPA_FETCH_DESDE_DS:
       if (!c->d_dEs || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "dEsde_dS is not kept by the time-chunked large-D sweep");
+      if (c->des_upper) {
+        hipError_t e = launch_mirror_upper(BN, c->D, c->d_dEs, c->stream);
+        if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "mirror launch failed: %s", hipGetErrorString(e));
+        c->des_upper = false;
+      }
       rc = download(c, out, c->d_dEs, BN * c->DD); break;
     case VGPA_FETCH_ESDE_T: rc = download(c, out, c->d_et, BN); break;
     case VGPA_FETCH_EDF: {

@@ -60,6 +60,8 @@ struct EnergyArgs {
   double* Edf;              // [B][Np][D][D] or nullptr
   double* dEm;              // [B][Np][D]
   double* dEs;              // [B][Np][D][D]
+  int ds_upper;             // L96, D <= 64: write only the upper triangle of dEs (row <= col) -- the consumer is a symmetric-unit backward
+                            // kernel, which reads nothing else (fused sweeps; VGPA_FETCH_DESDE_DS mirrors it on the way out)
   double* hyp;              // [B][Np][H] per-grid-point integrands of dEsde/dtheta, dEsde/dSigma (nullptr: skipped)
   double* Am;               // [B][Np][D] A_t m_t, a by-product the gradient assembly reuses (L96 kernel; may be nullptr)
   int32_t* status;          // [B] device status word (bit0: S_t not positive definite)
@@ -115,6 +117,8 @@ bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 bool sym_stores_q(int method, int D);      // the backward kernel launch_ode_mfma picks for sym_units honours OdeArgs::q_on
 // Psi_t = (diag(isg) A_t - Q''_t) / 2 in place (A: problem stride strideA, grid-point stride D*D)
+// the strict lower triangle of [batch * Np] D x D matrices from their upper one, in place
+hipError_t launch_mirror_upper(size_t n_mat, int D, double* m, hipStream_t st);
 hipError_t launch_psi_from_q(int batch, int Np, int D, size_t strideA, const double* A, const double* isg, double* psi_q, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
 hipError_t launch_obs(const ObsArgs& a, hipStream_t st);   // uses the grid-parallel variant when a.part != nullptr
