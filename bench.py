@@ -367,17 +367,24 @@ def main():
                              "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
                              "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r03_pmc_fetch_write_B512.csv"}
 
+    # streams of the default batched path (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I, B > #CUs): the backward kernel writes
+    # Q''_t = A_t / sigma^2 - 2 Psi_t where Psi_t would be, the gradient assembly reads Q''_t and S_t only, and dEsde_dS exists as its
+    # upper triangle (vgpa_hip.h VGPA_FLAG_KEEP_PSI; --keep-psi restores the round-2 streams)
+    n_cu_ = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    sym_path = (d > 44 or (B > n_cu_ and (d + 3) // 4 <= 10)) and not args.generic and not args.keep_psi
+    q_mode = sym_path and 33 <= d <= 40 and args.method.upper() in ("RK2", "RK4") and os.environ.get("VGPA_SYM_RUNS") != "1"
+    tri = d * (d + 1) / 2.0 if sym_path else float(d * d)
     kernels = {
         # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
         "solve_fwd": dict(bound="mfma", seconds=fwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
                           alg_bytes=B * 8.0 * n_pts * (2 * d * d + 2 * d)),       # read A,b ; write S,m
         "solve_bwd": dict(bound="mfma", seconds=bwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
-                          alg_bytes=B * 8.0 * n_pts * (3 * d * d + 2 * d)),       # read A, dEsde/dS, dEsde/dm ; write Psi, lam
+                          alg_bytes=B * 8.0 * n_pts * (2 * d * d + tri + 2 * d)),  # read A, dEsde/dS (upper), dEsde/dm ; write Psi | Q'', lam
         # per-grid-point kernels: HBM (energy: AI = 4 D^3 / (24 D^2) = D/6 flop/B; gradient: 2 D^3 / (32 D^2) = D/16)
-        "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (3 * d * d + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
-                           unit="GB/s"),                                          # read S, A, m, b ; write dEsde/dS, dEsde/dm, <f>, A m, e_t
-        "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * (4 * d * d + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
-                     unit="GB/s"),                                                # read A, S, Psi + vectors ; write gLa, gLb
+        "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (2 * d * d + tri + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
+                           unit="GB/s"),                                          # read S, A, m, b ; write dEsde/dS (upper), dEsde/dm, <f>, A m, e_t
+        "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * ((3 if q_mode else 4) * d * d + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
+                     unit="GB/s"),                                                # read Q'' (or A and Psi), S + vectors ; write gLa, gLb
     }
     nb_blocks = (d + 3) // 4
     method_id = {"EULER": 0, "HEUN": 1, "RK2": 2, "RK4": 3}.get(args.method.upper(), 3)
