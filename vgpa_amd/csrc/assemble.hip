@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
   const double v_b = vt ? bt[tid] : 0.0;
   const double v_ig = vt ? a.isig[tid * D + tid] : 0.0;
   const double v_lam = vt ? a.lam[o * D + tid] : 0.0;
+  const bool l96_band = !Edf && a.model == VGPA_MODEL_L96;
   if (tid < P) { mv[tid] = v_m; uv[tid] = 0.0; }
   if (D < P) {                                   // zero padding of the operands (rows / columns D..P-1)
     for (int e = tid; e < P * LD; e += NT) { QT[e] = 0.0; Ss[e] = 0.0; }
@@ -291,7 +292,9 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
     const int e = tid + q * NT;
     if (e < DD) {
       const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
-      const double ed = Edf ? ev[q] : edf_entry(a.model, a.theta, D, i, j, mv, s00);
+      // Lorenz-96 (the only model with D >= 5): the four-entry band of <df/dx> is added by the row's thread behind the barrier, so
+      // that this pass has no predicates (round 3: -0.5 ms per 512-problem launch)
+      const double ed = Edf ? ev[q] : (l96_band ? 0.0 : edf_entry(a.model, a.theta, D, i, j, mv, s00));
       Ss[i * LD + j] = sv[q];
       // (psi_is_q: the backward kernel left Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- one stream less)
       QT[j * LD + i] = a.psi_is_q ? __builtin_fma(ig[q], ed, pv[q]) : ig[q] * (ed + av[q]) - 2.0 * pv[q];
@@ -306,6 +309,17 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
     gB[tid] = a.dt * u;
   }
   __syncthreads();
+  if (l96_band) {
+    if (vt) {                                      // row k = tid of Sigma^-1 <df/dx> (lorenz_96.py:35-83), D >= 5: four distinct entries
+      const int k = tid, kp1 = wrapi(k + 1, D), km1 = wrapi(k - 1, D), km2 = wrapi(k - 2, D);
+      const double mm1 = mv[km1];
+      QT[k * LD + k] -= v_ig;
+      QT[kp1 * LD + k] = __builtin_fma(v_ig, mm1, QT[kp1 * LD + k]);
+      QT[km2 * LD + k] = __builtin_fma(-v_ig, mm1, QT[km2 * LD + k]);
+      QT[km1 * LD + k] = __builtin_fma(v_ig, mv[kp1] - mv[km2], QT[km1 * LD + k]);
+    }
+    __syncthreads();
+  }
 
   // ---- Q.S on the matrix cores: acc[q][ii] = block-row (wave + 4 ii), column group q
   const int r4 = lane >> 4, c4 = lane & 3, b = (lane >> 2) & 3;
@@ -365,6 +379,186 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
     const int Ib = v * G + b / rem;
     const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
     if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) gA[row * D + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
+  }
+}
+
+
+#ifndef VGPA_GRAD_TPW
+#define VGPA_GRAD_TPW 4
+#endif
+constexpr int kGradTPW = VGPA_GRAD_TPW;      // consecutive grid points per workgroup of k_grad_mfma: the loads of point t+1 are in flight under the product of t
+// The same assembly for GradArgs::psi_is_q (the batched fused sweeps of 33 <= D <= 40: `psi` holds Q''_t, A_t and a dense <df/dx> are not
+// streamed), software-pipelined over kGradTPW consecutive grid points of one problem.
+template <int NB>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) k_grad_mfma_q(GradArgs a) {
+  constexpr bool QMODE = true;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int P = 4 * NB, LD = P + 1;
+  constexpr int NQ = NB / 4, REM = NB % 4, G = REM ? 4 / REM : 0;
+  constexpr int NLEFT = REM ? (NB + G - 1) / G : 0;
+  constexpr int RW = (NB + 3) / 4;            // block-rows per wave
+  constexpr int LW = (NLEFT + 3) / 4;         // left-over units per wave
+  constexpr int rem = REM ? REM : 1;
+  const int D = a.D, DD = D * D;
+  const int prob = blockIdx.y, tid = threadIdx.x;
+  const int t_first = blockIdx.x * kGradTPW;
+  const int t_end = t_first + kGradTPW < a.Np ? t_first + kGradTPW : a.Np;
+  const int lane = tid & 63, wave = tid >> 6;
+  double* QT = smem;              // [P][LD]
+  double* Ss = QT + P * LD;       // [P][LD]
+  double* mv = Ss + P * LD;       // [P]
+  double* rv = mv + P;            // -Ef - A m + b
+  double* uv = rv + P;            // dEb + lam
+  const size_t len_x = (size_t)a.Np * DD + (size_t)a.Np * D;
+
+  // ALL HBM loads of a grid point are issued before the first one is consumed -- the matrices and (threads < D) the vector
+  // entries -- and, from the second grid point of the workgroup on, a whole product ahead of their use (round 3: the kernel is
+  // bound by its HBM streams, and with five workgroups per CU the load phase of one was not covered by the others)
+  constexpr int EPT = (P * P + NT - 1) / NT;
+  const unsigned magic = ((1u << 20) + (unsigned)D - 1u) / (unsigned)D;   // e / D for e < 4096, 5 <= D <= 64
+  double sv[EPT], pv[EPT], av[QMODE ? 1 : EPT], ig[QMODE ? 1 : EPT], ev[QMODE ? 1 : EPT];
+  double v_m = 0.0, v_am = 0.0, v_ef = 0.0, v_b = 0.0, v_lam = 0.0;
+  const bool vt = tid < D;
+  const double v_ig = vt ? a.isig[tid * D + tid] : 0.0;
+  if constexpr (!QMODE) {
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {               // (the diagonal of Sigma^-1 of this thread's elements: the same for every grid point)
+      const int e = tid + q * NT;
+      const int i = (int)(((unsigned)(e < DD ? e : 0) * magic) >> 20);
+      ig[q] = e < DD ? a.isig[i * D + i] : 0.0;
+    }
+  }
+  auto request = [&](int t) {
+    const size_t o = (size_t)prob * a.Np + t;
+    const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
+    const double* St = a.S + o * DD;
+    const double* Pt = a.psi + o * DD;
+    const double* Edf = a.Edf ? a.Edf + o * DD : nullptr;
+    (void)At; (void)Edf;
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+      const int e = tid + q * NT;
+      const bool in = e < DD;
+      sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0;
+      if constexpr (!QMODE) { av[q] = in ? At[e] : 0.0; ev[q] = (in && Edf) ? Edf[e] : 0.0; }
+    }
+    v_m = vt ? a.m[o * D + tid] : 0.0;
+    v_am = (vt && a.Am) ? a.Am[o * D + tid] : 0.0;
+    v_ef = vt ? a.Ef[o * D + tid] : 0.0;
+    v_b = vt ? a.b[(size_t)prob * a.strideB + (size_t)t * D + tid] : 0.0;
+    v_lam = vt ? a.lam[o * D + tid] : 0.0;
+  };
+  request(t_first);
+  if (tid < P) uv[tid] = 0.0;
+  if (D < P) {                                   // zero padding of the operands (rows / columns D..P-1)
+    for (int e = tid; e < P * LD; e += NT) { QT[e] = 0.0; Ss[e] = 0.0; }
+  }
+
+  const int r4 = lane >> 4, c4 = lane & 3, b = (lane >> 2) & 3;
+  const double* pa = QT + r4 * LD + c4;
+  const double* pb = Ss + r4 * LD;
+  const int colq = lane & 15;
+  const int coll = 4 * (4 * NQ + b % rem) + c4;
+  int rowoff[RW], leftoff[LW > 0 ? LW : 1];
+#pragma unroll
+  for (int ii = 0; ii < RW; ii++) { const int I = wave + 4 * ii; rowoff[ii] = 4 * (I < NB ? I : NB - 1); }
+#pragma unroll
+  for (int vv = 0; vv < LW; vv++) {
+    const int v = wave + 4 * vv;
+    int ib = (v < NLEFT ? v : NLEFT - 1) * G + b / rem;
+    leftoff[vv] = 4 * (ib < NB ? ib : NB - 1);            // spare block slots read valid memory; result unused
+  }
+
+#pragma unroll 1
+  for (int t = t_first; t < t_end; t++) {
+    const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
+    double* gA = a.g + (size_t)prob * len_x + (size_t)t * DD;
+    double* gB = a.g + (size_t)prob * len_x + (size_t)a.Np * DD + (size_t)t * D;
+    __syncthreads();                               // the previous point's product has read the operands (first pass: the padding is written)
+    if (tid < P) mv[tid] = v_m;
+    __syncthreads();
+    const bool has_edf = a.Edf != nullptr;
+    // the operands: S_t as it is, Q^T without the <df/dx> band (one predicate-free pass; the band of the Lorenz-96 Jacobian -- four
+    // entries per row -- is added by the row's thread behind the barrier)
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+      const int e = tid + q * NT;
+      if (e < DD) {
+        const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
+        Ss[i * LD + j] = sv[q];
+        // (QMODE: the backward kernel left Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- one stream less)
+        if constexpr (QMODE) QT[j * LD + i] = pv[q];
+        else QT[j * LD + i] = __builtin_fma(ig[q], has_edf ? ev[q] + av[q] : av[q], -2.0 * pv[q]);
+      }
+    }
+    if (vt) {
+      double s = v_am;
+      if (!a.Am) { s = 0.0; for (int k = 0; k < D; k++) s = __builtin_fma(At[tid * D + k], mv[k], s); }
+      const double r = -v_ef - s + v_b;
+      const double u = v_ig * r + v_lam;
+      uv[tid] = u;
+      gB[tid] = a.dt * u;
+    }
+    __syncthreads();
+    if (vt && !has_edf && a.model == VGPA_MODEL_L96) {         // row k = tid of Sigma^-1 <df/dx> (lorenz_96.py:35-83), D >= 5: four distinct entries
+      const int k = tid, kp1 = wrapi(k + 1, D), km1 = wrapi(k - 1, D), km2 = wrapi(k - 2, D);
+      const double mm1 = mv[km1];
+      QT[k * LD + k] -= v_ig;
+      QT[kp1 * LD + k] = __builtin_fma(v_ig, mm1, QT[kp1 * LD + k]);
+      QT[km2 * LD + k] = __builtin_fma(-v_ig, mm1, QT[km2 * LD + k]);
+      QT[km1 * LD + k] = __builtin_fma(v_ig, mv[kp1] - mv[km2], QT[km1 * LD + k]);
+    }
+    __syncthreads();
+    if (QMODE && t + 1 < t_end) request(t + 1);   // in flight under the product below (QMODE: two matrices = 28 registers; else requested behind the product)
+
+    // ---- Q.S on the matrix cores: acc[q][ii] = block-row (wave + 4 ii), column group q
+    double acc[(NQ > 0 ? NQ : 1) * RW], accl[LW > 0 ? LW : 1];
+#pragma unroll
+    for (int u = 0; u < (NQ > 0 ? NQ : 1) * RW; u++) acc[u] = 0.0;
+#pragma unroll
+    for (int u = 0; u < (LW > 0 ? LW : 1); u++) accl[u] = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < NB; kk++) {
+      double bq[NQ > 0 ? NQ : 1];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) bq[q] = pb[kk * 4 * LD + 16 * q + colq];
+      double bl = 0.0;
+      if (NLEFT > 0) bl = pb[kk * 4 * LD + coll];
+#pragma unroll
+      for (int ii = 0; ii < RW; ii++) {
+        if (NQ > 0) {
+          const double af = pa[kk * 4 * LD + rowoff[ii]];
+#pragma unroll
+          for (int q = 0; q < NQ; q++) acc[q * RW + ii] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * RW + ii], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int vv = 0; vv < LW; vv++) {
+        const double af = pa[kk * 4 * LD + leftoff[vv]];
+        accl[vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bl, accl[vv], 0, 0, 0);
+      }
+      // (the next grid point's operands are in flight in registers: keep the scheduler from hoisting every fragment read of the product)
+      if (kk % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- gLa = dt (Q S - u m^T), straight from the accumulators (16 contiguous doubles per lane group)
+#pragma unroll
+    for (int ii = 0; ii < RW; ii++) {
+      const int I = wave + 4 * ii;
+      const int row = 4 * I + r4;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int col = 16 * q + 4 * b + c4;
+        if (I < NB && row < D && col < D) gA[row * D + col] = a.dt * (acc[q * RW + ii] - uv[row] * mv[col]);
+      }
+    }
+#pragma unroll
+    for (int vv = 0; vv < LW; vv++) {
+      const int v = wave + 4 * vv;
+      const int Ib = v * G + b / rem;
+      const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
+      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) gA[row * D + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
+    }
+    if (!QMODE && t + 1 < t_end) request(t + 1);
   }
 }
 
@@ -530,6 +724,16 @@ hipError_t launch_grad(const GradArgs& a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)k_grad_mfma<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k_grad_mfma<NBV>, dim3(a.Np, a.batch), dim3(NT), lds, st, a);                                  \
     return hipGetLastError();
+    if (a.psi_is_q && !a.Edf && (nb == 9 || nb == 10)) {          // (what sym::stores_q allows)
+      if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_grad_mfma_q<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_grad_mfma_q<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }
+      const dim3 grid((a.Np + kGradTPW - 1) / kGradTPW, a.batch);
+      if (nb == 9) hipLaunchKernelGGL(k_grad_mfma_q<9>, grid, dim3(NT), lds, st, a);
+      else hipLaunchKernelGGL(k_grad_mfma_q<10>, grid, dim3(NT), lds, st, a);
+      return hipGetLastError();
+    }
     switch (nb) {
       VGPA_GRAD_CASE(2) VGPA_GRAD_CASE(3) VGPA_GRAD_CASE(4) VGPA_GRAD_CASE(5) VGPA_GRAD_CASE(6) VGPA_GRAD_CASE(7)
       VGPA_GRAD_CASE(8) VGPA_GRAD_CASE(9) VGPA_GRAD_CASE(10) VGPA_GRAD_CASE(11) VGPA_GRAD_CASE(12)
