@@ -278,7 +278,8 @@ struct WaveGemmGeo {
   static constexpr int NU = NB * NQ + NLEFT;
 };
 
-template <int NB, int MODE>
+// UPPER: only the units that hold an element with row <= col (a symmetric result of which the caller keeps the upper triangle)
+template <int NB, int MODE, bool UPPER = false>
 __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const double* __restrict__ Bm, int LD,
                                           double (&acc)[WaveGemmGeo<NB>::NU], const double* __restrict__ bscale = nullptr) {
   using g = WaveGemmGeo<NB>;
@@ -305,12 +306,12 @@ __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const 
       if (MODE == 1 && kk < I) continue;
       bool any = false;
 #pragma unroll
-      for (int q = 0; q < g::NQ; q++) any = any || (kk >= 4 * q);
+      for (int q = 0; q < g::NQ; q++) any = any || (kk >= 4 * q && !(UPPER && 4 * q + 3 < I));
       if (!any) continue;
       const double af = pa[kk * 4 * LD + 4 * I];
 #pragma unroll
       for (int q = 0; q < g::NQ; q++)
-        if (kk >= 4 * q) acc[q * NB + I] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * NB + I], 0, 0, 0);
+        if (kk >= 4 * q && !(UPPER && 4 * q + 3 < I)) acc[q * NB + I] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * NB + I], 0, 0, 0);
     }
     if (g::NLEFT > 0 && kk >= 4 * g::NQ) {
 #pragma unroll
@@ -1047,12 +1048,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   double* ds = a.dEs + o * D * D;
   {
     double acc[WaveGemmGeo<NB>::NU];
-    wave_gemm<NB, 1>(S.Lm, S.Lm, LD, acc, S.qq);
+    if (a.ds_upper) {                 // (units below the diagonal are not even computed: -22 % of the SYRK's products at NB = 10)
+      wave_gemm<NB, 1, true>(S.Lm, S.Lm, LD, acc, S.qq);
 #pragma unroll
-    for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
-      int row, col; bool ok;
-      wave_gemm_elem<NB>(u, row, col, ok);
-      if (ok && row < D && col < D && (row <= col || !a.ds_upper)) ds[row * D + col] = 0.5 * c * acc[u];
+      for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
+        if (u < NB * WaveGemmGeo<NB>::NQ && 4 * (u / NB) + 3 < u % NB) continue;
+        int row, col; bool ok;
+        wave_gemm_elem<NB>(u, row, col, ok);
+        if (ok && row < D && col < D && row <= col) ds[row * D + col] = 0.5 * c * acc[u];
+      }
+    } else {
+      wave_gemm<NB, 1>(S.Lm, S.Lm, LD, acc, S.qq);
+#pragma unroll
+      for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
+        int row, col; bool ok;
+        wave_gemm_elem<NB>(u, row, col, ok);
+        if (ok && row < D && col < D) ds[row * D + col] = 0.5 * c * acc[u];
+      }
     }
   }
 
