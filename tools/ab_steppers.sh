@@ -1,6 +1,7 @@
 #!/bin/bash
-# Same-box A/B of stepping-kernel build variants (boxes of the pool differ by 2-4 %): each variant = extra compiler flags for
-# the stepper translation units, rebuilt on the box, benched twice.   tools/ab_steppers.sh "name1:flags1" "name2:flags2" ...
+# Same-box A/B of kernel build variants (boxes of the pool differ by 2-4 %): each variant = extra compiler flags (-D macros of the
+# steppers, the energy kernel or the gradient assembly), rebuilt on the box, benched twice.
+#   tools/ab_steppers.sh "name1:flags1" "name2:flags2" ...
 set -u
 out=gpurun_out/ab_$(date +%H%M%S).txt
 for spec in "$@"; do
