@@ -371,7 +371,8 @@ def main():
     # Q''_t = A_t / sigma^2 - 2 Psi_t where Psi_t would be, the gradient assembly reads Q''_t and S_t only, and dEsde_dS exists as its
     # upper triangle (vgpa_hip.h VGPA_FLAG_KEEP_PSI; --keep-psi restores the round-2 streams)
     n_cu_ = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    sym_path = (d > 44 or (B > n_cu_ and (d + 3) // 4 <= 10)) and not args.generic and not args.keep_psi
+    sym_path = (d > 44 or (B > n_cu_ and (d + 3) // 4 <= 10) or ((d + 3) // 4 in (9, 10) and os.environ.get("VGPA_ODE_KERNEL") != "pe")) \
+               and not args.generic and not args.keep_psi
     q_mode = sym_path and 33 <= d <= 40 and args.method.upper() in ("RK2", "RK4") and os.environ.get("VGPA_SYM_RUNS") != "1"
     tri = d * (d + 1) / 2.0 if sym_path else float(d * d)
     kernels = {
@@ -391,7 +392,8 @@ def main():
     # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 64): symmetric-unit kernels from two
     # problems per CU on (and for 44 < D), role-specialised ones below (vgpa_api.hip::use_sym_units)
     n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym"
+    keep_pe = os.environ.get("VGPA_ODE_KERNEL") == "pe"
+    sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym" or (nb_blocks in (9, 10) and not keep_pe)
     wpe = 2 if nb_blocks <= 10 else 1
     cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
     # (last parameter: the backward cover kernels of RK2 / RK4 store Q''_t = Sigma^-1 A_t - 2 Psi_t for the gradient assembly)

@@ -82,6 +82,16 @@ def test_every_block_geometry(d, method):
     check(p, x)
 
 
+@pytest.mark.parametrize("d", [33, 36, 40])
+@pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
+def test_role_specialised_steppers_at_33_to_40(d, method, monkeypatch):
+    """33 <= D <= 40 defaults to the symmetric-unit cover kernels at every batch size; VGPA_ODE_KERNEL=pe (read at vgpa_create) keeps the
+    role-specialised family reachable, and tested, there."""
+    monkeypatch.setenv("VGPA_ODE_KERNEL", "pe")
+    p, x = make_problem("L96", d, 14, method=method)
+    check(p, x)
+
+
 @pytest.mark.parametrize("d", [45, 48, 57, 64])
 @pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
 def test_matrix_core_steppers_above_44(d, method):

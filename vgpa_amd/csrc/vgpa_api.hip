@@ -186,12 +186,19 @@ static bool use_wave(vgpa_ctx* c) {
 // D <= 44 has two families of matrix-core stepping kernels: the symmetric-unit ones (two problems per CU, 4 waves each) win
 // once there are more problems than CUs, the role-specialised ones (one problem per CU, 8 waves) below that and for one
 // problem.  (D = 41 .. 44: one symmetric-unit workgroup per CU only -- its LDS -- so the role-specialised kernels stay.)
+// 33 <= D <= 40 (round 3): the fragment-cover kernels win at every batch size -- a lone workgroup steps 4 % faster than the
+// role-specialised pair (4.45 / 4.93 against 4.65 / 4.97 ms per forward / backward sweep of one problem), and the Q'' stream and
+// the pipelined gradient assembly come with them; VGPA_ODE_KERNEL=pe in the environment keeps the role-specialised family there
+// (comparison runs, tests).
 static bool use_sym_units(vgpa_ctx* c) { return c->sym_units; }   // decided once in vgpa_create (pick_kernel_family)
 
 static void pick_kernel_family(vgpa_ctx* c) {
   int n_cu = 0;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess || n_cu <= 0) n_cu = 256;
-  c->sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) != 0 || (c->B > n_cu && (c->D + 3) / 4 <= 10);
+  const char* fam = getenv("VGPA_ODE_KERNEL");
+  const bool keep_pe = fam && !strcmp(fam, "pe");
+  const int nb = (c->D + 3) / 4;
+  c->sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) != 0 || (c->B > n_cu && nb <= 10) || ((nb == 9 || nb == 10) && !keep_pe);
 }
 
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
