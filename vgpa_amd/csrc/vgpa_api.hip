@@ -775,6 +775,7 @@ int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, con
   if ((rc = ensure(c, &c->d_dEs, BN * c->DD))) return rc;
   if ((rc = ensure(c, &c->d_psi, BN * c->DD))) return rc;
   if ((rc = upload(c, c->d_dEs, desde_ds, BN * c->DD))) return rc;
+  c->des_upper = false;                  // the caller's array is complete
   if ((rc = upload(c, c->d_jm_dense, deobs_dm, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_js_dense, deobs_ds, BN * c->DD))) return rc;
   const bool sym = stack_symmetric(desde_ds, BN, c->D) && stack_symmetric(deobs_ds, BN, c->D);
