@@ -58,9 +58,6 @@ constexpr int kMaxNB = 16;          // D <= 64
 #ifndef VGPA_SYM_INTERLEAVE
 #define VGPA_SYM_INTERLEAVE 1          // fragment reads between the products (sched_group_barrier) instead of in blocks
 #endif
-#ifndef VGPA_SYM_STAGGER
-#define VGPA_SYM_STAGGER 0            // s_sleep argument (64-cycle units) for the odd-slot workgroup at start; 0 = off
-#endif
 #ifndef VGPA_SYM_TAILPRIO
 #define VGPA_SYM_TAILPRIO 1
 #endif
@@ -299,19 +296,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   double* const xvw = Mb + g::XS + wave * g::XV;           // this wave's copy of the stage vector
   double* const pvb = Mb + g::XS + 4 * g::XV;              // [2][NPART][PP] partial inner products
   double* const trash = pvb + 2 * g::PV + 2 * tid;         // one 16-byte unit per thread
-#if VGPA_SYM_STAGGER
-  {   // experiment: the workgroup in the odd wave slot of its SIMDs starts part of a stage late (EXPERIMENTS.md)
-    if (tid == 0) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      reinterpret_cast<unsigned*>(smem)[0] = hw;
-    }
-    __syncthreads();
-    const unsigned hw0 = reinterpret_cast<volatile unsigned*>(smem)[0];
-    __syncthreads();
-    if (hw0 & 1u) __builtin_amdgcn_s_sleep(VGPA_SYM_STAGGER);
-  }
-#endif
   for (int i = tid; i < (int)g::LDS_DOUBLES; i += 256) smem[i] = 0.0;
   // QOUT (backward, mid-point methods, Sigma = sigma^2 I): the state store writes Q''_t = A_t / sigma^2 - 2 Psi_t in place of Psi_t --
   // the only combination of A_t and Psi_t the gradient assembly reads (assemble.hip), which then streams one matrix less.  (A
