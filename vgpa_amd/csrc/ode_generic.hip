@@ -247,7 +247,7 @@ __device__ __forceinline__ void load_jump(const OdeArgs& a, int prob, int t1, in
     for (int q = 0; q < EPT; q++) { const int e = tid + q * NT; js[q] = (e < DD) ? p[e] : 0.0; }
     jm = (tid < D) ? a.jm_dense[((size_t)prob * a.Np + t1) * D + tid] : 0.0;
   } else {
-    const int n = a.obs_idx ? a.obs_idx[t1] : -1;
+    const int n = a.obs_idx ? ldu(a.obs_idx, t1) : -1;           // (scalar load: see vgpa_internal.h)
 #pragma unroll
     for (int q = 0; q < EPT; q++) { const int e = tid + q * NT; js[q] = (n >= 0 && e < DD) ? a.js_const[e] : 0.0; }
     jm = (n >= 0 && tid < D) ? a.jm_sparse[((size_t)prob * a.n_obs + n) * D + tid] : 0.0;

@@ -62,6 +62,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double ldg(const double* base, unsigned off8) {
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off8);
 }
+using vgpa::ldu;
 __device__ __forceinline__ void stg(double* base, unsigned off8, double v) {
   *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off8) = v;
 }
@@ -687,7 +688,7 @@ struct ERole {
     S.c0 = vl ? ldg(S.cin + vec(tidx(0)), te8) : 0.0;
     S.c1 = (vl && n_steps >= 1) ? ldg(S.cin + vec(tidx(1)), te8) : 0.0;
     if (!FWD && n_steps >= 1) {
-      S.n_obs_cur = (!DENSEJ && a.obs_idx) ? a.obs_idx[tidx(1)] : -1;
+      S.n_obs_cur = (!DENSEJ && a.obs_idx) ? ldu(a.obs_idx, tidx(1)) : -1;
       S.jm = jump_vector(S, tidx(1), S.n_obs_cur);
     }
 #pragma unroll
@@ -700,7 +701,7 @@ struct ERole {
     const int n_steps = a.Np - 1;
     S.c2 = (vl && i + 2 <= n_steps) ? ldg(S.cin + vec(tidx(i + 2)), te8) : 0.0;
     if (!FWD) {
-      S.n_obs_next = (!DENSEJ && a.obs_idx && i + 2 <= n_steps) ? a.obs_idx[tidx(i + 2)] : -1;
+      S.n_obs_next = (!DENSEJ && a.obs_idx && i + 2 <= n_steps) ? ldu(a.obs_idx, tidx(i + 2)) : -1;
       S.jm_next = (i + 2 <= n_steps) ? jump_vector(S, tidx(i + 2), S.n_obs_next) : 0.0;
     }
   }

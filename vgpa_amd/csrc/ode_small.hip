@@ -201,7 +201,7 @@ __device__ __forceinline__ void load_jump(const OdeArgs& a, int prob, int t1, do
     ld_mat<D>(a.js_dense + ((size_t)prob * a.Np + t1) * DD, js);
     ld_vec<D>(a.jm_dense + ((size_t)prob * a.Np + t1) * D, jm);
   } else {
-    const int n = a.obs_idx ? a.obs_idx[t1] : -1;
+    const int n = a.obs_idx ? ldu(a.obs_idx, t1) : -1;           // (scalar load: see vgpa_internal.h)
     if (n >= 0) {
       ld_mat<D>(a.js_const, js);
       ld_vec<D>(a.jm_sparse + ((size_t)prob * a.n_obs + n) * D, jm);

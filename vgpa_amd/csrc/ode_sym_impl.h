@@ -43,6 +43,7 @@ using mfma::cmax;
 using mfma::cmin;
 using mfma::d2_t;
 using mfma::ldg;
+using mfma::ldu;
 using mfma::n_stages;
 using mfma::settle;
 using mfma::stage_op;
@@ -413,7 +414,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   };
   double vk = FWD ? ldg(a.m0, lane8) : 0.0, v1 = 0.0;      // v1: Heun's first slope / RK4's running sum k1 + 2 k2 + 2 k3
   double c0 = ldg(cin + vec(tidx(0)), lane8), c1 = ldg(cin + vec(tclamp(1)), lane8), c2 = 0.0;
-  int n_obs_cur = sparse_j ? a.obs_idx[tclamp(1)] : -1, n_obs_next = sparse_j ? a.obs_idx[tclamp(2)] : -1, n_obs_nn = -1;
+  int n_obs_cur = sparse_j ? ldu(a.obs_idx, tclamp(1)) : -1, n_obs_next = sparse_j ? ldu(a.obs_idx, tclamp(2)) : -1, n_obs_nn = -1;
   double jm = n_steps >= 1 ? jump_vector(tidx(1), n_obs_cur) : 0.0, jm_next = 0.0;
 
   __syncthreads();                       // LDS zero-filled
@@ -460,7 +461,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #pragma unroll
       for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * DD, gofs[s]);
       jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
-      n_obs_nn = (sparse_j && step + 3 <= n_steps) ? a.obs_idx[tidx(step + 3)] : -1;
+      n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
     }
   };
 

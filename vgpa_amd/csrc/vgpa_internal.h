@@ -9,6 +9,17 @@
 
 namespace vgpa {
 
+#ifdef __HIPCC__
+// A wave-uniform int from read-only global memory as a SCALAR load (s_load_dword -> SGPR, counted by lgkmcnt).  Behind the first
+// global store of a kernel the compiler no longer proves such a load unclobbered and emits a vector load + s_waitcnt vmcnt(0) +
+// v_readfirstlane on the spot -- i.e. it waits for every HBM prefetch the step has just issued (round 3: this was the backward
+// steppers' observation-index lookup, one exposed memory round trip per time step).
+__device__ __forceinline__ int ldu(const int32_t* p, int i) {
+  typedef const int32_t __attribute__((address_space(4))) * cptr;
+  return ((cptr)p)[i];
+}
+#endif
+
 constexpr int kMaxSmallD = 64;   // single-workgroup (LDS resident) stepping kernels
 constexpr int kMaxLaneD = 4;     // one-lane-per-problem stepping kernels (ode_small.hip)
 constexpr int kMaxTheta = 4;
