@@ -62,6 +62,9 @@ constexpr int kMaxNB = 16;          // D <= 64
 #ifndef VGPA_SYM_TAILPRIO
 #define VGPA_SYM_TAILPRIO 1
 #endif
+#ifndef VGPA_SYM_LOOP1
+#define VGPA_SYM_LOOP1 1               // cover kernels: the loop unit (diagonal blocks) runs one chain + an in-block transpose
+#endif
 
 // ---- runs: a cover of the unordered pairs {c, j} of super-block indices (loops included) by stars of <= 2 edges ---------
 // Run = super-row c with up to two partners.  Greedy: every loop (c, c) with the edge to c + 1; then, vertex by vertex, two
@@ -132,19 +135,27 @@ __host__ __device__ constexpr int sym_run_count(int nsb) {
 // bank conflicted.  Five block pairs are covered twice; the first occurrence owns the elements.
 constexpr int kCoverPat[4][2] = {{0, 2}, {0, 3}, {1, 2}, {1, 3}};          // unit slot -> (row-side map, column-side map)
 constexpr int kCoverMaps[4][4][4] = {                                      // [wave][map a0, a1, b0, b1][block q]
-    {{1, 8, 6, 1}, {2, 6, 7, 3}, {9, 2, 5, 2}, {6, 5, 5, 4}},
+    {{1, 8, 6, 1}, {2, 6, 7, 3}, {6, 5, 5, 4}, {9, 2, 5, 2}},
     {{9, 9, 8, 0}, {8, 1, 1, 2}, {8, 1, 1, 2}, {4, 5, 0, 5}},
     {{6, 9, 3, 6}, {4, 0, 5, 9}, {4, 0, 5, 9}, {0, 7, 4, 3}},
     {{8, 1, 7, 8}, {6, 7, 2, 3}, {6, 7, 2, 3}, {7, 3, 4, 0}}};
-constexpr int kCoverUnits[4] = {3, 4, 4, 4};
+constexpr int kCoverUsed[4] = {0xB, 0xF, 0xF, 0xF};                        // bit s: unit slot s of the wave is in use (the rectangle wave has three)
 constexpr bool kCoverAlias[4] = {false, true, true, true};                 // map b0 is map a1
+// Slot 2 = (a1, b0) is the LOOP unit of a triangle wave (b0 is a1): its four blocks are diagonal blocks -- and every diagonal block
+// of the matrix sits in one of the three loop units (static_assert below).  For a diagonal block the second chain X^T Aop is the
+// transpose of the first, block by block, so the loop unit runs ONE chain and adds its accumulator's in-block transpose (one
+// cross-lane exchange per stage): 70 products per wave and stage instead of 80.  The rectangle wave parks its unused unit in
+// slot 2, so that the instruction stream is the same for all four waves.
+constexpr int kCoverLoopSlot = 2;
+__host__ __device__ constexpr bool cover_slot_used(int w, int s) { return (kCoverUsed[w] >> s) & 1; }
 // does (wave w, slot s, block q) own its block pair (first occurrence in (w, s, q) order)?
 __host__ __device__ constexpr bool cover_owner(int w, int s, int q) {
   const int I = kCoverMaps[w][kCoverPat[s][0]][q], J = kCoverMaps[w][kCoverPat[s][1]][q];
   const int lo = I < J ? I : J, hi = I < J ? J : I;
   for (int w2 = 0; w2 <= w; w2++)
-    for (int s2 = 0; s2 < kCoverUnits[w2]; s2++)
+    for (int s2 = 0; s2 < 4; s2++)
       for (int q2 = 0; q2 < 4; q2++) {
+        if (!cover_slot_used(w2, s2)) continue;
         if (w2 == w && (s2 > s || (s2 == s && q2 >= q))) return true;
         const int I2 = kCoverMaps[w2][kCoverPat[s2][0]][q2], J2 = kCoverMaps[w2][kCoverPat[s2][1]][q2];
         if ((I2 < J2 ? I2 : J2) == lo && (I2 < J2 ? J2 : I2) == hi) return false;
@@ -159,7 +170,7 @@ __host__ __device__ constexpr CoverOwnerTab cover_owner_tab() {
     for (int s = 0; s < 4; s++) {
       unsigned char bits = 0;
       for (int q = 0; q < 4; q++)
-        if (s < kCoverUnits[w] && cover_owner(w, s, q)) bits = (unsigned char)(bits | (1u << q));
+        if (cover_slot_used(w, s) && cover_owner(w, s, q)) bits = (unsigned char)(bits | (1u << q));
       t.m[w][s] = bits;
     }
   return t;
@@ -168,11 +179,24 @@ __device__ constexpr CoverOwnerTab kCoverOwner = cover_owner_tab();
 __host__ __device__ constexpr int cover_pairs_owned() {
   int n = 0;
   for (int w = 0; w < 4; w++)
-    for (int s = 0; s < kCoverUnits[w]; s++)
-      for (int q = 0; q < 4; q++) n += cover_owner(w, s, q) ? 1 : 0;
+    for (int s = 0; s < 4; s++)
+      for (int q = 0; q < 4; q++) n += (cover_slot_used(w, s) && cover_owner(w, s, q)) ? 1 : 0;
   return n;
 }
 static_assert(cover_pairs_owned() == 55, "the fragment cover must own every block pair of the 10 x 10 upper triangle exactly once");
+// diagonal block pairs appear in the loop slot of the triangle waves and nowhere else
+__host__ __device__ constexpr bool cover_diagonals_in_loop_units() {
+  for (int w = 0; w < 4; w++)
+    for (int s = 0; s < 4; s++)
+      for (int q = 0; q < 4; q++) {
+        if (!cover_slot_used(w, s)) continue;
+        const bool diag = kCoverMaps[w][kCoverPat[s][0]][q] == kCoverMaps[w][kCoverPat[s][1]][q];
+        const bool loop = kCoverAlias[w] && s == kCoverLoopSlot;
+        if (diag != loop) return false;
+      }
+  return !cover_slot_used(0, kCoverLoopSlot);
+}
+static_assert(cover_diagonals_in_loop_units(), "single-chain loop units: every diagonal block in slot 2 of a triangle wave, slot 2 of the rectangle wave unused");
 
 template <int NB_>
 struct SGeo {
@@ -282,6 +306,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   using g = SGeo<NB>;
   constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = g::MAXS, LD = g::LD, NKP = g::NKP;
   constexpr bool COVER = (GR == 0);      // fragment cover (NSB = 5) instead of runs: see kCoverMaps
+  constexpr bool LOOP1 = COVER && VGPA_SYM_LOOP1;      // single-chain loop units: see kCoverLoopSlot
   static_assert(!COVER || (g::NSB == 5 && MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
@@ -311,7 +336,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   int colm[4] = {0, 0, 0, 0};            // cover: LDS column offset of this lane's fragment element, per map
   unsigned gofs[MAXS];
   bool own[MAXS], wd[MAXS], wm[MAXS];
-  const int cov_units = COVER ? kCoverUnits[wave] : 0;
+  const int cov_used = COVER ? kCoverUsed[wave] : 0;
+  const bool loop_diag = r4 == c4;                     // diagonal element of a diagonal block (loop unit)
+  const int loop_src = 16 * c4 + 4 * bq + r4;          // the lane that holds element (c4, r4) of the same block
   if constexpr (COVER) {
 #pragma unroll
     for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * kCoverMaps[wave][m][bq] + c4) ^ r4);
@@ -320,7 +347,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       const int Ib = kCoverMaps[wave][kCoverPat[s][0]][bq], Jb = kCoverMaps[wave][kCoverPat[s][1]][bq];
       const int row = 4 * Ib + r4, col = 4 * Jb + c4;
       const bool first = (kCoverOwner.m[wave][s] >> bq) & 1u;     // (a compile-time table, looked up with the run-time wave / block)
-      const bool act = s < cov_units && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
+      const bool act = ((cov_used >> s) & 1) && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
       offD[s] = elem_off<NB>(row, col);
       offM[s] = elem_off<NB>(col, row);
       wd[s] = act;
@@ -733,6 +760,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
             else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
             f = own[s] ? -f : 0.0;
+            if (LOOP1 && s == kCoverLoopSlot) f = loop_diag ? 0.5 * f : f;     // (the in-block transpose below adds the diagonal to itself)
           }
           w[u] = f;
         }
@@ -764,13 +792,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #pragma unroll
             for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+            for (int u = 0; u < 4; u++)
+              if (!(LOOP1 && u == kCoverLoopSlot)) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
           }
           if (t + 1 < NSTEP) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 6; i++) {
               __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two matrix-core products
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {                            // (14 products per step with single-chain loop units, 16 without)
+              if constexpr (LOOP1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              else __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -780,7 +815,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #pragma unroll
             for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA[cur][u >> 1][hh], fX[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
+            for (int u = 0; u < 4; u++)
+              if (!(LOOP1 && u == kCoverLoopSlot)) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX[cur][u >> 1][hh], fA[cur][2 + (u & 1)][hh], w[u], 0, 0, 0);
             if (hh == 0) {
               __builtin_amdgcn_sched_barrier(0);
               if (t + 1 < NSTEP) frag_all(cur ^ 1, (t + 1) % NKP, pa, px);
@@ -812,10 +848,16 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
           if (t + 1 < NSTEP) frag_a(0, (t + 1) % NKP, pa, px);
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
+            if constexpr (LOOP1) {       // loop unit (slot 2): one chain; slot 3's two products are kept apart (dependent accumulator)
+              w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa1[cur][hh], fXb[cur][1][hh], w[3], 0, 0, 0);
+              w[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa1[cur][hh], fXb[cur][0][hh], w[2], 0, 0, 0);
+              w[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa1[cur][hh], fAb[cur][1][hh], w[3], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa1[cur][hh], fXb[cur][m][hh], w[2 + m], 0, 0, 0);
+              for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa1[cur][hh], fXb[cur][m][hh], w[2 + m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa1[cur][hh], fAb[cur][m][hh], w[2 + m], 0, 0, 0);
+              for (int m = 0; m < 2; m++) w[2 + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa1[cur][hh], fAb[cur][m][hh], w[2 + m], 0, 0, 0);
+            }
           }
           if (t + 1 < NSTEP) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -832,7 +874,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #pragma unroll
             for (int m = 0; m < 2; m++) w[2 * half + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fAa[half][hh], fXb[cur][m][hh], w[2 * half + m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < 2; m++) w[2 * half + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa[half][hh], fAb[cur][m][hh], w[2 * half + m], 0, 0, 0);
+            for (int m = 0; m < 2; m++)
+              if (!(LOOP1 && 2 * half + m == kCoverLoopSlot)) w[2 * half + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(fXa[half][hh], fAb[cur][m][hh], w[2 * half + m], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < NSTEP) {
@@ -854,6 +897,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       }
       chore(t);                          // everything of the stage that is not the product rides between the products
       if (kp == NKP - 1) {
+        if constexpr (LOOP1) {           // Z = M + M^T - F on the diagonal blocks: element (r4, c4) of a block adds element (c4, r4)
+          w[kCoverLoopSlot] += __shfl(w[kCoverLoopSlot], loop_src, 64);
+        }
 #pragma unroll
         for (int u = 0; u < NSL; u++) {
           const int s = 2 * g0 + u;
