@@ -19,7 +19,9 @@ an error, never a silent one-GPU run.
 Secondary block `config5` (every N; --no-config5 skips it): BASELINE configs[4]'s matrix size -- ONE Lorenz-96 problem, D = 4096,
 RK4, short grid -- through vgpa_shard_sweep_sharded: S_t / Psi_t row-sharded over the N ranks with RCCL collectives per RK stage,
 energy / gradient phases time-parallel, x and the gradient memory-sharded.  The problem is fixed, so the per-N values of
-`config5.s_per_sweep` give STRONG scaling; the headline `value` stays the D = 40 metric.
+`config5.s_per_sweep` give STRONG scaling; the headline `value` stays the D = 40 metric.  At N > 1 the block runs in CHILD processes
+of the ranks (own process group, started before the rank touches the GPU, reaped before the headline measurement): it is the only
+part of the bench that needs several real RCCL ranks, so a crash or hang there must not cost the headline line (config5_children).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -57,6 +59,8 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
     ap.add_argument("--config5-np", type=int, default=9, help="grid points of the D = 4096 block (its step rate does not depend on it)")
     ap.add_argument("--config5-dim", type=int, default=4096)
+    ap.add_argument("--config5-timeout", type=float, default=480.0, help="N > 1: seconds the config-5 child processes may take")
+    ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
     return ap.parse_args()
 
 
@@ -203,6 +207,69 @@ def config5_block(args, rank, world, local_rank, rehearse):
         return {"error": repr(exc)}
 
 
+def config5_children(args, rank):
+    """N > 1: the config-5 block puts more than one rank through RCCL -- a path no one-GPU box can exercise -- so it runs in CHILD
+    processes of the ranks (one per rank, a process group of their own on a neighbouring port), started BEFORE the rank has touched
+    the GPU and reaped before the headline measurement begins: a crash, a hang (bounded by --config5-timeout; the rank kills the
+    exact child it started) or a communicator error there ends up as {"error": ...} in the block and cannot take the headline
+    line with it.  Returns the block (rank 0) or None."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(port + 17 if port + 17 < 65000 else port - 17)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:      # (with TORCHELASTIC_USE_AGENT_STORE the children would look for the
+        del env[k]                                                   #  launcher's store on their port instead of opening their own)
+    cmd = [sys.executable, os.path.abspath(__file__), *[a for a in sys.argv[1:] if a != "--config5-child"], "--config5-child"]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        out, _ = proc.communicate(timeout=args.config5_timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": f"config-5 child processes did not finish within {args.config5_timeout:.0f} s (killed)"} if rank == 0 else None
+    if rank != 0:
+        return None
+    for line in reversed((out or "").strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": f"config-5 child of rank 0 ended with code {proc.returncode} and no result"}
+
+
+def config5_child_main(args):
+    """Body of one config-5 child process (see config5_children): its own process group, the block, rank 0 prints it."""
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("VGPA_BENCH_LAUNCH_ONLY") == "1":       # CPU test of the child mechanism: rendezvous on the children's port, report, leave
+        if os.environ.get("VGPA_BENCH_C5_TEST_HANG") == "1":
+            time.sleep(3600)
+        import torch.distributed as dist
+        from vgpa_amd import parallel as par
+        par.init_from_env("gloo")
+        par.barrier()
+        seen = par.max_over_ranks(float(rank)) + 1.0
+        if rank == 0:
+            print(json.dumps({"child": "ok", "ranks_seen": int(seen), "port": os.environ["MASTER_PORT"]}), flush=True)
+        dist.destroy_process_group()
+        return
+    import torch
+    import torch.distributed as dist
+    rehearse = os.environ.get("VGPA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    from vgpa_amd import parallel as par
+    par.init_from_env("gloo" if rehearse else "nccl", None if rehearse else local_rank)
+    c5 = config5_block(args, rank, world, local_rank, rehearse)
+    if rank == 0:
+        c5["process"] = "child processes of the ranks, own process group (bench.py::config5_children)"
+        print(json.dumps(c5), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -215,17 +282,26 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (n_gpus in the JSON line is the number of "
                          f"ranks that ran)")
+    if args.config5_child:
+        return config5_child_main(args)
     if os.environ.get("VGPA_BENCH_LAUNCH_ONLY") == "1":       # CPU test of the launcher: rendezvous, report, leave (no GPU work)
         import torch.distributed as dist
         from vgpa_amd import parallel as par
+        c5 = config5_children(args, rank) if (world > 1 and not args.no_config5) else None
         par.init_from_env("gloo")
         par.barrier()
         seen = par.max_over_ranks(float(rank)) + 1.0
         if rank == 0:
-            print(json.dumps({"launcher": "ok", "n_gpus": world, "ranks_seen": int(seen)}), flush=True)
+            print(json.dumps({"launcher": "ok", "n_gpus": world, "ranks_seen": int(seen), "config5": c5}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
+
+    # N > 1: the secondary D = 4096 block first, in child processes (nothing here has touched the GPU yet)
+    c5_early = None
+    c5_in_children = world > 1 and not args.no_config5 and not args.generic
+    if c5_in_children:
+        c5_early = config5_children(args, rank)
 
     # host-side inputs first (numpy only), and with them the CPU baseline: its worker pool forks, which must happen
     # before this process initialises the GPU
@@ -333,8 +409,9 @@ def main():
         c1.close()
 
     # ---- secondary block: BASELINE configs[4]'s matrix size through the row-sharded driver (every rank takes part)
-    c5 = None
-    if not args.no_config5 and not args.generic:
+    # (one rank: in this process, behind the headline measurement; N > 1: already measured, in child processes -- see above)
+    c5 = c5_early
+    if not args.no_config5 and not args.generic and not c5_in_children:
         ctx.close()
         del x_dev, g_dev
         c5 = config5_block(args, rank, world, local_rank, rehearse)

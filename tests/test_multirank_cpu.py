@@ -85,8 +85,25 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
+    c5 = out.pop("config5")
     assert out == {"launcher": "ok", "n_gpus": 2, "ranks_seen": 2}
     assert "starting 2 ranks" in r.stderr
+    # N > 1: the config-5 block runs in child processes of the ranks, with a process group of their own on a neighbouring port
+    assert c5["child"] == "ok" and c5["ranks_seen"] == 2
+
+
+def test_a_failing_config5_child_cannot_take_the_headline_line_with_it():
+    """The D = 4096 block is the only part of the bench that puts several ranks through RCCL, which no one-GPU box can rehearse:
+    at N > 1 it runs in child processes that the ranks start before they touch the GPU.  Children that hang are killed at
+    --config5-timeout and the block reports it; the ranks go on and print their line, exit code 0."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--config5-timeout", "5"],
+               {"VGPA_BENCH_LAUNCH_ONLY": "1", "VGPA_BENCH_C5_TEST_HANG": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ranks_seen"] == 2 and "did not finish" in out["config5"]["error"]
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-config5"], {"VGPA_BENCH_LAUNCH_ONLY": "1"})
+    assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["config5"] is None
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

@@ -383,25 +383,6 @@ __global__ void __launch_bounds__(NT) k_grad_mfma(GradArgs a) {
 }
 
 
-#ifndef VGPA_GRAD_NT
-#define VGPA_GRAD_NT 0
-#endif
-// streamed operands of the pipelined gradient assembly (each element is read / written exactly once per sweep): optionally with the
-// non-temporal hint, so that they do not displace each other in the L2 / MALL
-__device__ __forceinline__ double ld_stream(const double* p) {
-#if VGPA_GRAD_NT & 1
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void st_stream(double* p, double v) {
-#if VGPA_GRAD_NT & 2
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
 #ifndef VGPA_GRAD_TPW
 #define VGPA_GRAD_TPW 4
 #endif
@@ -458,7 +439,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
     for (int q = 0; q < EPT; q++) {
       const int e = tid + q * NT;
       const bool in = e < DD;
-      sv[q] = in ? ld_stream(St + e) : 0.0; pv[q] = in ? ld_stream(Pt + e) : 0.0;
+      sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0;
       if constexpr (!QMODE) { av[q] = in ? At[e] : 0.0; ev[q] = (in && Edf) ? Edf[e] : 0.0; }
     }
     v_m = vt ? a.m[o * D + tid] : 0.0;
@@ -567,7 +548,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int col = 16 * q + 4 * b + c4;
-        if (I < NB && row < D && col < D) st_stream(gA + row * D + col, a.dt * (acc[q * RW + ii] - uv[row] * mv[col]));
+        if (I < NB && row < D && col < D) gA[row * D + col] = a.dt * (acc[q * RW + ii] - uv[row] * mv[col]);
       }
     }
 #pragma unroll
@@ -575,7 +556,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const int v = wave + 4 * vv;
       const int Ib = v * G + b / rem;
       const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
-      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) st_stream(gA + row * D + col, a.dt * (accl[vv] - uv[row] * mv[col]));
+      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) gA[row * D + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
     }
     if (!QMODE && t + 1 < t_end) request(t + 1);
   }
