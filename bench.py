@@ -512,6 +512,12 @@ def main():
                                          f"sweep = {sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS:.3f} of HBM on SURVEY 8d's "
                                          f"algorithmic bytes; single problem = "
                                          f"{(single or {}).get('sweeps_per_s', float('nan')):.1f} sweeps/s"),
+        # what `peak` is worth on this part (measured, not used for `frac`): profiles/r03c_sustained_fp64_peak.txt, r03c_clock_under_load*.txt
+        "peak_context": {"fp64_matrix_nominal_TFLOPs": FP64_PEAK_TFLOPS,
+                         "fp64_matrix_sustained_TFLOPs": 72.1, "sustained_how": "every SIMD issuing only v_mfma_f64_4x4x4_4b for 5 s: 2.39 GHz, 1.00 kW "
+                         "(tools/ubench/f64_sustained.hip)",
+                         "clock_GHz_under_this_bench": 2.13, "package_W_under_this_bench": 1300, "power_capped": True,
+                         "measured_in_this_run": False},
         "roofline_kernels": roof,
         "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
