@@ -5,7 +5,7 @@ TAG=${1:-r03}
 out=gpurun_out/${TAG}_sustained_fp64_peak.txt
 hipcc --offload-arch=gfx950 -O3 tools/ubench/f64_sustained.hip -o gpurun_out/f64_sustained || exit 1
 : > $out
-for cfg in "0 1 rand" "0 2 rand" "1 2 rand" "0 2 zero"; do
+for cfg in "0 1 rand" "0 2 rand" "0 2 rand8" "0 1 rand8" "1 2 rand" "1 2 rand8" "0 2 zero"; do
   set -- $cfg
   gpurun_out/f64_sustained $1 $2 5 $3 > gpurun_out/f64_sustained.log &
   pid=$!
