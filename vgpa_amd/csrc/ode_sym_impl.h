@@ -62,6 +62,9 @@ constexpr int kMaxNB = 16;          // D <= 64
 #ifndef VGPA_SYM_TAILPRIO
 #define VGPA_SYM_TAILPRIO 1
 #endif
+#ifndef VGPA_ABL_NOFRAG
+#define VGPA_ABL_NOFRAG 0              // DIAGNOSTIC (wrong results): only the first pipeline step of a stage reads fragments -- what the LDS reads cost
+#endif
 #ifndef VGPA_SYM_LOOP1
 #define VGPA_SYM_LOOP1 1               // cover kernels: the loop unit (diagonal blocks) runs one chain + an in-block transpose
 #endif
@@ -722,7 +725,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       }
     }
   };
-  auto product_begin = [&](const double* Aop, const double* Xc) { frag_load(0, 0, Aop + r4 * LD, Xc + r4 * LD); };
+  auto product_begin = [&](const double* Aop, const double* Xc) {
+    frag_load(0, 0, Aop + r4 * LD, Xc + r4 * LD);
+#if VGPA_ABL_NOFRAG
+    if constexpr (COVER) frag_load(1, 1, Aop + r4 * LD, Xc + r4 * LD);
+#endif
+  };
 
   // products (their step-0 fragments are in flight) + stepper + publish of stage j
   auto product_stage = [&](int j, int step, const double* Aop, const double* Xc, double* Xn, auto&& chore) {
@@ -786,7 +794,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
           // eight ds_read_b128 takes the LDS queue ~100 cycles to accept when eight waves of the CU do the same, and an in-order
           // wave that sits in it issues no products meanwhile
           __builtin_amdgcn_sched_barrier(0);
-          if (t + 1 < NSTEP) frag_all(cur ^ 1, (t + 1) % NKP, pa, px);
+          if (t + 1 < NSTEP && !VGPA_ABL_NOFRAG) frag_all(cur ^ 1, (t + 1) % NKP, pa, px);
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
@@ -829,7 +837,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
           // backward: first half = units (a0, b0), (a0, b1) with the next step's b0, b1, a1 reads between the products (a1 in
           // two buffers: 56 fragment registers), second half = units (a1, b0), (a1, b1) with the next step's a0 reads
           __builtin_amdgcn_sched_barrier(0);
-          if (t + 1 < NSTEP) { frag_b(cur ^ 1, (t + 1) % NKP, pa, px); frag_a1(cur ^ 1, (t + 1) % NKP, pa, px); }
+          if (t + 1 < NSTEP && !VGPA_ABL_NOFRAG) { frag_b(cur ^ 1, (t + 1) % NKP, pa, px); frag_a1(cur ^ 1, (t + 1) % NKP, pa, px); }
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
@@ -845,7 +853,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (t + 1 < NSTEP) frag_a(0, (t + 1) % NKP, pa, px);
+          if (t + 1 < NSTEP && !VGPA_ABL_NOFRAG) frag_a(0, (t + 1) % NKP, pa, px);
 #pragma unroll
           for (int hh = 0; hh < 2; hh++) {
             if constexpr (LOOP1) {       // loop unit (slot 2): one chain; slot 3's two products are kept apart (dependent accumulator)
