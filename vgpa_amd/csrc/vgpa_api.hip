@@ -474,6 +474,17 @@ static int enqueue_stream_sweep(vgpa_ctx* c, double* g_dev) {
   return VGPA_OK;
 }
 
+// DIAGNOSTIC (tools/power_per_kernel.sh): VGPA_DIAG_REPEAT="<fwd|energy|bwd|grad>:<n>" launches that phase of the fused sweep n times
+// instead of once -- every phase is a pure function of its inputs, so the results do not change -- to hold one kernel on the chip long
+// enough for clock / power samples.  Read once; absent = 1.
+static int diag_repeat(const char* phase) {
+  static const std::string spec = [] { const char* e = getenv("VGPA_DIAG_REPEAT"); return std::string(e ? e : ""); }();
+  const size_t colon = spec.find(':');
+  if (colon == std::string::npos || spec.compare(0, colon, phase) != 0) return 1;
+  const int n = atoi(spec.c_str() + colon + 1);
+  return n > 1 ? n : 1;
+}
+
 // fwd -> E_obs -> E_sde terms -> bwd -> F     (VarGP.free_energy, variational.py:141-200)
 static int enqueue_free_energy(vgpa_ctx* c) {
   if (c->stream_ld) return enqueue_stream_sweep(c, nullptr);
@@ -482,16 +493,19 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   prof_collect(c);
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
   prof_mark(c, 0);
-  if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
+  for (int r = diag_repeat("fwd"); r > 0; r--)
+    if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
   prof_mark(c, 1);
   hipError_t e = launch_obs(obs_args(c), c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
   // (a symmetric-unit backward kernel reads the upper triangle of dEsde_dS only: the energy kernel writes nothing else then)
   const bool sym_bwd = use_sym_units(c) && !use_lane(c) && !use_wave(c) && use_mfma(c, false, c->sym_inputs) && c->D <= kMaxSmallD &&
                        !(c->cfg.flags & VGPA_FLAG_KEEP_PSI);
-  if ((rc = run_energy(c, nullptr, sym_bwd))) return rc;
+  for (int r = diag_repeat("energy"); r > 0; r--)
+    if ((rc = run_energy(c, nullptr, sym_bwd))) return rc;
   prof_mark(c, 2);
-  if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
+  for (int r = diag_repeat("bwd"); r > 0; r--)
+    if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
   prof_mark(c, 3);
   if ((rc = run_reduce(c))) return rc;
   c->have_state = true;
@@ -926,7 +940,8 @@ static int finish_gradient(vgpa_ctx* c, double* g_dev) {
     if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
     return rc;
   }
-  int rc = run_grad(c, g_dev);
+  int rc = VGPA_OK;
+  for (int r = diag_repeat("grad"); r > 0 && rc == VGPA_OK; r--) rc = run_grad(c, g_dev);
   if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
   return rc;
 }
