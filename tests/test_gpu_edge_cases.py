@@ -301,3 +301,31 @@ def test_lane_per_problem_sweep_of_lorenz63():
         f1, g1 = one.sweep(xb[i])
         assert abs(f[i] - f1) <= 1e-12 * abs(f1) and rel_err(g[i], g1) < 1e-12
     one.close()
+
+
+def test_diagnostic_phase_repeat_leaves_the_results_alone():
+    """VGPA_DIAG_REPEAT=<phase>:<n> (tools/power_per_kernel.sh: one kernel of the fused sweep held on the chip for clock / power
+    samples) launches a phase n times; every phase is a pure function of its inputs, so F and the gradient must not move in any
+    bit.  The variable is read once per process: child processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_gpu_edge_cases as t\n"
+        "p, x = t.make_problem('L96', 40, 30)\n"
+        "ctx = t.gpu_context(p, batch=2)\n"
+        "f, g = ctx.sweep(np.stack([x, x + 0.01]))\n"
+        "print(json.dumps({'f': [float(v).hex() for v in f], 'g': float(np.abs(g).sum()).hex()}))\n" % os.path.dirname(__file__))
+    outs = []
+    for spec in ("", "fwd:3", "energy:2", "bwd:3", "grad:2"):
+        env = dict(os.environ)
+        env.pop("VGPA_DIAG_REPEAT", None)
+        if spec:
+            env["VGPA_DIAG_REPEAT"] = spec
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    assert all(o == outs[0] for o in outs[1:]), outs
