@@ -130,7 +130,8 @@ __host__ __device__ constexpr int sym_run_count(int nsb) {
 // (a0,b1), (a1,b0), (a1,b1): 8 fragment reads per k-pair for 16 products (runs: 12 for 16); when b0 IS a1 (`alias`: a
 // "triangle" a0-a1-b1 plus the loop unit (a1,a1)) 6 reads.  The maps below cover the 55 unordered block pairs of the upper
 // triangle of a 10 x 10 block matrix with one rectangle wave (3 units) and three triangle waves (4 units): 26 fragment reads per
-// k-pair and workgroup instead of 45, the same 15 units = 300 products per stage.  (Four triangle waves cannot do it: 16
+// k-pair and workgroup instead of 45, the same 15 units = 300 products per stage (280 since the loop units run one chain: see
+// kCoverLoopSlot).  (Four triangle waves cannot do it: 16
 // triangles do not cover K_10.)  Found by simulated annealing under three side conditions: (i) a ds_read_b128 lane group -- it
 // mixes lanes of blocks 0, 3 of one row pair with blocks 1, 2 of the next -- touches every bank once
 // ({m0, m3, m1 + 2, m2 + 2} distinct mod 4 wherever the blocks differ); (ii) / (iii) the four blocks of a unit differ in
