@@ -65,6 +65,12 @@ constexpr int kMaxNB = 16;          // D <= 64
 #ifndef VGPA_ABL_NOFRAG
 #define VGPA_ABL_NOFRAG 0              // DIAGNOSTIC (wrong results): only the first pipeline step of a stage reads fragments -- what the LDS reads cost
 #endif
+#ifndef VGPA_ABL_NOSTORE
+#define VGPA_ABL_NOSTORE 0             // DIAGNOSTIC (wrong results): the stage state is not written to HBM
+#endif
+#ifndef VGPA_ABL_NOVEC
+#define VGPA_ABL_NOVEC 0               // DIAGNOSTIC (wrong results): no vector recursion (partial inner products, per-wave update)
+#endif
 #ifndef VGPA_SYM_LOOP1
 #define VGPA_SYM_LOOP1 1               // cover kernels: the loop unit (diagonal blocks) runs one chain + an in-block transpose
 #endif
@@ -469,6 +475,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 
   // S_k / Psi_t and m_k / lam_t of grid point t to HBM: the matrix from the stage buffer that holds it
   auto store_items = [&](const d2_t (&v)[g::NIT], int t) {
+    if (VGPA_ABL_NOSTORE && t > 1) return;
     double* so = mout + (size_t)t * DD;
 #pragma unroll
     for (int q = 0; q < g::NIT; q++) {
@@ -993,6 +1000,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
       const double* Aopv = aop(k, j, false);
       product_stage(j, k, aop(k, j, true), Xc, Xn, [&](int t) {
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
+        if (!VGPA_ABL_NOVEC) {
         if (t == SA_R && (j > 0 || k > 0)) vecA_read(pv_prev);
         if (t == SA_F) {
           if (j > 0) vecA_finish(j - 1);
@@ -1004,6 +1012,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         }
         if (t == SB_R) tailB_read(Aopv);
         if (t == SB_F) tailB_finish(pv);
+        }
         if (t == SC_R) tailC_read(j, Xc);
         if (t == SC_F) tailC_finish(j, k);
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
