@@ -5,12 +5,16 @@
 TAG=${1:-r03}
 out=gpurun_out/${TAG}_stepper_power_ablations.txt
 : > $out
-for spec in "shipped:" "nofrag:-DVGPA_ABL_NOFRAG=1" "nostore:-DVGPA_ABL_NOSTORE=1" "novec:-DVGPA_ABL_NOVEC=1" "loop0:-DVGPA_SYM_LOOP1=0"; do
-  name=${spec%%:*}; flags=${spec#*:}
+# usage: tools/power_ablations.sh [tag] ["name:flags" ...]   (default: the shipped build and the four ablations)
+shift
+if [ $# -eq 0 ]; then set -- "shipped:" "nofrag:-DVGPA_ABL_NOFRAG=1" "nostore:-DVGPA_ABL_NOSTORE=1" "novec:-DVGPA_ABL_NOVEC=1" "loop0:-DVGPA_SYM_LOOP1=0"; fi
+names=""
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}; names="$names $name"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $flags -Ivgpa_amd/csrc -Iinclude tools/ubench/ode_sym_loop.hip -o gpurun_out/ode_sym_loop_$name 2> gpurun_out/ode_sym_loop_$name.err &
 done
 wait
-for name in shipped nofrag nostore novec loop0; do
+for name in $names; do
   for fwd in 1 0; do
     gpurun_out/ode_sym_loop_$name 512 $fwd 6 > gpurun_out/ode_sym_loop.log &
     pid=$!
