@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
     ap.add_argument("--config5-np", type=int, default=9, help="grid points of the D = 4096 block (its step rate does not depend on it)")
     ap.add_argument("--config5-dim", type=int, default=4096)
-    ap.add_argument("--config5-timeout", type=float, default=480.0, help="N > 1: seconds the config-5 child processes may take")
+    ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
     return ap.parse_args()
 
