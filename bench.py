@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--keep-psi", action="store_true", help="comparison runs: VGPA_FLAG_KEEP_PSI (the backward kernel stores Psi_t, "
                     "the gradient assembly re-reads A_t) instead of the default Q''_t stream")
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
-    ap.add_argument("--config5-np", type=int, default=9, help="grid points of the D = 4096 block (its step rate does not depend on it)")
+    ap.add_argument("--config5-np", type=int, default=16, help="grid points of the D = 4096 block: a multiple of 8, so that the "
+                    "time-parallel energy / gradient phases are balanced at N = 1, 2, 4, 8 (vgpa_shard_time_slice)")
     ap.add_argument("--config5-dim", type=int, default=4096)
     ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
@@ -186,20 +187,50 @@ def config5_block(args, rank, world, local_rank, rehearse):
         chk = torch.tensor([float(ga.abs().sum()), float(gb.abs().sum())], dtype=torch.float64, device="cpu" if rehearse else dev)
         if world > 1:
             dist.all_reduce(chk)
+        # where the sweep's time goes: the phases of the last timed sweep (HIP events on the shard's stream; MAX over ranks, and
+        # rank 0's own), the two per-stage collectives alone, and ONE recursion stage with and without its collectives -- the
+        # difference is the communication the pipelined schedule does not hide
+        ph = rec.phase_ms()
+        names = list(ph)
+        pht = torch.tensor([ph[k] for k in names], dtype=torch.float64, device="cpu" if rehearse else dev)
+        npts = torch.zeros(world, dtype=torch.float64, device="cpu" if rehearse else dev)
+        npts[rank] = hi - lo
+        if world > 1:
+            dist.all_reduce(pht, op=dist.ReduceOp.MAX)
+            dist.all_reduce(npts)
         a2a_ms, gather_ms = rec.time_collectives(10)
+        stage_with = rec.time_stage(10, True)
+        stage_without = rec.time_stage(10, False)
+        if world > 1:
+            st_t = torch.tensor([stage_with, stage_without], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(st_t, op=dist.ReduceOp.MAX)
+            stage_with, stage_without = float(st_t[0]), float(st_t[1])
         chunks = rec.gather_chunks
+        rccl_ranks = rec.rccl_ranks                           # ncclCommCount of the communicator the sweep ran on
         rec.close()
         flop = 24.0 * d ** 3 * n                             # nominal flop of one fused sweep
         return {"workload": f"Lorenz96 D={d}, RK4, Np={n}: ONE problem, fused sweep (free energy + gradient), S_t / Psi_t row-sharded, "
                             f"energy / gradient time-parallel, x and gradient memory-sharded (BASELINE configs[4] matrix size; its "
                             f"full grid fits no node)",
-                "n_gpus": world, "rccl_ranks": 0 if (world == 1 or comm is not None) else world,
+                "n_gpus": world, "rccl_ranks": rccl_ranks, "rccl_ranks_how": "ncclCommCount of the shard's communicator (0: one rank or host-staged rehearsal)",
+                "grid_points_per_rank": [int(v) for v in npts.tolist()],
                 "transport": "host-staged gloo (REHEARSAL: not a measurement)" if comm is not None else ("RCCL" if world > 1 else "none"),
                 "scaling": "strong", "s_per_sweep": secs,
                 "recursion_steps_per_s": 2 * (n - 1) / secs, "aggregate_tflops_nominal": flop / secs / 1e12,
                 "frac_of_fp64_peak_per_gpu": flop / secs / 1e12 / world / FP64_PEAK_TFLOPS,
                 "schedule": f"pipelined gather, {chunks} sub-blocks, second stream" if chunks else
                             ("serial (one grouped all-gather per stage)" if world > 1 else "one rank: no collective"),
+                "phase_ms_max_over_ranks": {k: float(v) for k, v in zip(names, pht.tolist())},
+                "phase_ms_rank0": ph,
+                "phase_how": "vgpa_shard_phase_ms: HIP events on the shard's stream around the phases of the last timed sweep; the recursions "
+                             "(row-sharded, one collective pair per RK stage) scale with the stage time, energy_obs and gradient (time-parallel) with "
+                             "grid_points_per_rank",
+                "per_stage_ms": {"stage_with_collectives": stage_with, "stage_compute_only": stage_without,
+                                 "collective_exposed": stage_with - stage_without,
+                                 "collective_hidden": max(0.0, a2a_ms + gather_ms - (stage_with - stage_without)),
+                                 "how": "vgpa_shard_time_stage: one forward RK4 stage as the driver issues it (K-chunk products waiting for the "
+                                        "previous gather's sub-blocks, all-to-all, stage kernel, gather), 10 back to back, with and without the "
+                                        "collectives; MAX over ranks"},
                 "per_stage_collective_ms": {"all_to_all": a2a_ms, "gather": gather_ms,
                                             "how": "vgpa_shard_time_collectives: the stage's two collectives alone, same buffers and streams"},
                 "F": f, "finite": bool(np.isfinite(f)), "checks": {"sum|gLa|": float(chk[0]), "sum|gLb|": float(chk[1])}}

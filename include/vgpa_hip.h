@@ -285,6 +285,8 @@ int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_
                       const vgpa_comm* comm_or_null_if_world_1, void* stream_or_null);
 void vgpa_shard_destroy(vgpa_shard* s);
 int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi);
+/* the same rule without a shard: grid points [t_lo, t_hi) of `rank` out of `world` on a grid of n_pts (host arithmetic only) */
+int vgpa_time_slice(int n_pts, int rank, int world, int* t_lo, int* t_hi);
 void* vgpa_shard_stream(vgpa_shard* s);
 int vgpa_shard_synchronize(vgpa_shard* s);
 enum vgpa_shard_option {
@@ -336,11 +338,22 @@ int vgpa_shard_sweep_sharded(vgpa_shard* s, const vgpa_shard_problem* problem, c
 /* the two per-stage collectives alone (same buffers, sizes, streams and schedule as inside a stage), averaged over `reps`
  * rounds: what bench.py reports as per-stage collective milliseconds.  Collective call. */
 int vgpa_shard_time_collectives(vgpa_shard* s, int reps, double* all_to_all_ms, double* gather_ms);
+/* One stage of the forward RK4 recursion as the driver issues it (K-chunk products waiting for the previous gather's sub-blocks,
+ * all-to-all, stage kernel, gather), `reps` times back to back on the shard's workspace; with_collectives == 0 leaves the
+ * collectives out, so the difference of the two is the communication a stage does not hide.  Timing only (the workspace is
+ * overwritten; call between sweeps).  Collective call when with_collectives != 0. */
+int vgpa_shard_time_stage(vgpa_shard* s, int reps, int with_collectives, double* ms_per_stage);
+/* Milliseconds of the six phases of this rank's LAST fused sweep (HIP events on the shard's stream): [0] exchanges of a
+ * memory-sharded x, [1] forward recursion, [2] observation + E_sde terms of the own grid points, [3] small gathers + time -> row
+ * exchange of dEsde_dS, [4] backward recursion, [5] gradient of the own grid points + F.  VGPA_ERR_STATE before the first sweep. */
+int vgpa_shard_phase_ms(vgpa_shard* s, double* ms6);
 /* RCCL behind the vgpa_comm table: collectives over xGMI; the library is dlopen'ed on first use */
 #define VGPA_RCCL_UNIQUE_ID_BYTES 128
 int vgpa_rccl_unique_id(void* out_128_bytes);
 int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_128_bytes, int rank, int world, int device);
 void vgpa_rccl_comm_destroy(vgpa_comm* comm);
+/* ranks of the communicator as librccl counts them (ncclCommCount); VGPA_ERR_ARG for a table RCCL did not fill */
+int vgpa_rccl_comm_count(const vgpa_comm* comm, int* count);
 
 /* timing of the stepping kernel on the context's stream (HIP events), for bench.py's roofline */
 int vgpa_profile_begin(vgpa_ctx* ctx);

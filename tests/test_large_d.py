@@ -1071,4 +1071,54 @@ def test_rccl_table_single_rank():
     assert comm.all_to_all(comm.user, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), 1000, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(y, x) and float(x[999]) == 999.0
+    n = ctypes.c_int(-1)
+    assert lib.vgpa_rccl_comm_count(ctypes.byref(comm), ctypes.byref(n)) == 0 and n.value == 1     # ncclCommCount: bench.py's rccl_ranks
+    assert lib.vgpa_rccl_comm_count(ctypes.byref(VgpaComm()), ctypes.byref(n)) == -1               # not an RCCL table
     lib.vgpa_rccl_comm_destroy(ctypes.byref(comm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,chunks", [(1, None), (2, None), (4, 0)])
+def test_sweep_phase_times_and_stage_timing_leave_the_results_alone(world, chunks):
+    """bench.py's config-5 block reports where a sharded sweep's time goes: vgpa_shard_phase_ms (six phases of the last sweep, HIP
+    events) and vgpa_shard_time_stage (one recursion stage with / without its collectives -- it overwrites the workspace).  Both are
+    instrumentation: the sweep after them must still equal the oracle's, and the phases must add up to no more than the sweep."""
+    import time
+    from vgpa_amd.large_d import NativeShardedRecursion
+    from vgpa_amd._lib import SHARD_OPT_GATHER_CHUNKS
+    from test_gpu_edge_cases import make_problem
+    d, n, method = 128, 12, "rk4"
+    p, x = make_problem("L96", d, n, method=method)
+    f_o, g_o, _ = vo.sweep(p, x, faithful=False)
+    ga_o = g_o[:n * d * d].reshape(n, d, d)
+    e0 = float(np.asarray(vo.kl0(p)))
+
+    def body(rank, comm):
+        rec = NativeShardedRecursion(method, p.dt, d, n, rank=rank, world=world, device=0, comm=comm.table(rank) if world > 1 else None)
+        if chunks is not None:
+            rec.set_option(SHARD_OPT_GATHER_CHUNKS, chunks)
+        with pytest.raises(RuntimeError):
+            rec.phase_ms()                       # no sweep yet: VGPA_ERR_STATE
+        args = (x, p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), e0)
+        rec.sweep(*args)
+        t0 = time.perf_counter()
+        rec.sweep(*args)
+        wall_ms = 1e3 * (time.perf_counter() - t0)
+        ph = rec.phase_ms()
+        t_with, t_without = rec.time_stage(3, True), rec.time_stage(3, False)
+        f, ga, _ = rec.sweep(*args)              # the workspace the timing runs scribbled over is re-initialised by the sweep
+        lo, hi = rec.time_slice
+        e = max(abs(f - f_o) / abs(f_o), rel_err(ga.cpu().numpy(), ga_o[lo:hi]) if hi > lo else 0.0)
+        ranks = rec.rccl_ranks
+        rec.close()
+        return e, ph, wall_ms, t_with, t_without, ranks
+
+    out, fails, _ = _virtual_ranks(world, body)
+    assert not any(fails), fails
+    for e, ph, wall_ms, t_with, t_without, ranks in out:
+        assert e < TOL
+        assert list(ph) == ["x_exchange", "forward_recursion", "energy_obs", "exchanges", "backward_recursion", "gradient"]
+        assert all(v >= 0.0 for v in ph.values()) and ph["forward_recursion"] > 0.0 and ph["backward_recursion"] > 0.0
+        assert sum(ph.values()) <= wall_ms * 1.05 + 0.5
+        assert t_with > 0.0 and t_without > 0.0
+        assert ranks == 0                        # an injected table is not an RCCL communicator

@@ -113,3 +113,33 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
     r = _bench(["--gpus", "0"], {})
     assert r.returncode != 0
+
+
+def test_config5_default_grid_gives_every_rank_the_same_number_of_grid_points():
+    """The strong-scaling block's time-parallel phases (energy terms, gradient: ~ 1/3 of the one-GPU time) scale with the LARGEST
+    time slice.  The default grid of `bench.py --config5-np` must therefore split evenly over 1, 2, 4 and 8 ranks (VERDICT r3:
+    Np = 9 gave rank 0 two grid points and the others one at N = 8).  vgpa_time_slice is the library's own ownership rule."""
+    import ctypes
+    import importlib.util
+    import vgpa_amd as va
+    spec = importlib.util.spec_from_file_location("bench_for_defaults", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        n = bench.parse().config5_np
+    finally:
+        sys.argv = argv
+    lib = va.load()
+    for world in (1, 2, 4, 8):
+        sizes, covered = [], []
+        for rank in range(world):
+            lo, hi = ctypes.c_int(), ctypes.c_int()
+            assert lib.vgpa_time_slice(n, rank, world, ctypes.byref(lo), ctypes.byref(hi)) == 0
+            sizes.append(hi.value - lo.value)
+            covered.extend(range(lo.value, hi.value))
+        assert covered == list(range(n))
+        assert max(sizes) == min(sizes) == n // world, (world, sizes)
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    assert lib.vgpa_time_slice(9, 0, 8, ctypes.byref(lo), ctypes.byref(hi)) == 0 and hi.value - lo.value == 2    # the old default
+    assert lib.vgpa_time_slice(n, 8, 8, ctypes.byref(lo), ctypes.byref(hi)) == -1

@@ -957,9 +957,30 @@ struct ShardCtx {
   bool cs_dirty = false;                    // work enqueued on cs that the compute stream has not joined yet
   bool failed = false;                      // a collective failed: the communicator is gone (VGPA_ERR_COMM from now on)
   int64_t timeout_ms = 600000;              // bound of every host wait on the streams
+  bool skip_comm = false;                   // timing only (vgpa_shard_time_stage): a stage's kernels without its collectives
+  hipEvent_t ev_phase[7] = {};              // phase boundaries of the last fused sweep (vgpa_shard_phase_ms)
+  bool phases_valid = false;
+  int group_depth = 0;                      // group_begin calls of this thread that have no group_end yet
+  double* pinned = nullptr;                 // page-locked host staging: world status words + F (async copies never target
+                                            // pageable, stack or local-vector memory: they may outlive the call that queued them)
 };
 
+static int group_begin(ShardCtx& c) {
+  if (!c.comm.group_begin) return 0;
+  const int rc = c.comm.group_begin(c.comm.user);
+  if (rc == 0) c.group_depth++;
+  return rc;
+}
+static int group_end(ShardCtx& c) {
+  if (!c.comm.group_end) return 0;
+  if (c.group_depth > 0) c.group_depth--;
+  return c.comm.group_end(c.comm.user);
+}
+
+// the communicator goes down; a group this thread still has open is closed first (its code no longer matters) so that the abort
+// -- and whatever else shares the library on this thread afterwards -- does not run inside an unbalanced group
 static void comm_failed(ShardCtx& c) {
+  while (c.group_depth > 0) { c.group_depth--; if (c.comm.group_end) (void)c.comm.group_end(c.comm.user); }
   if (!c.failed && c.comm.abort) (void)c.comm.abort(c.comm.user);
   c.failed = true;
 }
@@ -1017,17 +1038,17 @@ struct ShardStage {
 static hipError_t shard_gather(ShardCtx& c, double* out, double* vout) {
   const int D = c.D, Mp = c.Mp, row0 = c.row0, world = c.world, rank = c.rank;
   if (!pipelined(c)) {      // complete the next stage state: row blocks of the matrix and of the vector, one group
-    if (c.comm.group_begin) SH_COMM(c, c.comm.group_begin(c.comm.user));
+    SH_COMM(c, group_begin(c));
     SH_COMM(c, c.comm.all_gather(c.comm.user, out + (size_t)row0 * D, out, (uint64_t)Mp * D, c.st));
     SH_COMM(c, c.comm.all_gather(c.comm.user, vout + row0, vout, (uint64_t)Mp, c.st));
-    if (c.comm.group_end) SH_COMM(c, c.comm.group_end(c.comm.user));
+    SH_COMM(c, group_end(c));
     return hipSuccess;
   }
   LD_TRY(hipEventRecord(c.ev_stage, c.st));
   LD_TRY(hipStreamWaitEvent(c.cs, c.ev_stage, 0));
   const int sub = Mp / c.chunks;
   for (int j = 0; j < c.chunks; j++) {
-    SH_COMM(c, c.comm.group_begin(c.comm.user));
+    SH_COMM(c, group_begin(c));
     for (int d = 1; d < world; d++) {      // rotated peer order: every rank's d-th send meets its peer's d-th receive
       const int to = (rank + d) % world, from = (rank - d + world) % world;
       SH_COMM(c, c.comm.send(c.comm.user, out + ((size_t)row0 + (size_t)j * sub) * D, (uint64_t)sub * D, to, c.cs));
@@ -1037,7 +1058,7 @@ static hipError_t shard_gather(ShardCtx& c, double* out, double* vout) {
         SH_COMM(c, c.comm.recv(c.comm.user, vout + (size_t)from * Mp, (uint64_t)Mp, from, c.cs));
       }
     }
-    SH_COMM(c, c.comm.group_end(c.comm.user));
+    SH_COMM(c, group_end(c));
     LD_TRY(hipEventRecord(c.ev_chunk[j], c.cs));
   }
   c.pending = out; c.cs_dirty = true;
@@ -1077,7 +1098,7 @@ static hipError_t shard_stage(ShardCtx& c, const ShardStage& s) {
     LD_TRY(launch_gemm(!s.fwd, g, c.st));
   }
   const double* wcol = w.Wp;
-  if (c.world > 1) {
+  if (c.world > 1 && !c.skip_comm) {
     SH_COMM(c, c.comm.all_to_all(c.comm.user, w.Wp, w.Wcol, (uint64_t)Mp * Mp, c.st));
     wcol = w.Wcol;
   }
@@ -1093,7 +1114,7 @@ static hipError_t shard_stage(ShardCtx& c, const ShardStage& s) {
   a.jv = s.jv; a.vbase = s.vbase + row0;
   a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout + row0;
   LD_TRY(launch_stage(a, c.st));
-  if (c.world > 1) LD_TRY(shard_gather(c, s.out, s.vout));
+  if (c.world > 1 && !c.skip_comm) LD_TRY(shard_gather(c, s.out, s.vout));
   return hipSuccess;
 }
 
@@ -1383,7 +1404,8 @@ __global__ void k_shard_status(const int32_t* __restrict__ status, double local_
 }
 
 // Collective: every rank contributes -code (0 = fine), all receive the largest.  Synchronises the compute stream.
-static int shard_agree(ShardCtx& c, const int32_t* status_dev, int local_code) {
+// `f_dev` (optional): a device scalar that travels to the host with the status words, returned in *f_host on VGPA_OK only.
+static int shard_agree(ShardCtx& c, const int32_t* status_dev, int local_code, const double* f_dev = nullptr, double* f_host = nullptr) {
   double* mine = c.w.agree + c.rank;
   if (shard_join(c) != hipSuccess) return VGPA_ERR_DEVICE;
   hipLaunchKernelGGL(k_shard_status, dim3(1), dim3(64), 0, c.st, status_dev, (double)(-local_code), mine);
@@ -1391,12 +1413,14 @@ static int shard_agree(ShardCtx& c, const int32_t* status_dev, int local_code) {
     if (c.failed) return VGPA_ERR_COMM;
     if (c.comm.all_gather(c.comm.user, mine, c.w.agree, 1, c.st) != 0) { comm_failed(c); return VGPA_ERR_COMM; }
   }
-  std::vector<double> host((size_t)c.world, 0.0);
-  if (hipMemcpyAsync(host.data(), c.w.agree, sizeof(double) * c.world, hipMemcpyDeviceToHost, c.st) != hipSuccess) return VGPA_ERR_DEVICE;
-  const int rc = shard_wait(c);
+  if (!c.pinned) return VGPA_ERR_DEVICE;
+  if (hipMemcpyAsync(c.pinned, c.w.agree, sizeof(double) * c.world, hipMemcpyDeviceToHost, c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  if (f_dev && hipMemcpyAsync(c.pinned + c.world, f_dev, sizeof(double), hipMemcpyDeviceToHost, c.st) != hipSuccess) return VGPA_ERR_DEVICE;
+  const int rc = shard_wait(c);       // (on a time-out the copies stay queued: their target lives as long as the shard)
   if (rc != VGPA_OK) return rc;
   double worst = 0.0;
-  for (double v : host) worst = v > worst ? v : worst;
+  for (int q = 0; q < c.world; q++) worst = c.pinned[q] > worst ? c.pinned[q] : worst;
+  if (f_dev && f_host) *f_host = c.pinned[c.world];
   return -(int)worst;
 }
 
@@ -1438,6 +1462,9 @@ hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem&
     hipLaunchKernelGGL(k_shard_unpad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Np, W, world, pad, padded, full);
   };
   LD_TRY(hipMemsetAsync(B.status, 0, sizeof(int32_t), st));
+  c.phases_valid = false;
+  auto mark = [&](int i) -> hipError_t { return hipEventRecord(c.ev_phase[i], st); };      // (the recursions end joined: st has waited for cs)
+  LD_TRY(mark(0));
   AView av;
   const double* b_full;
   if (x_full) {
@@ -1458,7 +1485,9 @@ hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem&
     unpad(D, B.b_all, B.b_full);
     b_full = B.b_full;
   }
+  LD_TRY(mark(1));
   LD_TRY(shard_solve_fwd(c, Np, av, b_full, p.m0, p.S0, p.Sigma, B.m_own, B.S_own));
+  LD_TRY(mark(2));
   // observation terms
   const size_t ocnt = (size_t)p.M * (D + 1);
   if (p.M > 0) {
@@ -1476,11 +1505,12 @@ hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem&
   if (n_own > 0)
     LD_TRY(lde_energy(D, n_own, p.theta, p.isg, a_own, b_own, B.m_own, B.S_own, et_mine, B.Ef_own, nullptr, gm_mine, B.gs_own, B.status,
                       B.lde_ws, B.lde_nb, st));
+  LD_TRY(mark(3));
   if (world > 1) {
-    if (c.comm.group_begin) SH_COMM(c, c.comm.group_begin(c.comm.user));
+    SH_COMM(c, group_begin(c));
     SH_COMM(c, c.comm.all_gather(c.comm.user, gm_mine, B.gm_all, (uint64_t)pad * D, st));
     SH_COMM(c, c.comm.all_gather(c.comm.user, et_mine, B.et_all, (uint64_t)pad, st));
-    if (c.comm.group_end) SH_COMM(c, c.comm.group_end(c.comm.user));
+    SH_COMM(c, group_end(c));
   }
   unpad(D, B.gm_all, B.gm_full);
   unpad(1, B.et_all, B.et_full);
@@ -1498,14 +1528,19 @@ hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem&
     in.g_rows = B.gs_own; in.g_rows_t = DD;
     psi_own = B.g_rows;
   }
+  LD_TRY(mark(4));
   LD_TRY(shard_solve_bwd(c, Np, av, in, B.lam_own, psi_own));
+  LD_TRY(mark(5));
   if (n_own > 0)
     LD_TRY(lde_grad(D, n_own, c.dt, p.isg, a_own, b_own, B.m_own, B.S_own, B.lam_own, psi_own, B.Ef_own, gA_own, gB_own, B.lde_ws,
                     B.lde_nb, st));
   ReduceArgs r{};
   r.Np = Np; r.batch = 1; r.dt = c.dt; r.pre = 1.0; r.div = 1.0; r.e0 = p.e0;
   r.e_t = B.et_full; r.eobs = B.scal; r.esde = B.scal + 1; r.f = B.scal + 2;
-  return launch_reduce(r, st);
+  LD_TRY(launch_reduce(r, st));
+  LD_TRY(mark(6));
+  c.phases_valid = true;
+  return hipSuccess;
 }
 #undef SH_COMM
 #undef LD_TRY
@@ -1592,9 +1627,12 @@ int vgpa_shard_create(vgpa_shard** out, int method, double dt, int dim_d, int n_
   ok = ok && hipEventCreateWithFlags(&s->c.ev_stage, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&s->c.ev_tail, hipEventDisableTiming) == hipSuccess;
   for (int j = 0; ok && j < ld::kMaxChunks; j++) ok = hipEventCreateWithFlags(&s->c.ev_chunk[j], hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; ok && j < 7; j++) ok = hipEventCreate(&s->c.ev_phase[j]) == hipSuccess;
   const size_t n = ld::shard_workspace_doubles(dim_d, s->c.Mp, world);
   ok = ok && hipMalloc((void**)&s->ws, n * sizeof(double)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&s->c.pinned, ((size_t)world + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (!ok) { vgpa_shard_destroy(s); return VGPA_ERR_DEVICE; }
+  for (int q = 0; q <= world; q++) s->c.pinned[q] = 0.0;
   (void)hipMemsetAsync(s->ws, 0, n * sizeof(double), s->c.st);
   s->c.w = ld::carve_shard(s->ws, dim_d, s->c.Mp);
   // default schedule: the pipelined gather with four sub-blocks wherever the table and the row-block size allow it
@@ -1613,9 +1651,11 @@ void vgpa_shard_destroy(vgpa_shard* s) {
   if (s->c.cs && !s->c.failed) (void)hipStreamSynchronize(s->c.cs);
   if (s->ws) (void)hipFree(s->ws);
   for (void* q : s->sweep_allocs) (void)hipFree(q);
+  if (s->c.pinned) (void)hipHostFree(s->c.pinned);    // (hipFree / hipHostFree wait for the device: no queued copy outlives its target)
   if (s->c.ev_stage) (void)hipEventDestroy(s->c.ev_stage);
   if (s->c.ev_tail) (void)hipEventDestroy(s->c.ev_tail);
   for (int j = 0; j < ld::kMaxChunks; j++) if (s->c.ev_chunk[j]) (void)hipEventDestroy(s->c.ev_chunk[j]);
+  for (int j = 0; j < 7; j++) if (s->c.ev_phase[j]) (void)hipEventDestroy(s->c.ev_phase[j]);
   if (s->c.cs) (void)hipStreamDestroy(s->c.cs);
   if (s->own_stream) (void)hipStreamDestroy(s->c.st);
   delete s;
@@ -1643,6 +1683,13 @@ int vgpa_shard_get_option(const vgpa_shard* s, int option, int64_t* value) {
 int vgpa_shard_time_slice(const vgpa_shard* s, int* t_lo, int* t_hi) {
   if (!s || !t_lo || !t_hi) return VGPA_ERR_ARG;
   ld::time_slice(s->Np, s->c.rank, s->c.world, t_lo, t_hi);
+  return VGPA_OK;
+}
+
+// the ownership rule itself, without a shard (pure host arithmetic: callers size their buffers with it, tests check its balance)
+int vgpa_time_slice(int n_pts, int rank, int world, int* t_lo, int* t_hi) {
+  if (n_pts < 1 || world < 1 || rank < 0 || rank >= world || !t_lo || !t_hi) return VGPA_ERR_ARG;
+  ld::time_slice(n_pts, rank, world, t_lo, t_hi);
   return VGPA_OK;
 }
 
@@ -1737,7 +1784,10 @@ int shard_sweep_entry(vgpa_shard* s, const vgpa_shard_problem* p, const double* 
   ld::SweepBuffers& B = s->sb;
   if (first || !have) {      // allocation is a local event: agree on it before any rank enters the sweep's collectives
     const int rc = ld::shard_agree(s->c, nullptr, have ? VGPA_OK : VGPA_ERR_DEVICE);
-    if (rc != VGPA_OK) { if (!have) { s->sb = ld::SweepBuffers{}; } return rc; }
+    if (rc != VGPA_OK) {       // EVERY rank forgets its buffers' key, so that `first` agrees on all of them at the next call
+      if (!have) s->sb = ld::SweepBuffers{}; else s->sb.M = -1;
+      return rc;
+    }
   }
   s->obs_idx.assign((size_t)Np, -1);
   for (int n = 0; n < M; n++) s->obs_idx[(size_t)p->obs_t[n]] = n;
@@ -1753,13 +1803,10 @@ int shard_sweep_entry(vgpa_shard* s, const vgpa_shard_problem* p, const double* 
     ld::comm_failed(s->c);                   // this rank stops enqueueing: its peers must not wait for it
     return was_comm ? VGPA_ERR_COMM : VGPA_ERR_DEVICE;
   }
-  double f = 0.0;
-  if (hipMemcpyAsync(&f, B.scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->c.st) != hipSuccess) { ld::comm_failed(s->c); return VGPA_ERR_DEVICE; }
   // the outcome is collective: a covariance that lost positive definiteness on ONE rank's time slice (or a device fault there)
-  // is every rank's return code (the reference raises LinAlgError and the whole run ends, variational.py:380)
-  const int rc = ld::shard_agree(s->c, B.status, VGPA_OK);
-  *f_host = f;
-  return rc;
+  // is every rank's return code (the reference raises LinAlgError and the whole run ends, variational.py:380); F rides to the
+  // host with the status words, through the shard's page-locked staging
+  return ld::shard_agree(s->c, B.status, VGPA_OK, B.scal + 2, f_host);
 }
 }  // namespace
 
@@ -1803,6 +1850,65 @@ int vgpa_shard_time_collectives(vgpa_shard* s, int reps, double* all_to_all_ms, 
     if (rc == VGPA_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (which == 0 ? *all_to_all_ms : *gather_ms) = ms / reps;
   }
   if (rc == VGPA_ERR_COMM) ld::comm_failed(c);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// Milliseconds of the six phases of the LAST fused sweep on this rank (HIP events on the shard's stream): [0] exchanges that bring
+// a memory-sharded x to the recursions, [1] forward recursion, [2] observation + E_sde terms of the own grid points, [3] gathers
+// of the small terms + the time -> row exchange of dEsde_dS, [4] backward recursion, [5] gradient of the own grid points + F.
+int vgpa_shard_phase_ms(vgpa_shard* s, double* ms6) {
+  if (!s || !ms6) return VGPA_ERR_ARG;
+  if (!s->c.phases_valid) return VGPA_ERR_STATE;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  if (hipEventSynchronize(s->c.ev_phase[6]) != hipSuccess) return VGPA_ERR_DEVICE;
+  for (int i = 0; i < 6; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->c.ev_phase[i], s->c.ev_phase[i + 1]) != hipSuccess) return VGPA_ERR_DEVICE;
+    ms6[i] = ms;
+  }
+  return VGPA_OK;
+}
+
+// ONE stage of the row-sharded recursion as the forward RK4 loop issues it -- K-chunk products (waiting for the sub-blocks of the
+// previous stage's gather), all-to-all, stage kernel, gather of the next stage state -- `reps` times back to back on the shard's
+// own workspace, stage i reading what stage i - 1 completed; with_collectives == 0 leaves the collectives out (same kernels, same
+// launches), so that (with) - (without) is the communication a stage does NOT hide.  Timing only: the workspace is overwritten.
+// Collective call when with_collectives != 0.
+int vgpa_shard_time_stage(vgpa_shard* s, int reps, int with_collectives, double* ms_per_stage) {
+  if (!s || reps < 1 || !ms_per_stage) return VGPA_ERR_ARG;
+  *ms_per_stage = 0.0;
+  if (s->c.failed) return VGPA_ERR_COMM;
+  if (hipSetDevice(s->device) != hipSuccess) return VGPA_ERR_DEVICE;
+  ld::ShardCtx& c = s->c;
+  ld::ShardWork& w = c.w;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return VGPA_ERR_DEVICE;
+  const size_t r0 = (size_t)c.row0 * c.D;
+  int rc = ld::shard_join(c) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+  c.skip_comm = !with_collectives;
+  c.mid_a0 = c.mid_a1 = nullptr;
+  for (int it = -2; it < reps && rc == VGPA_OK; it++) {
+    if (it == 0) (void)hipEventRecord(e0, c.st);
+    ld::ShardStage st{};
+    st.fwd = true;
+    st.Ag0 = w.cur + r0; st.Ag1 = nullptr; st.ldag = c.D; st.Av0 = w.cur + r0; st.Av1 = nullptr; st.ldav = c.D;
+    st.X = (it & 1) ? w.XB : w.XA; st.xv = (it & 1) ? w.xvB : w.xvA;
+    st.E0 = w.cur + r0; st.e0 = w.vcur + c.row0;
+    st.base = w.cur; st.vbase = w.vcur;
+    st.out = (it & 1) ? w.XA : w.XB; st.vout = (it & 1) ? w.xvA : w.xvB;
+    st.kstore = 1; st.final_mode = 0; st.cx = 0.0; st.cf = 0.0;          // out = base + 0 * slope: the data stay what they are
+    if (ld::shard_stage(c, st) != hipSuccess) rc = c.failed ? VGPA_ERR_COMM : VGPA_ERR_DEVICE;
+  }
+  c.skip_comm = false;
+  if (rc == VGPA_OK && ld::shard_join(c) != hipSuccess) rc = VGPA_ERR_DEVICE;
+  if (rc == VGPA_OK) {
+    (void)hipEventRecord(e1, c.st);
+    rc = ld::shard_wait(c);
+    float ms = 0.f;
+    if (rc == VGPA_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_per_stage = ms / reps;
+  }
+  if (rc != VGPA_OK) ld::comm_failed(c);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return rc;
 }

@@ -19,6 +19,7 @@ typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t)
 typedef int (*send_t)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*recv_t)(void*, size_t, int, int, void*, hipStream_t);
 typedef int (*group_t)();
+typedef int (*comm_count_t)(void*, int*);
 constexpr int kNcclFloat64 = 8;          // ncclDataType_t (rccl.h)
 
 struct Api {
@@ -31,6 +32,7 @@ struct Api {
   send_t send = nullptr;
   recv_t recv = nullptr;
   group_t group_start = nullptr, group_end = nullptr;
+  comm_count_t comm_count = nullptr;      // optional
   bool tried = false, ok = false;
 };
 Api g_api;
@@ -59,6 +61,7 @@ bool load_api() {
   g_api.recv = (recv_t)dlsym(g_api.so, "ncclRecv");
   g_api.group_start = (group_t)dlsym(g_api.so, "ncclGroupStart");
   g_api.group_end = (group_t)dlsym(g_api.so, "ncclGroupEnd");
+  g_api.comm_count = (comm_count_t)dlsym(g_api.so, "ncclCommCount");
   g_api.ok = g_api.get_unique_id && g_api.comm_init_rank && g_api.comm_destroy && g_api.all_gather && g_api.send && g_api.recv &&
              g_api.group_start && g_api.group_end;
   return g_api.ok;
@@ -141,6 +144,16 @@ int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_bytes, int rank, int wo
   out->recv = rccl_recv;
   out->abort = rccl_abort;
   return VGPA_OK;
+}
+
+// ranks of the communicator as the LIBRARY counts them (ncclCommCount) -- what bench.py reports as `rccl_ranks`
+int vgpa_rccl_comm_count(const vgpa_comm* comm, int* count) {
+  if (!comm || !comm->user || !count) return VGPA_ERR_ARG;
+  if (comm->all_gather != rccl_all_gather) return VGPA_ERR_ARG;       // not a table vgpa_rccl_comm_create filled
+  RcclComm* c = static_cast<RcclComm*>(comm->user);
+  if (!c->comm) return VGPA_ERR_COMM;
+  if (!g_api.comm_count) return VGPA_ERR_UNSUPPORTED;
+  return g_api.comm_count(c->comm, count) == 0 ? VGPA_OK : VGPA_ERR_DEVICE;
 }
 
 void vgpa_rccl_comm_destroy(vgpa_comm* comm) {

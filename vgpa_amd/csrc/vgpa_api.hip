@@ -198,7 +198,10 @@ static void pick_kernel_family(vgpa_ctx* c) {
   const char* fam = getenv("VGPA_ODE_KERNEL");
   const bool keep_pe = fam && !strcmp(fam, "pe");
   const int nb = (c->D + 3) / 4;
-  c->sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) != 0 || (c->B > n_cu && nb <= 10) || ((nb == 9 || nb == 10) && !keep_pe);
+  // (D > 44 has no other matrix-core stepper: launch_ode_mfma always takes the symmetric-unit kernels there, so the context
+  //  says so too and the energy kernel writes dEsde_dS as the upper triangle those kernels read)
+  c->sym_units = (c->cfg.flags & VGPA_FLAG_SYM_UNITS) != 0 || (c->B > n_cu && nb <= 10) || ((nb == 9 || nb == 10) && !keep_pe) ||
+                 (nb >= 12 && c->D <= kMaxSmallD);
 }
 
 static bool use_mfma(vgpa_ctx* c, bool fwd, bool sym) {
@@ -728,8 +731,11 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
     HTRY(hipMemGetInfo(&free_b, &total_b));
     const double need = 8.0 * (double)BN * (double)DD * 4.0;        // dEs + Psi + the caller's x and g still to come
     c->stream_ld = (cfg->flags & VGPA_FLAG_STREAM_LARGE_D) != 0 || need > 0.9 * (double)free_b;
-    if (c->stream_ld && c->B > 1)
-      return fail(nullptr, VGPA_ERR_UNSUPPORTED, "the time-chunked large-D sweep holds one problem (a batch of %d does not fit resident)", c->B);
+    if (c->stream_ld && c->B > 1) {      // (everything allocated so far goes back: this fires exactly when memory is short)
+      const int nb_ = c->B;
+      vgpa_destroy(c);
+      return fail(nullptr, VGPA_ERR_UNSUPPORTED, "the time-chunked large-D sweep holds one problem (a batch of %d does not fit resident)", nb_);
+    }
     c->lde_budget = std::fmin(16.0e9, std::fmax(1.0e9, 0.05 * (double)free_b));   // workspace of the batched energy terms
     c->ld_chunk = ld::lde_batch(D, c->lde_budget) - 1;   // a chunk evaluates ld_chunk + 1 grid points: exactly one energy batch
     if (c->ld_chunk > c->Np - 1) c->ld_chunk = c->Np - 1;

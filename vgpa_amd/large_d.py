@@ -497,6 +497,31 @@ class NativeShardedRecursion:
                     "vgpa_shard_time_collectives")
         return a.value, g.value
 
+    def time_stage(self, reps=20, with_collectives=True):
+        """Milliseconds of ONE stage of the forward RK4 recursion as the driver issues it (vgpa_shard_time_stage); without the
+        collectives it is the stage's compute alone.  Timing only: overwrites the shard's workspace."""
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.vgpa_shard_time_stage(self._h, int(reps), 1 if with_collectives else 0, ctypes.byref(ms)),
+                    "vgpa_shard_time_stage")
+        return ms.value
+
+    def phase_ms(self):
+        """Phases of this rank's last fused sweep in milliseconds (vgpa_shard_phase_ms)."""
+        v = (ctypes.c_double * 6)()
+        self._check(self._lib.vgpa_shard_phase_ms(self._h, v), "vgpa_shard_phase_ms")
+        names = ("x_exchange", "forward_recursion", "energy_obs", "exchanges", "backward_recursion", "gradient")
+        return {k: float(x) for k, x in zip(names, v)}
+
+    @property
+    def rccl_ranks(self):
+        """Ranks of the communicator as librccl itself counts them (ncclCommCount); 0 without an RCCL communicator (one rank,
+        or an injected table)."""
+        if self._comm is None or not self._own_comm:
+            return 0
+        n = ctypes.c_int(0)
+        self._check(self._lib.vgpa_rccl_comm_count(ctypes.byref(self._comm), ctypes.byref(n)), "vgpa_rccl_comm_count")
+        return int(n.value)
+
     def _problem(self, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
         from ._lib import VgpaShardProblem
         d = self.D
