@@ -76,10 +76,15 @@ enum {
                                   when the resident arrays would not fit into free device memory. */
   VGPA_FLAG_SYM_UNITS = 16,    /* 5 <= D <= 44: the symmetric-unit stepping kernels (ode_sym_impl.h; two problems per CU, the
                                   default for 44 < D <= 64) instead of the role-specialised ones.  Same results to rounding. */
-  VGPA_FLAG_KEEP_PSI = 32      /* batched symmetric-unit sweeps (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I): by default the backward
+  VGPA_FLAG_KEEP_PSI = 32,     /* batched symmetric-unit sweeps (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I): by default the backward
                                   kernel leaves Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- all the gradient assembly
                                   needs of the two, one HBM stream less -- and VGPA_FETCH_PSIT recovers Psi_t from it
                                   ((Sigma^-1 A_t - Q''_t) / 2, equal to rounding).  This flag stores Psi_t itself. */
+  VGPA_FLAG_MATERIALIZE = 64   /* lane-per-problem contexts of OU / double well / Lorenz-63 (D = 1 always, D = 3 from 512 problems):
+                                  by default the fused objective runs as TWO kernels -- forward moments, then one backward pass
+                                  that re-evaluates the closed-form E_sde terms in registers, steps (lam, Psi), assembles the
+                                  gradient and sums F -- and dEsde_dm / dEsde_dS / <f> / E_sde(t) / lam_t / Psi_t reach HBM only
+                                  when vgpa_fetch asks for them.  This flag keeps the four-kernel path that writes them all. */
 };
 
 typedef struct vgpa_ctx vgpa_ctx;

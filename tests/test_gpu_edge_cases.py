@@ -329,3 +329,45 @@ def test_diagnostic_phase_repeat_leaves_the_results_alone():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     assert all(o == outs[0] for o in outs[1:]), outs
+
+
+@pytest.mark.parametrize("model,method,n,nb", [("L63", "rk4", 37, 520), ("L63", "rk4", 6, 576), ("L63", "heun", 22, 513), ("L63", "rk2", 9, 640),
+                                               ("L63", "euler", 3, 512), ("OU", "euler", 41, 70), ("OU", "rk4", 18, 1), ("DW", "rk4", 33, 130),
+                                               ("DW", "heun", 17, 64), ("OU", "rk2", 3, 3)])
+def test_fused_lane_pass(model, method, n, nb):
+    """BASELINE configs[0] / [1] batched: OU, double well and Lorenz-63 contexts on the lane-per-problem path run the objective as
+    forward kernel -> observations -> ONE fused pass (E_sde terms in registers, backward recursion, gradient, F); the streams
+    travel through LDS in chunks of T grid points.  Grids shorter than, equal to and not a multiple of the chunk; batches that
+    leave the last wave ragged.  Checked: a few problems against the ORACLE, every problem against the four-kernel path
+    (VGPA_FLAG_MATERIALIZE: same expressions, F summed in another order), free_energy + gradient(eval_fun=False) against the
+    one-call sweep, and the arrays the fused pass never wrote (lam_t, Psi_t, dEsde_dm, dEsde_dS, <f>, E_sde(t)) as vgpa_fetch
+    materialises them."""
+    from vgpa_amd._lib import FLAG_MATERIALIZE
+    d = 3 if model == "L63" else 1
+    p, x0 = make_problem(model, d, n, method=method, obs_at=sorted(set(range(1, n - 1, 4))) if n > 3 else [1])
+    rng = np.random.default_rng(n * 1000 + nb)
+    xb = x0[None, :] + 0.05 * rng.standard_normal((nb, x0.size))
+    ctx, ref = gpu_context(p, batch=nb), gpu_context(p, batch=nb, flags=FLAG_MATERIALIZE)
+    f, g = ctx.sweep(xb)
+    f_r, g_r = ref.sweep(xb)
+    f, g, f_r, g_r = np.atleast_1d(f), np.atleast_2d(g), np.atleast_1d(f_r), np.atleast_2d(g_r)
+    assert np.max(np.abs(f - f_r) / np.abs(f_r)) < 1e-12
+    assert rel_err(g, g_r) < 1e-12
+    for i in sorted({0, min(63, nb - 1), min(64, nb - 1), nb - 1}):
+        f_o, g_o, st = vo.sweep(p, xb[i], faithful=False)
+        assert abs(f[i] - f_o) <= TOL * abs(f_o), (i, f[i], f_o)
+        assert rel_err(g[i], g_o) < TOL, i
+    # two calls: F alone (no recursion), then the gradient from the cached moments
+    f2 = np.atleast_1d(ctx.free_energy(xb))
+    g2 = np.atleast_2d(ctx.gradient())
+    assert np.array_equal(f2, f) and np.array_equal(g2, g)
+    # what the fused pass keeps in registers, on demand
+    for key in ("lamt", "psit", "dEsde_dm", "dEsde_ds", "Efx", "Esde_t", "mt", "st", "Edf"):
+        got, want = ctx.fetch(key), ref.fetch(key)
+        assert rel_err(got, want) < 1e-13, key
+    e0, es, eo = ctx.energy_parts()
+    e0r, esr, eor = ref.energy_parts()
+    assert rel_err(np.atleast_1d(es), np.atleast_1d(esr)) < 1e-12 and np.array_equal(np.atleast_1d(eo), np.atleast_1d(eor))
+    # and a gradient behind the fetch (derived arrays valid: either route) still equals the sweep's
+    assert rel_err(np.atleast_2d(ctx.gradient()), g) < 1e-12
+    ctx.close(); ref.close()

@@ -22,6 +22,7 @@ FLAG_STREAM_LARGE_D = 4
 FLAG_LIBRARY_GEMM = 8
 FLAG_SYM_UNITS = 16
 FLAG_KEEP_PSI = 32
+FLAG_MATERIALIZE = 64
 OPT_LD_CHUNK = 1
 
 # exported symbols, checked by the CPU test-suite against include/vgpa_hip.h

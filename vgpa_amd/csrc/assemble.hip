@@ -5,6 +5,7 @@
 //                                 _grad_at :308)
 //   E_sde = trapezoid(e_t)      : src/numerics/utilities.py:144-201 (piecewise sums == one global sum)
 #include "vgpa_internal.h"
+#include "energy_small.h"
 
 namespace vgpa {
 namespace {
@@ -582,47 +583,21 @@ __global__ void __launch_bounds__(64) k_grad_small(GradArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < D; i++) { mv[i] = a.m[o * D + i]; bv[i] = bt[i]; ef[i] = a.Ef[o * D + i]; lm[i] = a.lam[o * D + i]; }
-  double rv[D], uv[D], pa[DD], q[DD];
+  if (!a.Edf) {
 #pragma unroll
-  for (int i = 0; i < D; i++) {
-    double s = 0.0;
+    for (int i = 0; i < D; i++)
 #pragma unroll
-    for (int k = 0; k < D; k++) s = __builtin_fma(Av[i * D + k], mv[k], s);
-    rv[i] = -ef[i] - s + bv[i];
+      for (int j = 0; j < D; j++) Ev[i * D + j] = edf_entry(a.model, a.theta, D, i, j, mv, Sv[0]);
   }
-#pragma unroll
-  for (int i = 0; i < D; i++)
-#pragma unroll
-    for (int j = 0; j < D; j++)
-      pa[i * D + j] = (a.Edf ? Ev[i * D + j] : edf_entry(a.model, a.theta, D, i, j, mv, Sv[0])) + Av[i * D + j];
-#pragma unroll
-  for (int i = 0; i < D; i++) {
-    double deb = 0.0;
-#pragma unroll
-    for (int l = 0; l < D; l++) deb = __builtin_fma(Iv[i * D + l], rv[l], deb);
-    uv[i] = deb + lm[i];
-#pragma unroll
-    for (int j = 0; j < D; j++) {
-      double s = 0.0;
-#pragma unroll
-      for (int l = 0; l < D; l++) s = __builtin_fma(Iv[i * D + l], pa[l * D + j], s);
-      q[i * D + j] = s - 2.0 * Pv[i * D + j];
-    }
-  }
+  double gAv[DD], gBv[D];
+  grad_point<D>(Av, bv, mv, Sv, ef, Ev, Pv, lm, Iv, a.dt, gAv, gBv);
   const size_t len_x = (size_t)a.Np * DD + (size_t)a.Np * D;
   double* gA = a.g + (size_t)prob * len_x + (size_t)t * DD;
   double* gB = a.g + (size_t)prob * len_x + (size_t)a.Np * DD + (size_t)t * D;
 #pragma unroll
-  for (int i = 0; i < D; i++) {
-    gB[i] = a.dt * uv[i];
+  for (int i = 0; i < D; i++) gB[i] = gBv[i];
 #pragma unroll
-    for (int j = 0; j < D; j++) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; k++) s = __builtin_fma(q[i * D + k], Sv[k * D + j], s);
-      gA[i * D + j] = a.dt * (s - uv[i] * mv[j]);
-    }
-  }
+  for (int e = 0; e < DD; e++) gA[e] = gAv[e];
 }
 
 // E_sde = pre * trapz(e_t, dt) / div ;  F = e0 + E_sde + E_obs.   One workgroup per problem.

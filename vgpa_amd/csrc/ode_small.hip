@@ -11,7 +11,19 @@
 //             (jumps added after the step, Q9; f_lam uses A.lam, Q3)
 //   RHS     : f_S = -A S - S A^T + Sigma (ode_solver.py:60), f_Psi = -G + Psi A + A^T Psi (ode_solver.py:94)
 // A_{t+-1}, b / dE of the next step are requested one step ahead.
+//
+// Round 4 -- memory path.  A lane's operands sit len_x doubles away from its neighbour's, so a per-lane load is 64 cache-line
+// requests per instruction and the kernels were bound by the request rate of the texture path (0.15 of the HBM roofline at
+// 65536 Lorenz-63 problems), not by bytes.  k_fwd_lane / k_sweep_lane move every time-indexed stream through LDS in CHUNKS of T
+// grid points: the wave reads the chunk of its 64 problems with flat, coalesced loads (lane i takes double i of the
+// concatenated per-problem pieces: 5-10 line requests per instruction), parks it in registers for the T steps of the previous
+// chunk, drops it into LDS rows (row p = problem p), and each lane consumes its own row; results take the consumed slots and
+// leave the same way.  k_sweep_lane is the FUSED backward pass of the models with closed-form moments (OU, double well,
+// Lorenz-63: BASELINE configs[0] / [1]): a lane re-evaluates the energy terms of grid point t-1 from (A, b, m, S) in registers
+// (energy_small.h), steps (lam, Psi), assembles gLa / gLb of t-1 and carries the trapezoid of E_sde -- dEsde_dm, dEsde_dS,
+// <f>, E_sde(t), lam_t, Psi_t never touch HBM (vgpa_fetch materialises them on demand through the separate kernels).
 #include "vgpa_internal.h"
+#include "energy_small.h"
 
 namespace vgpa {
 namespace {
@@ -92,104 +104,235 @@ __device__ __forceinline__ void mid_mat(const double (&a0)[D * D], const double 
   for (int e = 0; e < D * D; e++) m[e] = 0.5 * (a0[e] + a1[e]);
 }
 
+// ---- coalesced chunks: N doubles per problem and chunk, 64 problems per wave -> N doubles per lane ----------------------------
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N>
+constexpr int row_stride() { return N | 1; }      // odd: a lane's row reads are spread over the banks
+
+// How the 64 lanes of an instruction cover the chunk: G consecutive doubles of each of PG = 64 / G problems; a problem's N
+// doubles take R = ceil(N / G) instructions, the 64 problems NG = ceil(64 / PG) groups.  Affine in the lane -- lane l always
+// works on (problem l / G, double l % G) of its instruction's block -- so that addresses are one per-lane offset plus uniform
+// terms, not one precomputed address pair per instruction (which is what the register allocator makes of a flat index).
+template <int N>
+struct ChunkMap {
+  static constexpr int cost(int g) { return ((NTS + NTS / g - 1) / (NTS / g)) * ((N + g - 1) / g); }
+  static constexpr int pick() {
+    int best = 16;
+    for (int g = 16; g >= 4; g--)
+      if (cost(g) < cost(best)) best = g;
+    return best;
+  }
+  static constexpr int G = pick();
+  static constexpr int R = (N + G - 1) / G;
+  static constexpr int PG = NTS / G;
+  static constexpr int NG = (NTS + PG - 1) / PG;
+  static constexpr int NI = NG * R;               // instructions per chunk = doubles a lane holds between request and LDS
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Requests the chunk [first, first + N) of every problem of the wave.  base_u: the stream's first problem of this wave
+// (wave-uniform); problem p at base_u + p * pstride, `limit` doubles each.  Indices outside [0, limit) are clamped (their values
+// are never used), problems beyond the batch repeat the last valid one.  32-bit offsets: 64 * pstride * 8 < 2^32 (launcher).
+template <int N>
+__device__ __forceinline__ void chunk_request(const double* __restrict__ base_u, unsigned pstride, int nvalid, long first, long limit,
+                                              double (&v)[ChunkMap<N>::NI]) {
+  using M = ChunkMap<N>;
+  const unsigned lane = threadIdx.x;
+  const bool act = lane < (unsigned)(M::PG * M::G);
+  const int pl = act ? (int)(lane / M::G) : 0, el = act ? (int)(lane % M::G) : 0;
+  const double* bu = base_u + first;                      // uniform; only ever dereferenced at clamped offsets
+  const int lo = (int)(-first), hi = (int)(limit - 1 - first);
+#pragma unroll
+  for (int jg = 0; jg < M::NG; jg++)
+#pragma unroll
+    for (int r = 0; r < M::R; r++) {
+      int p = jg * M::PG + pl;
+      p = p < nvalid ? p : nvalid - 1;
+      const int e = clampi(r * M::G + el, lo, hi);
+      v[jg * M::R + r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(bu) + ((unsigned)p * pstride + (unsigned)e) * 8u);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void chunk_to_lds(double* __restrict__ lds, const double (&v)[ChunkMap<N>::NI]) {
+  using M = ChunkMap<N>;
+  const unsigned lane = threadIdx.x;
+  const bool act = lane < (unsigned)(M::PG * M::G);
+  const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
+  double* mine = lds + pl * row_stride<N>() + el;
+#pragma unroll
+  for (int jg = 0; jg < M::NG; jg++)
+#pragma unroll
+    for (int r = 0; r < M::R; r++) {
+      const bool ok = act && (r * M::G + el < N) && (jg * M::PG + pl < NTS);
+      if (ok) mine[jg * M::PG * row_stride<N>() + r * M::G] = v[jg * M::R + r];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void chunk_flush(const double* __restrict__ lds, double* __restrict__ base_u, unsigned pstride, int nvalid,
+                                            long first, long limit) {
+  using M = ChunkMap<N>;
+  const unsigned lane = threadIdx.x;
+  const bool act = lane < (unsigned)(M::PG * M::G);
+  const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
+  const double* mine = lds + pl * row_stride<N>() + el;
+  double* bu = base_u + first;
+  const int lo = (int)(-first), hi = (int)(limit - 1 - first);
+#pragma unroll
+  for (int jg = 0; jg < M::NG; jg++)
+#pragma unroll
+    for (int r = 0; r < M::R; r++) {
+      const int p = jg * M::PG + pl, e = r * M::G + el;
+      const bool ok = act && e < N && p < nvalid && e >= lo && e <= hi;
+      if (ok) {
+        const double val = mine[jg * M::PG * row_stride<N>() + r * M::G];
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(bu) + ((unsigned)p * pstride + (unsigned)e) * 8u) = val;
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
+// one forward step k -> k+1: (sk, mk) in place; operands of the start point (A0, b0) and of the end point (A1, b1)
 template <int METHOD, int D>
-__global__ void __launch_bounds__(NTS) k_fwd_small(OdeArgs a) {
+__device__ __forceinline__ void fwd_step(const double (&A0)[D * D], const double (&A1)[D * D], const double (&b0)[D], const double (&b1)[D],
+                                         const double (&sig)[D * D], double dt, double (&sk)[D * D], double (&mk)[D]) {
   constexpr int DD = D * D;
-  const int prob = blockIdx.x * NTS + threadIdx.x;
-  if (prob >= a.batch) return;
+  const double h = 0.5 * dt;
+  double r[DD], y[D], X[DD], xv[D];
+  if (METHOD == VGPA_ODE_EULER) {
+    rhs_fwd<D>(A0, sk, sig, r);
+    matvec<D>(A0, mk, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) sk[e] = sk[e] + r[e] * dt;
+#pragma unroll
+    for (int i = 0; i < D; i++) mk[i] = mk[i] + (-y[i] + b0[i]) * dt;
+  } else if (METHOD == VGPA_ODE_HEUN) {
+    double acc1[DD], pm[D];
+    rhs_fwd<D>(A0, sk, sig, r);
+    matvec<D>(A0, mk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { pm[i] = -y[i] + b0[i]; xv[i] = mk[i] + pm[i] * dt; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = sk[e] + r[e] * dt; }
+    rhs_fwd<D>(A1, X, sig, r);
+    matvec<D>(A1, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) sk[e] = sk[e] + h * (acc1[e] + r[e]);
+#pragma unroll
+    for (int i = 0; i < D; i++) mk[i] = mk[i] + h * (pm[i] + (-y[i] + b1[i]));
+  } else if (METHOD == VGPA_ODE_RK2) {
+    // mean predictor uses A_k; covariance predictor uses S_k in the place of A_k (Q2)
+    double pm[D], AM[DD];
+    matvec<D>(A0, mk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { pm[i] = -y[i] + b0[i]; xv[i] = mk[i] + h * pm[i]; }
+    rhs_fwd<D>(sk, sk, sig, r);
+#pragma unroll
+    for (int e = 0; e < DD; e++) X[e] = sk[e] + h * r[e];
+    mid_mat<D>(A0, A1, AM);
+    rhs_fwd<D>(AM, X, sig, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) sk[e] = sk[e] + dt * r[e];
+#pragma unroll
+    for (int i = 0; i < D; i++) mk[i] = mk[i] + dt * (-y[i] + 0.5 * (b0[i] + b1[i]));
+  } else {  // RK4
+    double acc1[DD], acc2[DD], AM[DD], k1[D], k2[D], k3[D], bmid[D];
+    rhs_fwd<D>(A0, sk, sig, r);
+    matvec<D>(A0, mk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k1[i] = -y[i] + b0[i]; xv[i] = mk[i] + h * k1[i]; bmid[i] = 0.5 * (b0[i] + b1[i]); }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = sk[e] + h * r[e]; }
+    mid_mat<D>(A0, A1, AM);
+    rhs_fwd<D>(AM, X, sig, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k2[i] = -y[i] + bmid[i]; xv[i] = mk[i] + h * k2[i]; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc2[e] = r[e]; X[e] = sk[e] + h * r[e]; }
+    rhs_fwd<D>(AM, X, sig, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k3[i] = -y[i] + bmid[i]; xv[i] = mk[i] + dt * k3[i]; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc2[e] = acc2[e] + r[e]; X[e] = sk[e] + dt * r[e]; }
+    rhs_fwd<D>(A1, X, sig, r);
+    matvec<D>(A1, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) sk[e] = sk[e] + dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) mk[i] = mk[i] + dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-y[i] + b1[i])) / 6.0;
+  }
+}
+
+// Forward moments, one lane per problem, streams staged through LDS in chunks of T grid points.  Step k consumes the operands of
+// grid point k+1 (slot s of the chunk) and produces (m, S) of grid point k+1: the result takes the consumed slot.
+template <int METHOD, int D, int T>
+__global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_fwd_lane(OdeArgs a) {
+  constexpr int DD = D * D, NA = T * DD, NB = T * D;
+  __shared__ double sA[NTS * row_stride<NA>()];
+  __shared__ double sB[NTS * row_stride<NB>()];
+  const int lane = threadIdx.x, prob0 = blockIdx.x * NTS;
+  const int nvalid = (a.batch - prob0) < NTS ? (a.batch - prob0) : NTS;
+  const bool live = lane < nvalid;
+  const int prob = prob0 + (live ? lane : nvalid - 1);
   const int Np = a.Np;
   const double* A = a.A + (size_t)prob * a.strideA;
   const double* b = a.b + (size_t)prob * a.strideB;
-  double* mt = a.m + (size_t)prob * Np * D;
-  double* st = a.S + (size_t)prob * Np * DD;
-  const double dt = a.dt, h = 0.5 * a.dt;
+  const double dt = a.dt;
+  const size_t sS = (size_t)Np * DD, sm = (size_t)Np * D;
 
-  double sk[DD], sig[DD], mk[D];
+  double sk[DD], sig[DD], mk[D], A0[DD], b0[D];
   ld_mat<D>(a.S0, sk); ld_mat<D>(a.Sigma, sig); ld_vec<D>(a.m0, mk);
-  st_mat<D>(st, sk); st_vec<D>(mt, mk);
-  double A0[DD], A1[DD], b0[D], b1[D];
   ld_mat<D>(A, A0); ld_vec<D>(b, b0);
-  if (Np > 1) { ld_mat<D>(A + DD, A1); ld_vec<D>(b + D, b1); }
+  if (live) { st_mat<D>(a.S + (size_t)prob * sS, sk); st_vec<D>(a.m + (size_t)prob * sm, mk); }
 
-  for (int k = 0; k < Np - 1; k++) {
-    // A_{k+2}, b_{k+2} for the next step (clamped at the end of the grid; the value is then unused)
-    double A2[DD], b2[D];
-    const int kn = (k + 2 < Np) ? k + 2 : Np - 1;
-    ld_mat<D>(A + (size_t)kn * DD, A2); ld_vec<D>(b + (size_t)kn * D, b2);
-
-    double r[DD], y[D], X[DD], xv[D];
-    if (METHOD == VGPA_ODE_EULER) {
-      rhs_fwd<D>(A0, sk, sig, r);
-      matvec<D>(A0, mk, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) sk[e] = sk[e] + r[e] * dt;
-#pragma unroll
-      for (int i = 0; i < D; i++) mk[i] = mk[i] + (-y[i] + b0[i]) * dt;
-    } else if (METHOD == VGPA_ODE_HEUN) {
-      double acc1[DD], pm[D];
-      rhs_fwd<D>(A0, sk, sig, r);
-      matvec<D>(A0, mk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { pm[i] = -y[i] + b0[i]; xv[i] = mk[i] + pm[i] * dt; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = sk[e] + r[e] * dt; }
-      rhs_fwd<D>(A1, X, sig, r);
-      matvec<D>(A1, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) sk[e] = sk[e] + h * (acc1[e] + r[e]);
-#pragma unroll
-      for (int i = 0; i < D; i++) mk[i] = mk[i] + h * (pm[i] + (-y[i] + b1[i]));
-    } else if (METHOD == VGPA_ODE_RK2) {
-      // mean predictor uses A_k; covariance predictor uses S_k in the place of A_k (Q2)
-      double pm[D], AM[DD];
-      matvec<D>(A0, mk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { pm[i] = -y[i] + b0[i]; xv[i] = mk[i] + h * pm[i]; }
-      rhs_fwd<D>(sk, sk, sig, r);
-#pragma unroll
-      for (int e = 0; e < DD; e++) X[e] = sk[e] + h * r[e];
-      mid_mat<D>(A0, A1, AM);
-      rhs_fwd<D>(AM, X, sig, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) sk[e] = sk[e] + dt * r[e];
-#pragma unroll
-      for (int i = 0; i < D; i++) mk[i] = mk[i] + dt * (-y[i] + 0.5 * (b0[i] + b1[i]));
-    } else {  // RK4
-      double acc1[DD], acc2[DD], AM[DD], k1[D], k2[D], k3[D], bmid[D];
-      rhs_fwd<D>(A0, sk, sig, r);
-      matvec<D>(A0, mk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k1[i] = -y[i] + b0[i]; xv[i] = mk[i] + h * k1[i]; bmid[i] = 0.5 * (b0[i] + b1[i]); }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = sk[e] + h * r[e]; }
-      mid_mat<D>(A0, A1, AM);
-      rhs_fwd<D>(AM, X, sig, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k2[i] = -y[i] + bmid[i]; xv[i] = mk[i] + h * k2[i]; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc2[e] = r[e]; X[e] = sk[e] + h * r[e]; }
-      rhs_fwd<D>(AM, X, sig, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k3[i] = -y[i] + bmid[i]; xv[i] = mk[i] + dt * k3[i]; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc2[e] = acc2[e] + r[e]; X[e] = sk[e] + dt * r[e]; }
-      rhs_fwd<D>(A1, X, sig, r);
-      matvec<D>(A1, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) sk[e] = sk[e] + dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0;
-#pragma unroll
-      for (int i = 0; i < D; i++) mk[i] = mk[i] + dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-y[i] + b1[i])) / 6.0;
+  const int nchunks = (Np - 1 + T - 1) / T;
+  double pa[ChunkMap<NA>::NI], pb[ChunkMap<NB>::NI];
+  const double* Au = a.A + (size_t)prob0 * a.strideA;        // wave-uniform stream bases
+  const double* bu = a.b + (size_t)prob0 * a.strideB;
+  double* Su = a.S + (size_t)prob0 * sS;
+  double* mu = a.m + (size_t)prob0 * sm;
+  const unsigned strA = (unsigned)a.strideA, strB = (unsigned)a.strideB;
+  chunk_request<NA>(Au, strA, nvalid, (long)DD, (long)Np * DD, pa);
+  chunk_request<NB>(bu, strB, nvalid, (long)D, (long)Np * D, pb);
+  double* rowA = sA + lane * row_stride<NA>();
+  double* rowB = sB + lane * row_stride<NB>();
+  for (int c = 0; c < nchunks; c++) {
+    chunk_to_lds<NA>(sA, pa);
+    chunk_to_lds<NB>(sB, pb);
+    wave_sync();
+    if (c + 1 < nchunks) {      // the next chunk travels while this one is stepped through
+      chunk_request<NA>(Au, strA, nvalid, (long)((c + 1) * T + 1) * DD, (long)Np * DD, pa);
+      chunk_request<NB>(bu, strB, nvalid, (long)((c + 1) * T + 1) * D, (long)Np * D, pb);
     }
-    st_mat<D>(st + (size_t)(k + 1) * DD, sk);
-    st_vec<D>(mt + (size_t)(k + 1) * D, mk);
 #pragma unroll
-    for (int e = 0; e < DD; e++) { A0[e] = A1[e]; A1[e] = A2[e]; }
+    for (int s = 0; s < T; s++) {
+      if (c * T + s < Np - 1) {
+        double A1[DD], b1[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) { b0[i] = b1[i]; b1[i] = b2[i]; }
+        for (int e = 0; e < DD; e++) A1[e] = rowA[s * DD + e];
+#pragma unroll
+        for (int i = 0; i < D; i++) b1[i] = rowB[s * D + i];
+        fwd_step<METHOD, D>(A0, A1, b0, b1, sig, dt, sk, mk);
+#pragma unroll
+        for (int e = 0; e < DD; e++) { rowA[s * DD + e] = sk[e]; A0[e] = A1[e]; }
+#pragma unroll
+        for (int i = 0; i < D; i++) { rowB[s * D + i] = mk[i]; b0[i] = b1[i]; }
+      }
+    }
+    wave_sync();
+    chunk_flush<NA>(sA, Su, (unsigned)sS, nvalid, (long)(c * T + 1) * DD, (long)Np * DD);
+    chunk_flush<NB>(sB, mu, (unsigned)sm, nvalid, (long)(c * T + 1) * D, (long)Np * D);
+    wave_sync();
   }
 }
 
@@ -214,6 +357,83 @@ __device__ __forceinline__ void load_jump(const OdeArgs& a, int prob, int t1, do
   }
 }
 
+// one backward step t -> t-1: (pk, lk) in place; "t" operands (At, gst, gmt), "t-1" operands (Am, gsm, gmm), jump of t-1
+template <int METHOD, int D>
+__device__ __forceinline__ void bwd_step(const double (&At)[D * D], const double (&Am)[D * D], const double (&gst)[D * D],
+                                         const double (&gsm)[D * D], const double (&gmt)[D], const double (&gmm)[D],
+                                         const double (&js)[D * D], const double (&jm)[D], double dt, double (&pk)[D * D],
+                                         double (&lk)[D]) {
+  constexpr int DD = D * D;
+  const double h = 0.5 * dt;
+  double r[DD], y[D], X[DD], xv[D];
+  if (METHOD == VGPA_ODE_EULER) {
+    rhs_bwd<D>(At, pk, gst, r);
+    matvec<D>(At, lk, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) pk[e] = pk[e] - r[e] * dt + js[e];
+#pragma unroll
+    for (int i = 0; i < D; i++) lk[i] = lk[i] - (-gmt[i] + y[i]) * dt + jm[i];
+  } else if (METHOD == VGPA_ODE_HEUN) {
+    double acc1[DD], pl[D];
+    rhs_bwd<D>(At, pk, gst, r);
+    matvec<D>(At, lk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { pl[i] = -gmt[i] + y[i]; xv[i] = lk[i] - pl[i] * dt; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = pk[e] - r[e] * dt; }
+    rhs_bwd<D>(Am, X, gsm, r);
+    matvec<D>(Am, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) pk[e] = pk[e] - h * (acc1[e] + r[e]) + js[e];
+#pragma unroll
+    for (int i = 0; i < D; i++) lk[i] = lk[i] - h * (pl[i] + (-gmm[i] + y[i])) + jm[i];
+  } else if (METHOD == VGPA_ODE_RK2) {
+    double pl[D], AM[DD], gmid[DD];
+    rhs_bwd<D>(At, pk, gst, r);
+    matvec<D>(At, lk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { pl[i] = -gmt[i] + y[i]; xv[i] = lk[i] - h * pl[i]; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) X[e] = pk[e] - h * r[e];
+    mid_mat<D>(Am, At, AM);
+    mid_mat<D>(gsm, gst, gmid);
+    rhs_bwd<D>(AM, X, gmid, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) pk[e] = pk[e] - dt * r[e] + js[e];
+#pragma unroll
+    for (int i = 0; i < D; i++) lk[i] = lk[i] - dt * (-(0.5 * (gmm[i] + gmt[i])) + y[i]) + jm[i];
+  } else {  // RK4
+    double acc1[DD], acc2[DD], AM[DD], gmid[DD], k1[D], k2[D], k3[D], gvm[D];
+    rhs_bwd<D>(At, pk, gst, r);
+    matvec<D>(At, lk, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k1[i] = -gmt[i] + y[i]; xv[i] = lk[i] - h * k1[i]; gvm[i] = 0.5 * (gmm[i] + gmt[i]); }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = pk[e] - h * r[e]; }
+    mid_mat<D>(Am, At, AM);
+    mid_mat<D>(gsm, gst, gmid);
+    rhs_bwd<D>(AM, X, gmid, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k2[i] = -gvm[i] + y[i]; xv[i] = lk[i] - h * k2[i]; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc2[e] = r[e]; X[e] = pk[e] - h * r[e]; }
+    rhs_bwd<D>(AM, X, gmid, r);
+    matvec<D>(AM, xv, y);
+#pragma unroll
+    for (int i = 0; i < D; i++) { k3[i] = -gvm[i] + y[i]; xv[i] = lk[i] - dt * k3[i]; }
+#pragma unroll
+    for (int e = 0; e < DD; e++) { acc2[e] = acc2[e] + r[e]; X[e] = pk[e] - dt * r[e]; }
+    rhs_bwd<D>(Am, X, gsm, r);
+    matvec<D>(Am, xv, y);
+#pragma unroll
+    for (int e = 0; e < DD; e++) pk[e] = pk[e] - dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0 + js[e];
+#pragma unroll
+    for (int i = 0; i < D; i++) lk[i] = lk[i] - dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-gmm[i] + y[i])) / 6.0 + jm[i];
+  }
+}
+
 template <int METHOD, int D>
 __global__ void __launch_bounds__(NTS) k_bwd_small(OdeArgs a) {
   constexpr int DD = D * D;
@@ -225,7 +445,7 @@ __global__ void __launch_bounds__(NTS) k_bwd_small(OdeArgs a) {
   const double* gs = a.dEs + (size_t)prob * Np * DD;
   double* lam = a.lam + (size_t)prob * Np * D;
   double* psi = a.psi + (size_t)prob * Np * DD;
-  const double dt = a.dt, h = 0.5 * a.dt;
+  const double dt = a.dt;
 
   double pk[DD], lk[D];
 #pragma unroll
@@ -248,73 +468,7 @@ __global__ void __launch_bounds__(NTS) k_bwd_small(OdeArgs a) {
     double js[DD], jm[D];
     load_jump<D>(a, prob, t - 1, js, jm);
 
-    double r[DD], y[D], X[DD], xv[D];
-    if (METHOD == VGPA_ODE_EULER) {
-      rhs_bwd<D>(At, pk, gst, r);
-      matvec<D>(At, lk, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) pk[e] = pk[e] - r[e] * dt + js[e];
-#pragma unroll
-      for (int i = 0; i < D; i++) lk[i] = lk[i] - (-gmt[i] + y[i]) * dt + jm[i];
-    } else if (METHOD == VGPA_ODE_HEUN) {
-      double acc1[DD], pl[D];
-      rhs_bwd<D>(At, pk, gst, r);
-      matvec<D>(At, lk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { pl[i] = -gmt[i] + y[i]; xv[i] = lk[i] - pl[i] * dt; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = pk[e] - r[e] * dt; }
-      rhs_bwd<D>(Am, X, gsm, r);
-      matvec<D>(Am, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) pk[e] = pk[e] - h * (acc1[e] + r[e]) + js[e];
-#pragma unroll
-      for (int i = 0; i < D; i++) lk[i] = lk[i] - h * (pl[i] + (-gmm[i] + y[i])) + jm[i];
-    } else if (METHOD == VGPA_ODE_RK2) {
-      double pl[D], AM[DD], gmid[DD];
-      rhs_bwd<D>(At, pk, gst, r);
-      matvec<D>(At, lk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { pl[i] = -gmt[i] + y[i]; xv[i] = lk[i] - h * pl[i]; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) X[e] = pk[e] - h * r[e];
-      mid_mat<D>(Am, At, AM);
-      mid_mat<D>(gsm, gst, gmid);
-      rhs_bwd<D>(AM, X, gmid, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) pk[e] = pk[e] - dt * r[e] + js[e];
-#pragma unroll
-      for (int i = 0; i < D; i++) lk[i] = lk[i] - dt * (-(0.5 * (gmm[i] + gmt[i])) + y[i]) + jm[i];
-    } else {  // RK4
-      double acc1[DD], acc2[DD], AM[DD], gmid[DD], k1[D], k2[D], k3[D], gvm[D];
-      rhs_bwd<D>(At, pk, gst, r);
-      matvec<D>(At, lk, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k1[i] = -gmt[i] + y[i]; xv[i] = lk[i] - h * k1[i]; gvm[i] = 0.5 * (gmm[i] + gmt[i]); }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc1[e] = r[e]; X[e] = pk[e] - h * r[e]; }
-      mid_mat<D>(Am, At, AM);
-      mid_mat<D>(gsm, gst, gmid);
-      rhs_bwd<D>(AM, X, gmid, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k2[i] = -gvm[i] + y[i]; xv[i] = lk[i] - h * k2[i]; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc2[e] = r[e]; X[e] = pk[e] - h * r[e]; }
-      rhs_bwd<D>(AM, X, gmid, r);
-      matvec<D>(AM, xv, y);
-#pragma unroll
-      for (int i = 0; i < D; i++) { k3[i] = -gvm[i] + y[i]; xv[i] = lk[i] - dt * k3[i]; }
-#pragma unroll
-      for (int e = 0; e < DD; e++) { acc2[e] = acc2[e] + r[e]; X[e] = pk[e] - dt * r[e]; }
-      rhs_bwd<D>(Am, X, gsm, r);
-      matvec<D>(Am, xv, y);
-#pragma unroll
-      for (int e = 0; e < DD; e++) pk[e] = pk[e] - dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0 + js[e];
-#pragma unroll
-      for (int i = 0; i < D; i++) lk[i] = lk[i] - dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-gmm[i] + y[i])) / 6.0 + jm[i];
-    }
+    bwd_step<METHOD, D>(At, Am, gst, gsm, gmt, gmm, js, jm, dt, pk, lk);
     st_mat<D>(psi + (size_t)(t - 1) * DD, pk);
     st_vec<D>(lam + (size_t)(t - 1) * D, lk);
 #pragma unroll
@@ -324,10 +478,161 @@ __global__ void __launch_bounds__(NTS) k_bwd_small(OdeArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// E_sde terms of one grid point in the form the recursion and the gradient assembly take them: dEsde_dS as a full D x D matrix,
+// <df/dx> as a matrix (variational.py:263-281 adds it to A_t)
+template <int MODEL, int D>
+__device__ __forceinline__ void point_terms(const LaneSweepArgs& q, const double (&Av)[D * D], const double (&bv)[D], const double (&mv)[D],
+                                            const double (&Sv)[D * D], double (&gs)[D * D], double (&gm)[D], double& e_t, double (&ef)[D],
+                                            double (&edf)[D * D]) {
+  if constexpr (MODEL == VGPA_MODEL_L63) {
+    EnergyL63 r;
+    const double isg[3] = {q.isg[0], q.isg[1], q.isg[2]};
+    energy_l63<false>(q.theta, isg, Av, bv, mv, Sv, r);
+    gs[0] = r.ds[0]; gs[1] = r.ds[1]; gs[2] = r.ds[2];
+    gs[3] = r.ds[1]; gs[4] = r.ds[3]; gs[5] = r.ds[4];
+    gs[6] = r.ds[2]; gs[7] = r.ds[4]; gs[8] = r.ds[5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { gm[i] = r.dm[i]; ef[i] = r.ef[i]; }
+    e_t = r.e_t;
+    const double vS = q.theta[0], vR = q.theta[1], vB = q.theta[2];        // <df/dx>, lorenz_63.py:323-327
+    edf[0] = -vS; edf[1] = vS; edf[2] = 0.0;
+    edf[3] = vR - mv[2]; edf[4] = -1.0; edf[5] = -mv[0];
+    edf[6] = mv[1]; edf[7] = mv[0]; edf[8] = -vB;
+  } else {
+    Energy1d r;
+    energy_1d<MODEL>(q.theta[0], q.sigma1, Av[0], bv[0], mv[0], Sv[0], r);
+    gs[0] = r.ds; gm[0] = r.dm; ef[0] = r.ef; edf[0] = r.edf; e_t = r.e_t;
+  }
+}
+
+// The fused pass (see the head of this file).  Chunk c holds grid points [hi - T + 1, hi], hi = Np - 2 - c T; step s of the chunk
+// goes from t = hi - s + 1 to t - 1 = hi - s, whose operands sit in slot T - 1 - s; gLa / gLb of t - 1 take the slots of A / b.
+template <int METHOD, int MODEL, bool GRAD, int T>
+__global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_lane(LaneSweepArgs q) {
+  constexpr int D = (MODEL == VGPA_MODEL_L63) ? 3 : 1, DD = D * D, NA = T * DD, NV = T * D;
+  __shared__ double sA[NTS * row_stride<NA>()];
+  __shared__ double sS[NTS * row_stride<NA>()];
+  __shared__ double sB[NTS * row_stride<NV>()];
+  __shared__ double sM[NTS * row_stride<NV>()];
+  const OdeArgs& a = q.o;
+  const int lane = threadIdx.x, prob0 = blockIdx.x * NTS;
+  const int nvalid = (a.batch - prob0) < NTS ? (a.batch - prob0) : NTS;
+  const bool live = lane < nvalid;
+  const int prob = prob0 + (live ? lane : nvalid - 1);
+  const int Np = a.Np;
+  const double dt = a.dt;
+  const size_t sSs = (size_t)Np * DD, sms = (size_t)Np * D, len_x = a.strideA;
+  const long limA = (long)Np * DD, limV = (long)Np * D;
+
+  double Iv[DD];
+#pragma unroll
+  for (int e = 0; e < DD; e++) Iv[e] = q.isig[e];
+
+  // grid point Np - 1: operands straight from HBM (once), Psi = 0, lam = 0
+  double At[DD], gst[DD], gmt[D], e_t, pk[DD], lk[D];
+  {
+    double bt[D], mt[D], St[DD], ef[D], edf[DD];
+    ld_mat<D>(a.A + (size_t)prob * a.strideA + (size_t)(Np - 1) * DD, At);
+    ld_vec<D>(a.b + (size_t)prob * a.strideB + (size_t)(Np - 1) * D, bt);
+    ld_vec<D>(a.m + (size_t)prob * sms + (size_t)(Np - 1) * D, mt);
+    ld_mat<D>(a.S + (size_t)prob * sSs + (size_t)(Np - 1) * DD, St);
+    point_terms<MODEL, D>(q, At, bt, mt, St, gst, gmt, e_t, ef, edf);
+#pragma unroll
+    for (int e = 0; e < DD; e++) pk[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) lk[i] = 0.0;
+    if (GRAD) {
+      double gA[DD], gB[D];
+      grad_point<D>(At, bt, mt, St, ef, edf, pk, lk, Iv, dt, gA, gB);
+      if (live) {
+        st_mat<D>(q.g + (size_t)prob * len_x + (size_t)(Np - 1) * DD, gA);
+        st_vec<D>(q.g + (size_t)prob * len_x + (size_t)Np * DD + (size_t)(Np - 1) * D, gB);
+      }
+    }
+  }
+  double esum = 0.0;
+
+  const int nchunks = (Np - 1 + T - 1) / T;
+  double pa[ChunkMap<NA>::NI], ps[ChunkMap<NA>::NI], pb[ChunkMap<NV>::NI], pm[ChunkMap<NV>::NI];
+  const double* Au = a.A + (size_t)prob0 * a.strideA;        // wave-uniform stream bases
+  const double* bu = a.b + (size_t)prob0 * a.strideB;
+  const double* Su = a.S + (size_t)prob0 * sSs;
+  const double* mu = a.m + (size_t)prob0 * sms;
+  double* gAu = q.g + (size_t)prob0 * len_x;
+  double* gBu = gAu + (size_t)Np * DD;
+  const unsigned strA = (unsigned)a.strideA, strB = (unsigned)a.strideB, strS = (unsigned)sSs, strM = (unsigned)sms;
+  {
+    const long lo = (long)(Np - 2) - T + 1;
+    chunk_request<NA>(Au, strA, nvalid, lo * DD, limA, pa);
+    chunk_request<NV>(bu, strB, nvalid, lo * D, limV, pb);
+    chunk_request<NV>(mu, strM, nvalid, lo * D, limV, pm);
+    chunk_request<NA>(Su, strS, nvalid, lo * DD, limA, ps);
+  }
+  double* rowA = sA + lane * row_stride<NA>();
+  double* rowS = sS + lane * row_stride<NA>();
+  double* rowB = sB + lane * row_stride<NV>();
+  double* rowM = sM + lane * row_stride<NV>();
+  for (int c = 0; c < nchunks; c++) {
+    const int hi = Np - 2 - c * T;
+    const long lo = (long)hi - T + 1;
+    chunk_to_lds<NA>(sA, pa);
+    chunk_to_lds<NV>(sB, pb);
+    chunk_to_lds<NV>(sM, pm);
+    chunk_to_lds<NA>(sS, ps);
+    wave_sync();
+    if (c + 1 < nchunks) {      // the next chunk travels while this one is stepped through
+      const long lon = lo - T;
+      chunk_request<NA>(Au, strA, nvalid, lon * DD, limA, pa);
+      chunk_request<NV>(bu, strB, nvalid, lon * D, limV, pb);
+      chunk_request<NV>(mu, strM, nvalid, lon * D, limV, pm);
+      chunk_request<NA>(Su, strS, nvalid, lon * DD, limA, ps);
+    }
+#pragma unroll
+    for (int s = 0; s < T; s++) {
+      const int idx = hi - s;               // grid point t - 1 of this step
+      if (idx >= 0) {
+        const int slot = T - 1 - s;
+        double Am[DD], bm[D], mm[D], Sm[DD], gsm[DD], gmm[D], e_m, ef[D], edf[DD];
+#pragma unroll
+        for (int e = 0; e < DD; e++) { Am[e] = rowA[slot * DD + e]; Sm[e] = rowS[slot * DD + e]; }
+#pragma unroll
+        for (int i = 0; i < D; i++) { bm[i] = rowB[slot * D + i]; mm[i] = rowM[slot * D + i]; }
+        point_terms<MODEL, D>(q, Am, bm, mm, Sm, gsm, gmm, e_m, ef, edf);
+        esum += dt * (e_t + e_m) / 2.0;     // my_trapz, utilities.py:144 (interval [t-1, t])
+        e_t = e_m;
+        if (GRAD) {
+          double js[DD], jm[D];
+          load_jump<D>(a, prob, idx, js, jm);
+          bwd_step<METHOD, D>(At, Am, gst, gsm, gmt, gmm, js, jm, dt, pk, lk);
+          double gA[DD], gB[D];
+          grad_point<D>(Am, bm, mm, Sm, ef, edf, pk, lk, Iv, dt, gA, gB);
+#pragma unroll
+          for (int e = 0; e < DD; e++) { rowA[slot * DD + e] = gA[e]; At[e] = Am[e]; gst[e] = gsm[e]; }
+#pragma unroll
+          for (int i = 0; i < D; i++) { rowB[slot * D + i] = gB[i]; gmt[i] = gmm[i]; }
+        }
+      }
+    }
+    if (GRAD) {
+      wave_sync();
+      chunk_flush<NA>(sA, gAu, (unsigned)len_x, nvalid, lo * DD, limA);
+      chunk_flush<NV>(sB, gBu, (unsigned)len_x, nvalid, lo * D, limV);
+    }
+    wave_sync();
+  }
+  if (live) {
+    const double esde = q.pre * esum / q.div;
+    q.esde[prob] = esde;
+    q.f[prob] = q.e0 + esde + q.eobs[prob];
+  }
+}
+
 template <int METHOD, bool FWD, int D>
 hipError_t launch_d(const OdeArgs& a, hipStream_t st) {
   dim3 grid((a.batch + NTS - 1) / NTS), block(NTS);
-  if (FWD) hipLaunchKernelGGL((k_fwd_small<METHOD, D>), grid, block, 0, st, a);
+  constexpr int T = (D == 1) ? 16 : (D == 2 ? 8 : 4);      // grid points per chunk: 16 ... 64 doubles of the matrix stream per problem
+  if (FWD) hipLaunchKernelGGL((k_fwd_lane<METHOD, D, T>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_bwd_small<METHOD, D>), grid, block, 0, st, a);
   return hipGetLastError();
 }
@@ -343,6 +648,25 @@ hipError_t launch_m(const OdeArgs& a, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
+template <int METHOD, int MODEL>
+hipError_t launch_sweep_mm(const LaneSweepArgs& q, hipStream_t st) {
+  dim3 grid((q.o.batch + NTS - 1) / NTS), block(NTS);
+  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 2 : 16;
+  if (q.want_grad) hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, T>), grid, block, 0, st, q);
+  else hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, false, T>), grid, block, 0, st, q);
+  return hipGetLastError();
+}
+
+template <int METHOD>
+hipError_t launch_sweep_m(const LaneSweepArgs& q, hipStream_t st) {
+  switch (q.model) {
+    case VGPA_MODEL_OU: return launch_sweep_mm<METHOD, VGPA_MODEL_OU>(q, st);
+    case VGPA_MODEL_DW: return launch_sweep_mm<METHOD, VGPA_MODEL_DW>(q, st);
+    case VGPA_MODEL_L63: return launch_sweep_mm<METHOD, VGPA_MODEL_L63>(q, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 }  // namespace
 
 hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t st) {
@@ -352,6 +676,21 @@ hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t 
     case VGPA_ODE_HEUN: return fwd ? launch_m<VGPA_ODE_HEUN, true>(a, st) : launch_m<VGPA_ODE_HEUN, false>(a, st);
     case VGPA_ODE_RK2: return fwd ? launch_m<VGPA_ODE_RK2, true>(a, st) : launch_m<VGPA_ODE_RK2, false>(a, st);
     case VGPA_ODE_RK4: return fwd ? launch_m<VGPA_ODE_RK4, true>(a, st) : launch_m<VGPA_ODE_RK4, false>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+bool sweep_lane_supported(int model, int D) {
+  return (model == VGPA_MODEL_L63 && D == 3) || ((model == VGPA_MODEL_OU || model == VGPA_MODEL_DW) && D == 1);
+}
+
+hipError_t launch_sweep_lane(int method, const LaneSweepArgs& q, hipStream_t st) {
+  if (!sweep_lane_supported(q.model, q.o.D) || q.o.js_dense || q.o.Np < 2) return hipErrorInvalidValue;
+  switch (method) {
+    case VGPA_ODE_EULER: return launch_sweep_m<VGPA_ODE_EULER>(q, st);
+    case VGPA_ODE_HEUN: return launch_sweep_m<VGPA_ODE_HEUN>(q, st);
+    case VGPA_ODE_RK2: return launch_sweep_m<VGPA_ODE_RK2>(q, st);
+    case VGPA_ODE_RK4: return launch_sweep_m<VGPA_ODE_RK4>(q, st);
   }
   return hipErrorInvalidValue;
 }

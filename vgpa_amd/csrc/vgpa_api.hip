@@ -62,6 +62,7 @@ struct vgpa_ctx {
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
   bool have_state = false;
+  bool derived_valid = true;     // dEsde_dm / dEsde_dS / <f> / E_sde(t) / lam / Psi belong to the cached (m, S): false behind a fused lane pass
   bool sym_units = false;        // stepping-kernel family of this context (pick_kernel_family)
   // profiling
   bool prof = false;
@@ -176,11 +177,17 @@ static void prof_collect(vgpa_ctx* c) {
 // workgroup has the shorter latency: Lorenz-63 RK4 Np = 1001 forward 1.2 ms vs 1.6 ms; at 65536 problems 108 ms vs
 // 6 ms).  VGPA_FLAG_FORCE_GENERIC keeps the workgroup-per-problem kernels.
 static bool use_lane(vgpa_ctx* c) {
-  return c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && (c->D == 1 || c->B >= 512);
+  // (the lane kernels address a wave's 64 problems with 32-bit byte offsets from a wave-uniform base)
+  return c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && (c->D == 1 || c->B >= 512) && c->len_x < ((size_t)1 << 22);
+}
+// the fused lane pass (ode_small.hip::k_sweep_lane): forward kernel -> observations -> ONE kernel for the E_sde terms, the backward
+// recursion, the gradient and F
+static bool lane_fused(vgpa_ctx* c) {
+  return use_lane(c) && c->full && sweep_lane_supported(c->cfg.model, c->D) && !(c->cfg.flags & VGPA_FLAG_MATERIALIZE);
 }
 // D = 2..4 below that: 16 lanes per problem, operands exchanged by ds_bpermute (ode_wave.hip)
 static bool use_wave(vgpa_ctx* c) {
-  return c->D >= 2 && c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && c->B < 512;
+  return c->D >= 2 && c->D <= kMaxLaneD && !(c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) && !use_lane(c);
 }
 
 // D <= 44 has two families of matrix-core stepping kernels: the symmetric-unit ones (two problems per CU, 4 waves each) win
@@ -488,10 +495,60 @@ static int diag_repeat(const char* phase) {
   return n > 1 ? n : 1;
 }
 
+// the fused lane pass over the cached (m, S): F (want_grad = false) or F and the gradient
+static int run_lane_pass(vgpa_ctx* c, double* g_dev) {
+  LaneSweepArgs q{};
+  OdeArgs& a = q.o;
+  a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+  a.strideA = a.strideB = c->len_x;
+  a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
+  a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M;
+  q.model = c->cfg.model; q.want_grad = g_dev ? 1 : 0;
+  for (int i = 0; i < kMaxTheta; i++) q.theta[i] = c->theta[i];
+  q.sigma1 = c->sigma1;
+  for (int i = 0; i < c->D; i++) q.isg[i] = c->h_isig[(size_t)i * c->D + i];
+  for (size_t e = 0; e < c->DD; e++) q.isig[e] = c->h_isig[e];
+  q.e0 = c->cfg.e0; q.pre = c->single ? 0.5 : 1.0; q.div = c->single ? c->sigma1 : 1.0;
+  q.eobs = c->d_eobs; q.esde = c->d_esde; q.f = c->d_f; q.g = g_dev;
+  hipError_t e = launch_sweep_lane(c->cfg.method, q, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "fused lane pass launch failed: %s", hipGetErrorString(e));
+  return VGPA_OK;
+}
+
+// forward moments -> observation terms -> fused lane pass (F, and the gradient when g_dev is given)
+static int enqueue_lane_sweep(vgpa_ctx* c, double* g_dev) {
+  int rc;
+  prof_collect(c);
+  HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  prof_mark(c, 0);
+  if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
+  prof_mark(c, 1);
+  hipError_t e = launch_obs(obs_args(c), c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
+  prof_mark(c, 2);
+  if ((rc = run_lane_pass(c, g_dev))) return rc;
+  prof_mark(c, 3);
+  c->have_state = true;
+  c->derived_valid = false;
+  if (g_dev && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+  return VGPA_OK;
+}
+
+// what vgpa_fetch wants of the arrays the fused lane pass never wrote: the separate kernels over the cached (m, S)
+static int materialize_derived(vgpa_ctx* c) {
+  if (c->derived_valid) return VGPA_OK;
+  int rc;
+  if ((rc = run_energy(c, nullptr, false))) return rc;
+  if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
+  c->derived_valid = true;
+  return VGPA_OK;
+}
+
 // fwd -> E_obs -> E_sde terms -> bwd -> F     (VarGP.free_energy, variational.py:141-200)
 static int enqueue_free_energy(vgpa_ctx* c) {
   if (c->stream_ld) return enqueue_stream_sweep(c, nullptr);
   if (!c->full) return fail(c, VGPA_ERR_STATE, "context was created without m0/s0/observations (ODE-only)");
+  if (lane_fused(c)) return enqueue_lane_sweep(c, nullptr);
   int rc;
   prof_collect(c);
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
@@ -512,6 +569,7 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   prof_mark(c, 3);
   if ((rc = run_reduce(c))) return rc;
   c->have_state = true;
+  c->derived_valid = true;
   return VGPA_OK;
 }
 
@@ -936,6 +994,7 @@ static int finish_gradient(vgpa_ctx* c, double* g_dev);
 // F and the gradient in one go (df(x, eval_fun=True)): the streamed context folds both into one chunked pass
 static int enqueue_sweep(vgpa_ctx* c, double* g_dev) {
   if (c->stream_ld) return enqueue_stream_sweep(c, g_dev);
+  if (c->full && lane_fused(c)) return enqueue_lane_sweep(c, g_dev);
   int rc = enqueue_free_energy(c);
   return rc ? rc : finish_gradient(c, g_dev);
 }
@@ -943,6 +1002,11 @@ static int enqueue_sweep(vgpa_ctx* c, double* g_dev) {
 static int finish_gradient(vgpa_ctx* c, double* g_dev) {
   if (c->stream_ld) {            // cached state = (m, S): the chunked pass recomputes the energy terms on its way back
     int rc = stream_pass(c, g_dev);
+    if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+    return rc;
+  }
+  if (lane_fused(c) && !c->derived_valid) {      // gradient(x, eval_fun=False) behind a fused F: the pass again, now with the recursion
+    int rc = run_lane_pass(c, g_dev);
     if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
     return rc;
   }
@@ -1011,6 +1075,7 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t BN = (size_t)c->B * c->Np;
   int rc = VGPA_OK;
+  if (which != VGPA_FETCH_MT && which != VGPA_FETCH_ST && which != VGPA_FETCH_EDF && (rc = materialize_derived(c))) return rc;
   switch (which) {
     case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;
     case VGPA_FETCH_ST: rc = download(c, out, c->d_S, BN * c->DD); break;

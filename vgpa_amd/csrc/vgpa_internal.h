@@ -55,6 +55,23 @@ struct OdeArgs {
   double q_scale;
 };
 
+// Fused lane-per-problem pass of the models with closed-form moments (OU, double well, Lorenz-63; ode_small.hip::k_sweep_lane):
+// E_sde terms of every grid point re-evaluated in registers, backward recursion, gradient assembly, F -- from (A, b, m, S) alone.
+struct LaneSweepArgs {
+  OdeArgs o;               // A, b (x layout), m, S, dt, batch, Np, D, sparse jumps (obs_idx, jm_sparse, js_const, n_obs)
+  int model;
+  int want_grad;           // 0: F only (no recursion); 1: F and the gradient
+  double theta[kMaxTheta];
+  double sigma1;           // 1-D models: sigma
+  double isg[4];           // diagonal of Sigma^-1
+  double isig[16];         // Sigma^-1 [D][D]
+  double e0, pre, div;     // F = e0 + pre * trapz(E_sde(t)) / div + E_obs
+  const double* eobs;      // [B]
+  double* esde;            // [B]
+  double* f;               // [B]
+  double* g;               // [B][Np*D*D + Np*D] (want_grad)
+};
+
 struct EnergyArgs {
   int model, D, Np, batch;
   double dt;
@@ -123,6 +140,8 @@ struct ReduceArgs {
 // launchers (each returns hipGetLastError()) -----------------------------------------------------
 hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t st);     // D <= kMaxLaneD
+bool sweep_lane_supported(int model, int D);
+hipError_t launch_sweep_lane(int method, const LaneSweepArgs& a, hipStream_t st);
 hipError_t launch_ode_wave(int method, bool fwd, const OdeArgs& a, hipStream_t st);      // 2 <= D <= kMaxLaneD, few problems
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
