@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--config5-dim", type=int, default=4096)
     ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
+    ap.add_argument("--no-config2", action="store_true", help="skip the secondary Lorenz-63 block (BASELINE configs[1], the HBM-bound small-D path)")
+    ap.add_argument("--config2-batch", type=int, default=49152, help="independent Lorenz-63 problems of the config-2 block: 768 waves of 64 -- "
+                    "three per CU, what the fused lane pass's 49 KB of LDS per wave admits (any multiple fills the chip evenly)")
     return ap.parse_args()
 
 
@@ -128,6 +131,80 @@ def cpu_baseline(p, x, method, d, n_pts, dt):
                       f"per-step operations as the reference), one core; many_cores: one such sweep on each of cores_used cores",
             "seconds": t_faith, "lean_value": 1.0 / t_lean, "lean_seconds": t_lean, "host_cores": os.cpu_count(),
             "many_cores": all_cores, "F_cpu": f_cpu}
+
+
+def config2_block(args, local_rank):
+    """BASELINE configs[1]: Lorenz-63, D = 3, RK4, Np = 1001, the reference's seeded inputs -- the small-D path, which IS bound by
+    HBM.  A batch of independent problems on the lane-per-problem kernels: forward moments (k_fwd_lane), observation
+    terms (k_obs), ONE fused backward pass (k_sweep_lane: closed-form E_sde terms in registers, (lam, Psi) recursion, gradient, F).
+    Roofline on SURVEY 8(d)'s algorithmic bytes 8 Np (5 D^2 + 6 D) per sweep against 8 TB/s; problem 0 must reproduce the
+    reference's anchor; the numpy oracle is timed beside it (one sweep, one core).  Never raises."""
+    try:
+        import vgpa_amd as va
+        from helpers import build_problem
+        from oracle import vgpa_oracle as vo
+        d, n_pts, dt, B = 3, 1001, 0.01, args.config2_batch
+        p = build_problem("L63", "RK4", (n_pts - 1) * dt, dt, None)
+        x0 = p["vgp"].initialization()
+        len_x = x0.size
+        e0 = float(p["kl0"](p["m0"], p["s0"]))
+        x_first = x0 + 0.05 * np.random.default_rng(0).standard_normal(len_x)          # problem 0: the reference's perturbed anchor input
+        # CPU oracle beside it (the same sweep, one core)
+        z = dict(model="L63", method="RK4", dt=dt, theta=np.asarray(p["model"].theta), sigma=p["model"].sigma, m0=p["m0"], s0=p["s0"],
+                 mu0=p["mu0"], tau0=p["tau0"], obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], time_window=p["model"].time_window)
+        prob = vo.Problem.from_fixture({k: np.asarray(val) for k, val in z.items()})
+        t0 = time.perf_counter()
+        f_cpu, _, _ = vo.sweep(prob, x_first, faithful=False)
+        t_cpu = time.perf_counter() - t0
+        ctx = va.Context("L63", "RK4", d, n_pts, dt, sigma=p["model"].sigma, theta=p["model"].theta, m0=p["m0"], s0=p["s0"],
+                         obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=B, device=local_rank)
+        x_dev, g_dev = ctx.alloc(B * len_x), ctx.alloc(B * len_x)
+        noise = 0.05 * np.random.default_rng(1).standard_normal((61, len_x))           # 61 further inputs, repeated over the batch
+        rows = np.vstack([x_first[None, :], x0[None, :] + noise])
+        piece = 62 * 64
+        tile = np.tile(rows, (64, 1))
+        for i0 in range(0, B, piece):
+            k = min(piece, B - i0)
+            x_dev.upload_at(i0 * len_x, tile[:k])
+        for _ in range(2):
+            ctx.sweep_enqueue(x_dev, g_dev)
+            ctx.fetch_f()
+        steps = 10
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.sweep_enqueue(x_dev, g_dev)
+            f = ctx.fetch_f()
+        secs = (time.perf_counter() - t0) / steps
+        pr = ctx.profile_end()
+        anchors = json.load(open(os.path.join(ROOT, "tests", "golden", "anchors.json")))["l63_rk4_full_p"]
+        g0 = g_dev.download_at(0, len_x)
+        err_f = abs(f[0] - anchors["F"]) / abs(anchors["F"])
+        err_g = abs(float(np.linalg.norm(g0)) - anchors["grad_norm"]) / anchors["grad_norm"]
+        ctx.close()
+        alg = 8.0 * n_pts * (5 * d * d + 6 * d)
+        fwd_s, bwd_s = pr["fwd_ms"] / steps * 1e-3, pr["bwd_ms"] / steps * 1e-3
+        tj = {}
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+        gbs = alg * B / secs / 1e9
+        return {"workload": f"Lorenz63 D=3, RK4, Np={n_pts} (BASELINE configs[1]), {B} independent problems, one lane per problem",
+                "sweeps_per_s": B / secs, "ms_per_step": 1e3 * secs, "batch": B,
+                "phase_ms_per_step": {"fwd (k_fwd_lane)": 1e3 * fwd_s, "obs (k_obs)": pr["energy_ms"] / steps,
+                                      "fused E_sde + bwd + grad + F (k_sweep_lane)": 1e3 * bwd_s},
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "alg_bytes_per_sweep": alg, "alg_bytes_per_step": alg * B,
+                             "traffic": tj.get(f"config2_sweep_B{B}"),
+                             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_small.sh; not measured in this run)",
+                             "kernels": {"k_fwd_lane": {"launch_ms": 1e3 * fwd_s, "alg_GBs": 8.0 * n_pts * (2 * d * d + 2 * d) * B / fwd_s / 1e9},
+                                         "k_sweep_lane": {"launch_ms": 1e3 * bwd_s, "alg_GBs": 8.0 * n_pts * (3 * d * d + 4 * d) * B / bwd_s / 1e9}}},
+                "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "sweeps/s", "cores": 1, "kind": "port", "seconds": t_cpu,
+                                 "sample": "one full sweep of problem 0, numpy oracle", "gpu_vs_cpu_F_rel_err": abs(f[0] - f_cpu) / abs(f_cpu)},
+                "parity_check_rel_err_F": err_f, "parity_check_rel_err_grad_norm": err_g,
+                "parity_ok": bool(max(err_f, err_g) < 1e-9)}
+    except Exception as exc:                                 # noqa: BLE001 - the headline line must still be printed
+        return {"error": repr(exc)}
 
 
 def config5_block(args, rank, world, local_rank, rehearse):
@@ -439,12 +516,21 @@ def main():
                   "bwd_ms": pr1["bwd_ms"] / reps, "grad_ms": pr1["grad_ms"] / reps}
         c1.close()
 
+    # ---- secondary block: BASELINE configs[1] (Lorenz-63), the HBM-bound small-D path; rank 0 only, outside the timed region
+    c2 = None
+    if rank == 0 and not args.no_config2 and not args.generic:
+        ctx.close()
+        del x_dev, g_dev
+        ctx = None
+        c2 = config2_block(args, local_rank)
+
     # ---- secondary block: BASELINE configs[4]'s matrix size through the row-sharded driver (every rank takes part)
     # (one rank: in this process, behind the headline measurement; N > 1: already measured, in child processes -- see above)
     c5 = c5_early
     if not args.no_config5 and not args.generic and not c5_in_children:
-        ctx.close()
-        del x_dev, g_dev
+        if ctx is not None:
+            ctx.close()
+            del x_dev, g_dev
         c5 = config5_block(args, rank, world, local_rank, rehearse)
 
     if rank != 0:
@@ -560,6 +646,8 @@ def main():
         "parity_check_rel_err_F": check,
         "parity_check_rel_err_grad_norm": check_g,
     }
+    if c2 is not None:
+        out["config2"] = c2
     if c5 is not None:
         out["config5"] = c5
 

@@ -286,3 +286,39 @@ def test_scg_optimisation_trace_matches_oracle_objective():
     assert f_gpu < v.free_energy(x0)
     assert abs(f_gpu - f_cpu_val) <= 1e-7 * abs(f_cpu_val)
     assert rel_err(x_gpu, x_cpu) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pert", [0.0, 0.05])
+def test_full_size_anchors_on_the_lane_kernels(pert):
+    """BASELINE configs[1] (Lorenz-63, RK4, Np = 1001) on the kernels bench.py's config-2 block runs -- one lane per problem,
+    chunked LDS staging, the fused backward pass -- against the REFERENCE's anchors: a batch of 600 problems whose first, 64th and
+    last members are the anchor input (the rest perturbed), F / gradient / energy parts from the fused pass, the state norms through
+    vgpa_fetch (which materialises lam_t / Psi_t with the separate kernels)."""
+    import vgpa_amd as va
+    anchors = json.load(open(os.path.join(GOLDEN_DIR, "anchors.json")))
+    a = anchors["l63_rk4_full" + ("_p" if pert else "")]
+    p = build_problem("L63", "RK4", a["tf"], a["dt"], None)
+    x = p["vgp"].initialization()
+    if pert:
+        x = x + pert * np.random.default_rng(0).standard_normal(x.size)
+    nb = 600
+    xb = x[None, :] + 0.01 * np.random.default_rng(3).standard_normal((nb, x.size))
+    where = (0, 64, nb - 1)
+    for i in where:
+        xb[i] = x
+    e0 = float(p["kl0"](p["m0"], p["s0"]))
+    ctx = va.Context("L63", "RK4", 3, a["Np"], a["dt"], sigma=p["model"].sigma, theta=p["model"].theta, m0=p["m0"], s0=p["s0"],
+                     obs_t=p["obs_t"], obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=nb)
+    f, g = ctx.sweep(xb)
+    _, esde, eobs = ctx.energy_parts()
+    st, psit, mt = ctx.fetch("st"), ctx.fetch("psit"), ctx.fetch("mt")
+    for i in where:
+        assert abs(f[i] - a["F"]) <= TOL * abs(a["F"])
+        assert abs(np.linalg.norm(g[i]) - a["grad_norm"]) <= TOL * a["grad_norm"]
+        assert abs(np.abs(g[i]).max() - a["grad_absmax"]) <= TOL * a["grad_absmax"]
+        assert abs(esde[i] - a["Esde"]) <= TOL * abs(a["Esde"]) and abs(eobs[i] - a["Eobs"]) <= TOL * abs(a["Eobs"])
+        assert abs(np.linalg.norm(st[i].ravel()) - a["st_fro"]) <= TOL * a["st_fro"]
+        assert abs(np.linalg.norm(psit[i].ravel()) - a["psi_fro"]) <= TOL * a["psi_fro"]
+        assert rel_err(mt[i][-1], a["mt_last"]) < TOL
+    ctx.close()

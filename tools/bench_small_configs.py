@@ -48,8 +48,15 @@ def run(model, method, batch, reps=20, flags=0):
 
 
 if __name__ == "__main__":
+    # usage: bench_small_configs.py [batch,batch,...] [MODEL] [reps] [fused-only]
     from vgpa_amd._lib import FLAG_MATERIALIZE
     batches = [int(b) for b in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 65536]
+    if len(sys.argv) > 2:          # one model, the fused path only: what a counter pass wants
+        m = sys.argv[2].upper()
+        reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+        for batch in batches:
+            print(json.dumps(run(m, "Euler" if m == "OU" else "RK4", batch, reps=reps)), flush=True)
+        sys.exit(0)
     for model, method in (("OU", "Euler"), ("L63", "RK4")):
         for batch in batches:
             for flags in ((0, FLAG_MATERIALIZE) if batch >= 512 or model == "OU" else (0,)):

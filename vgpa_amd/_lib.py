@@ -208,6 +208,20 @@ class DeviceBuffer:
         assert host.size == self.count
         self.ctx._check(self.ctx._lib.vgpa_memcpy_h2d(self.ctx._h, self.ptr, _ptr(host), host.size * 8))
 
+    def upload_at(self, offset, host):
+        """host -> this buffer from double `offset` on (large batches go up in pieces instead of through one host array)."""
+        host = _c64(host).ravel()
+        assert 0 <= offset and offset + host.size <= self.count
+        dst = c_void_p(self.ptr.value + 8 * int(offset))
+        self.ctx._check(self.ctx._lib.vgpa_memcpy_h2d(self.ctx._h, dst, _ptr(host), host.size * 8))
+
+    def download_at(self, offset, count):
+        out = np.empty(int(count))
+        assert 0 <= offset and offset + out.size <= self.count
+        src = c_void_p(self.ptr.value + 8 * int(offset))
+        self.ctx._check(self.ctx._lib.vgpa_memcpy_d2h(self.ctx._h, _ptr(out), src, out.size * 8))
+        return out
+
     def download(self):
         out = np.empty(self.count)
         self.ctx._check(self.ctx._lib.vgpa_memcpy_d2h(self.ctx._h, _ptr(out), self.ptr, out.size * 8))

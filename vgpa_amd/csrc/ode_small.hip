@@ -22,6 +22,8 @@
 // Lorenz-63: BASELINE configs[0] / [1]): a lane re-evaluates the energy terms of grid point t-1 from (A, b, m, S) in registers
 // (energy_small.h), steps (lam, Psi), assembles gLa / gLb of t-1 and carries the trapezoid of E_sde -- dEsde_dm, dEsde_dS,
 // <f>, E_sde(t), lam_t, Psi_t never touch HBM (vgpa_fetch materialises them on demand through the separate kernels).
+#include <cstdlib>
+
 #include "vgpa_internal.h"
 #include "energy_small.h"
 
@@ -114,24 +116,28 @@ __device__ __forceinline__ void wave_sync() {
 template <int N>
 constexpr int row_stride() { return N | 1; }      // odd: a lane's row reads are spread over the banks
 
-// How the 64 lanes of an instruction cover the chunk: G consecutive doubles of each of PG = 64 / G problems; a problem's N
-// doubles take R = ceil(N / G) instructions, the 64 problems NG = ceil(64 / PG) groups.  Affine in the lane -- lane l always
+// How the 64 lanes of an instruction cover the chunk: G consecutive doubles (G divides N) of each of 64 / G problems (rounded UP:
+// the last lanes start the next group's first problem -- the same data the next group's instruction moves again, a benign
+// duplicate); a problem's N doubles take R = N / G instructions, the 64 problems NG groups.  Affine in the lane -- lane l always
 // works on (problem l / G, double l % G) of its instruction's block -- so that addresses are one per-lane offset plus uniform
-// terms, not one precomputed address pair per instruction (which is what the register allocator makes of a flat index).
+// terms (not one precomputed address pair per instruction, which is what the register allocator makes of a flat index), and no
+// access needs a predicate: out-of-range problems / grid points are CLAMPED to valid ones, whose data they duplicate.
 template <int N>
 struct ChunkMap {
-  static constexpr int cost(int g) { return ((NTS + NTS / g - 1) / (NTS / g)) * ((N + g - 1) / g); }
+  static constexpr int cost(int g) { return (N % g) ? (1 << 20) : ((NTS + NTS / g - 1) / (NTS / g)) * (N / g); }
   static constexpr int pick() {
-    int best = 16;
-    for (int g = 16; g >= 4; g--)
-      if (cost(g) < cost(best)) best = g;
+    int best = 1;
+    for (int g = 2; g <= 16; g++)
+      if (cost(g) <= cost(best)) best = g;
     return best;
   }
   static constexpr int G = pick();
-  static constexpr int R = (N + G - 1) / G;
-  static constexpr int PG = NTS / G;
+  static constexpr int R = N / G;
+  static constexpr int PG = NTS / G;                       // whole problems per instruction
   static constexpr int NG = (NTS + PG - 1) / PG;
-  static constexpr int NI = NG * R;               // instructions per chunk = doubles a lane holds between request and LDS
+  static constexpr int NI = NG * R;                        // instructions per chunk = doubles a lane holds between request and LDS
+  static constexpr int ROWS = (NG - 1) * PG + (NTS - 1) / G + 1;   // LDS rows incl. the scratch rows behind problem 63
+  static constexpr int LDS = ROWS * (N | 1);
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -144,9 +150,8 @@ __device__ __forceinline__ void chunk_request(const double* __restrict__ base_u,
                                               double (&v)[ChunkMap<N>::NI]) {
   using M = ChunkMap<N>;
   const unsigned lane = threadIdx.x;
-  const bool act = lane < (unsigned)(M::PG * M::G);
-  const int pl = act ? (int)(lane / M::G) : 0, el = act ? (int)(lane % M::G) : 0;
-  const double* bu = base_u + first;                      // uniform; only ever dereferenced at clamped offsets
+  const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
+  const char* bu = reinterpret_cast<const char*>(base_u + first);      // wave-uniform; only ever dereferenced at clamped offsets
   const int lo = (int)(-first), hi = (int)(limit - 1 - first);
 #pragma unroll
   for (int jg = 0; jg < M::NG; jg++)
@@ -155,7 +160,7 @@ __device__ __forceinline__ void chunk_request(const double* __restrict__ base_u,
       int p = jg * M::PG + pl;
       p = p < nvalid ? p : nvalid - 1;
       const int e = clampi(r * M::G + el, lo, hi);
-      v[jg * M::R + r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(bu) + ((unsigned)p * pstride + (unsigned)e) * 8u);
+      v[jg * M::R + r] = *reinterpret_cast<const double*>(bu + ((unsigned)p * pstride + (unsigned)e) * 8u);
     }
 }
 
@@ -163,39 +168,42 @@ template <int N>
 __device__ __forceinline__ void chunk_to_lds(double* __restrict__ lds, const double (&v)[ChunkMap<N>::NI]) {
   using M = ChunkMap<N>;
   const unsigned lane = threadIdx.x;
-  const bool act = lane < (unsigned)(M::PG * M::G);
-  const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
-  double* mine = lds + pl * row_stride<N>() + el;
+  double* mine = lds + (int)(lane / M::G) * row_stride<N>() + (int)(lane % M::G);
 #pragma unroll
   for (int jg = 0; jg < M::NG; jg++)
 #pragma unroll
-    for (int r = 0; r < M::R; r++) {
-      const bool ok = act && (r * M::G + el < N) && (jg * M::PG + pl < NTS);
-      if (ok) mine[jg * M::PG * row_stride<N>() + r * M::G] = v[jg * M::R + r];
-    }
+    for (int r = 0; r < M::R; r++) mine[jg * M::PG * row_stride<N>() + r * M::G] = v[jg * M::R + r];
 }
 
+// results leave the way the operands came; lanes whose (problem, grid point) is out of range store a valid neighbour's value to
+// that neighbour's address a second time
 template <int N>
 __device__ __forceinline__ void chunk_flush(const double* __restrict__ lds, double* __restrict__ base_u, unsigned pstride, int nvalid,
                                             long first, long limit) {
   using M = ChunkMap<N>;
   const unsigned lane = threadIdx.x;
-  const bool act = lane < (unsigned)(M::PG * M::G);
   const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
-  const double* mine = lds + pl * row_stride<N>() + el;
-  double* bu = base_u + first;
+  char* bu = reinterpret_cast<char*>(base_u + first);
   const int lo = (int)(-first), hi = (int)(limit - 1 - first);
 #pragma unroll
   for (int jg = 0; jg < M::NG; jg++)
 #pragma unroll
     for (int r = 0; r < M::R; r++) {
-      const int p = jg * M::PG + pl, e = r * M::G + el;
-      const bool ok = act && e < N && p < nvalid && e >= lo && e <= hi;
-      if (ok) {
-        const double val = mine[jg * M::PG * row_stride<N>() + r * M::G];
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(bu) + ((unsigned)p * pstride + (unsigned)e) * 8u) = val;
-      }
+      int p = jg * M::PG + pl;
+      p = p < nvalid ? p : nvalid - 1;
+      const int e = clampi(r * M::G + el, lo, hi);
+      const double val = lds[p * row_stride<N>() + e];
+      *reinterpret_cast<double*>(bu + ((unsigned)p * pstride + (unsigned)e) * 8u) = val;
     }
+}
+
+// x / 6 without the division sequence: q = x * RN(1/6), one exact residual, one correction (Markstein): the correctly rounded
+// quotient for every x in the normal range (RK4's dt (k1 + 2 k2 + 2 k3 + k4) / 6.0: runge_kutta4.py:107-108, 205-206)
+__device__ __forceinline__ double div6(double x) {
+  const double y = 1.0 / 6.0;
+  const double q = x * y;
+  const double r = __builtin_fma(-6.0, q, x);
+  return __builtin_fma(r, y, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -267,9 +275,9 @@ __device__ __forceinline__ void fwd_step(const double (&A0)[D * D], const double
     rhs_fwd<D>(A1, X, sig, r);
     matvec<D>(A1, xv, y);
 #pragma unroll
-    for (int e = 0; e < DD; e++) sk[e] = sk[e] + dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0;
+    for (int e = 0; e < DD; e++) sk[e] = sk[e] + div6(dt * (acc1[e] + 2.0 * acc2[e] + r[e]));
 #pragma unroll
-    for (int i = 0; i < D; i++) mk[i] = mk[i] + dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-y[i] + b1[i])) / 6.0;
+    for (int i = 0; i < D; i++) mk[i] = mk[i] + div6(dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-y[i] + b1[i])));
   }
 }
 
@@ -278,8 +286,8 @@ __device__ __forceinline__ void fwd_step(const double (&A0)[D * D], const double
 template <int METHOD, int D, int T>
 __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_fwd_lane(OdeArgs a) {
   constexpr int DD = D * D, NA = T * DD, NB = T * D;
-  __shared__ double sA[NTS * row_stride<NA>()];
-  __shared__ double sB[NTS * row_stride<NB>()];
+  __shared__ double sA[ChunkMap<NA>::LDS];
+  __shared__ double sB[ChunkMap<NB>::LDS];
   const int lane = threadIdx.x, prob0 = blockIdx.x * NTS;
   const int nvalid = (a.batch - prob0) < NTS ? (a.batch - prob0) : NTS;
   const bool live = lane < nvalid;
@@ -428,9 +436,9 @@ __device__ __forceinline__ void bwd_step(const double (&At)[D * D], const double
     rhs_bwd<D>(Am, X, gsm, r);
     matvec<D>(Am, xv, y);
 #pragma unroll
-    for (int e = 0; e < DD; e++) pk[e] = pk[e] - dt * (acc1[e] + 2.0 * acc2[e] + r[e]) / 6.0 + js[e];
+    for (int e = 0; e < DD; e++) pk[e] = pk[e] - div6(dt * (acc1[e] + 2.0 * acc2[e] + r[e])) + js[e];
 #pragma unroll
-    for (int i = 0; i < D; i++) lk[i] = lk[i] - dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-gmm[i] + y[i])) / 6.0 + jm[i];
+    for (int i = 0; i < D; i++) lk[i] = lk[i] - div6(dt * (k1[i] + 2.0 * (k2[i] + k3[i]) + (-gmm[i] + y[i]))) + jm[i];
   }
 }
 
@@ -511,10 +519,10 @@ __device__ __forceinline__ void point_terms(const LaneSweepArgs& q, const double
 template <int METHOD, int MODEL, bool GRAD, int T>
 __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_lane(LaneSweepArgs q) {
   constexpr int D = (MODEL == VGPA_MODEL_L63) ? 3 : 1, DD = D * D, NA = T * DD, NV = T * D;
-  __shared__ double sA[NTS * row_stride<NA>()];
-  __shared__ double sS[NTS * row_stride<NA>()];
-  __shared__ double sB[NTS * row_stride<NV>()];
-  __shared__ double sM[NTS * row_stride<NV>()];
+  __shared__ double sA[ChunkMap<NA>::LDS];
+  __shared__ double sS[ChunkMap<NA>::LDS];
+  __shared__ double sB[ChunkMap<NV>::LDS];
+  __shared__ double sM[ChunkMap<NV>::LDS];
   const OdeArgs& a = q.o;
   const int lane = threadIdx.x, prob0 = blockIdx.x * NTS;
   const int nvalid = (a.batch - prob0) < NTS ? (a.batch - prob0) : NTS;
@@ -631,7 +639,16 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
 template <int METHOD, bool FWD, int D>
 hipError_t launch_d(const OdeArgs& a, hipStream_t st) {
   dim3 grid((a.batch + NTS - 1) / NTS), block(NTS);
-  constexpr int T = (D == 1) ? 16 : (D == 2 ? 8 : 4);      // grid points per chunk: 16 ... 64 doubles of the matrix stream per problem
+  constexpr int T = (D == 1) ? 16 : (D == 2 ? 8 : 4);      // grid points per chunk: the LDS of four waves per CU decides
+#ifdef VGPA_LANE_T_EXPERIMENTS
+  if (FWD && D == 3 && METHOD == VGPA_ODE_RK4) {
+    const char* e = getenv("VGPA_LANE_T_FWD");
+    const int t = e ? atoi(e) : T;
+    if (t == 2) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 2>), grid, block, 0, st, a); return hipGetLastError(); }
+    if (t == 6) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 6>), grid, block, 0, st, a); return hipGetLastError(); }
+    if (t == 8) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 8>), grid, block, 0, st, a); return hipGetLastError(); }
+  }
+#endif
   if (FWD) hipLaunchKernelGGL((k_fwd_lane<METHOD, D, T>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_bwd_small<METHOD, D>), grid, block, 0, st, a);
   return hipGetLastError();
@@ -651,7 +668,19 @@ hipError_t launch_m(const OdeArgs& a, hipStream_t st) {
 template <int METHOD, int MODEL>
 hipError_t launch_sweep_mm(const LaneSweepArgs& q, hipStream_t st) {
   dim3 grid((q.o.batch + NTS - 1) / NTS), block(NTS);
-  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 2 : 16;
+  // Lorenz-63: 4 grid points = 49 KB of LDS per wave, three waves per CU -- measured ahead of 2 grid points with four waves per CU
+  // (4.3 against 5.0 ms per 49152 problems: fewer partial cache lines per chunk; EXPERIMENTS.md s.8); batches fill the chip in
+  // multiples of 768 waves = 49152 problems
+  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 4 : 16;
+#ifdef VGPA_LANE_T_EXPERIMENTS
+  if (MODEL == VGPA_MODEL_L63 && METHOD == VGPA_ODE_RK4 && q.want_grad) {
+    const char* e = getenv("VGPA_LANE_T_BWD");
+    const int t = e ? atoi(e) : T;
+    if (t == 1) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 1>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 3) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 3>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 2) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 2>), grid, block, 0, st, q); return hipGetLastError(); }
+  }
+#endif
   if (q.want_grad) hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, T>), grid, block, 0, st, q);
   else hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, false, T>), grid, block, 0, st, q);
   return hipGetLastError();
