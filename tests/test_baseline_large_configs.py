@@ -137,3 +137,62 @@ def test_config5_row_sharded_recursion_at_d4096_eight_ranks():
     one forward and one backward RK4 step; every rank's time slice against the unsharded oracle."""
     from test_large_d import _run_native_virtual_ranks
     _run_native_virtual_ranks("rk4", 4096, 2, 8)
+
+
+def test_config4_time_chunked_sweep_at_d1024_with_a_real_chunk():
+    """BASELINE configs[3]'s matrix size on a grid long enough for the time-chunked sweep to mean something: D = 1024, RK4,
+    Np = 33, chunks of 8 steps (four full chunks: Psi_t and dEsde_dS exist only as chunk ring buffers, the backward recursion
+    crosses three chunk boundaries, eight observations fall inside and across chunks) -- against ORACLE anchors generated in the
+    build container (tools/gen_d4096_anchor.py 1024 33 -> tests/golden/anchors_d1024_np33.json, ~1 minute of CPU): F, per-grid-
+    point norms / maxima / sampled entries of the gradient, state norms.  Then the resident sweep of the same context size must
+    equal the chunked one bit for bit, as must a chunk length that does not divide the grid (5)."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT, GOLDEN_DIR
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_d4096_anchor import inputs_grid
+    from vgpa_amd._lib import FLAG_STREAM_LARGE_D, OPT_LD_CHUNK
+    import vgpa_amd as va
+    a = json.load(open(os.path.join(GOLDEN_DIR, "anchors_d1024_np33.json")))
+    d, n = a["D"], a["Np"]
+    x, m0, s0, sig, obs_t, obs_y, rdiag = inputs_grid(d, n)
+
+    def context(flags):
+        return va.Context("L96", a["method"], d, n, a["dt"], sigma=np.diag(sig), theta=[8.0], m0=m0, s0=s0, obs_t=obs_t, obs_y=obs_y,
+                          obs_noise=np.diag(rdiag), e0=0.0, flags=flags)
+
+    ctx = context(FLAG_STREAM_LARGE_D)
+    assert ctx.streaming
+    ctx.set_option(OPT_LD_CHUNK, 8)
+    f, g = ctx.sweep(x)
+    ga, gb = g[:n * d * d].reshape(n, d, d), g[n * d * d:].reshape(n, d)
+    assert abs(f - a["F_minus_E0"]) <= TOL * abs(a["F_minus_E0"])
+    e0, esde, eobs = ctx.energy_parts()
+    assert abs(esde - a["Esde"]) <= TOL * abs(a["Esde"]) and abs(eobs - a["Eobs"]) <= TOL * abs(a["Eobs"])
+    for t in range(n):
+        assert abs(np.linalg.norm(ga[t]) - a["grad_a_fro"][t]) <= TOL * a["grad_a_fro"][t], t
+        assert abs(np.abs(ga[t]).max() - a["grad_a_absmax"][t]) <= TOL * a["grad_a_absmax"][t], t
+        assert abs(np.linalg.norm(gb[t]) - a["grad_b_norm"][t]) <= TOL * a["grad_b_norm"][t], t
+        got = np.array([ga[t][i, j] for (i, j) in a["samples_ij"]])
+        assert rel_err(got, np.array(a["grad_a_samples"][t])) < 1e-8, t            # (single entries, some of them near cancellation)
+        assert rel_err(gb[t][:8], np.array(a["grad_b_first8"][t])) < TOL, t
+    st, mt, lam = ctx.fetch("st"), ctx.fetch("mt"), ctx.fetch("lamt")
+    for t in range(n):
+        assert abs(np.linalg.norm(st[t]) - a["st_fro"][t]) <= TOL * a["st_fro"][t]
+        assert abs(np.linalg.norm(mt[t]) - a["mt_norm"][t]) <= TOL * a["mt_norm"][t]
+        assert abs(np.linalg.norm(lam[t]) - a["lamt_norm"][t]) <= TOL * max(a["lamt_norm"][t], 1e-300)
+    ctx.close()
+    odd = context(FLAG_STREAM_LARGE_D)
+    odd.set_option(OPT_LD_CHUNK, 5)
+    f5, g5 = odd.sweep(x)
+    odd.close()
+    assert f5 == f and np.array_equal(g5, g)
+    res = context(0)
+    assert not res.streaming
+    f_r, g_r = res.sweep(x)
+    assert f_r == f and np.array_equal(g_r, g)                  # same kernels, same order per grid point
+    psit = res.fetch("psit")
+    for t in range(n):
+        assert abs(np.linalg.norm(psit[t]) - a["psit_fro"][t]) <= TOL * max(a["psit_fro"][t], 1e-300)
+    res.close()

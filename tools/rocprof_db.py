@@ -107,8 +107,38 @@ def traffic_all(fetch_db, write_db, out_csv, note="", out_json=None, key=None, p
         print(key, "=", tot)
 
 
+def counters(db_path, out_csv, note=""):
+    """Every counter of a --pmc pass, per kernel: the sum over the dispatches' values (all XCDs / SEs / instances) averaged
+    over the dispatches of the kernel, and -- where both were collected -- the matrix pipe's busy share
+    SQ_VALU_MFMA_BUSY_CYCLES / (32 SQ_BUSY_CYCLES).  SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs of the chip, SQ_BUSY_CYCLES
+    over its 32 shader engines (8 XCDs x 4: each counts the cycles ANY of its CUs is busy = the kernel's duration while it fills the
+    chip), so mfma / (32 busy) = the share of SIMD-cycles the matrix pipe is busy (checked on the D = 40 forward stepper:
+    9.175e9 / (32 x 5.09e8) = 0.56 against 0.54 from the rocprofv3 duration, profiles/r03c_sq_counters_B512.txt)."""
+    cur = sqlite3.connect(db_path).cursor()
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for did, kname, cname, val in cur.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection"):
+        acc[kname][cname] += float(val)
+        disp[kname].add(did)
+    names = sorted({c for k in acc for c in acc[k]})
+    with open(out_csv, "w") as fh:
+        fh.write("# rocprofv3 --pmc " + " ".join(names) + (": " + note if note else "") + "\n")
+        fh.write("# per kernel: counter sums over all instances, averaged over the kernel's dispatches\n")
+        fh.write("kernel,dispatches," + ",".join(names) + ",mfma_busy_share_of_simd_cycles\n")
+        for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0.0)):
+            n = max(len(disp[k]), 1)
+            vals = [acc[k].get(c, 0.0) / n for c in names]
+            busy, mf = acc[k].get("SQ_BUSY_CYCLES", 0.0), acc[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            ratio = (mf / (32.0 * busy)) if busy > 0 else float("nan")
+            fh.write('"%s",%d,%s,%.4f\n' % (k, n, ",".join("%.0f" % v for v in vals), ratio))
+            if busy > 0 and mf > 0:
+                print("%-70s dispatches %5d  matrix pipe busy %.3f of the SIMD-cycles" % (k[:70], n, ratio))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(*sys.argv[2:5])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic_all":
         traffic_all(*sys.argv[2:9])
