@@ -133,6 +133,17 @@ def cpu_baseline(p, x, method, d, n_pts, dt):
             "many_cores": all_cores, "F_cpu": f_cpu}
 
 
+def peak_context():
+    path = os.path.join(ROOT, "profiles", "peak_context.json")
+    try:
+        ctx = json.load(open(path))
+    except (OSError, ValueError):
+        return {"fp64_matrix_nominal_TFLOPs": FP64_PEAK_TFLOPS, "error": "profiles/peak_context.json is missing (tools/peak_context.py)"}
+    ctx["measured_in_this_run"] = False
+    ctx["file"] = "profiles/peak_context.json"
+    return ctx
+
+
 def config2_block(args, local_rank):
     """BASELINE configs[1]: Lorenz-63, D = 3, RK4, Np = 1001, the reference's seeded inputs -- the small-D path, which IS bound by
     HBM.  A batch of independent problems on the lane-per-problem kernels: forward moments (k_fwd_lane), observation
@@ -261,7 +272,10 @@ def config5_block(args, rank, world, local_rank, rehearse):
             f, ga, gb = once()
         sync()
         secs = par.max_over_ranks((time.perf_counter() - t0) / reps, device="cpu" if rehearse else "cuda")
-        chk = torch.tensor([float(ga.abs().sum()), float(gb.abs().sum())], dtype=torch.float64, device="cpu" if rehearse else dev)
+        # (the driver returns library-owned device arrays; torch wraps them without a copy through __cuda_array_interface__)
+        ga_t, gb_t = torch.as_tensor(ga, device=dev), torch.as_tensor(gb, device=dev)
+        chk = torch.tensor([float(ga_t.abs().sum()), float(gb_t.abs().sum())], dtype=torch.float64, device="cpu" if rehearse else dev)
+        del ga_t, gb_t
         if world > 1:
             dist.all_reduce(chk)
         # where the sweep's time goes: the phases of the last timed sweep (HIP events on the shard's stream; MAX over ranks, and
@@ -629,12 +643,9 @@ def main():
                                          f"sweep = {sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS:.3f} of HBM on SURVEY 8d's "
                                          f"algorithmic bytes; single problem = "
                                          f"{(single or {}).get('sweeps_per_s', float('nan')):.1f} sweeps/s"),
-        # what `peak` is worth on this part (measured, not used for `frac`): profiles/r03c_sustained_fp64_peak.txt, r03c_clock_under_load*.txt
-        "peak_context": {"fp64_matrix_nominal_TFLOPs": FP64_PEAK_TFLOPS,
-                         "fp64_matrix_sustained_TFLOPs": 72.1, "sustained_how": "every SIMD issuing only v_mfma_f64_4x4x4_4b for 5 s: 2.39 GHz, 1.00 kW "
-                         "(tools/ubench/f64_sustained.hip)",
-                         "clock_GHz_under_this_bench": 2.13, "package_W_under_this_bench": 1300, "power_capped": True,
-                         "measured_in_this_run": False},
+        # what `peak` is worth on this part (measured by tools/clock_under_load.sh + tools/sustained_peak.sh, parsed by tools/peak_context.py
+        # into profiles/peak_context.json; not used for `frac`, not measured in this run)
+        "peak_context": peak_context(),
         "roofline_kernels": roof,
         "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,

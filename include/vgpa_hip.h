@@ -360,6 +360,13 @@ void vgpa_rccl_comm_destroy(vgpa_comm* comm);
 /* ranks of the communicator as librccl counts them (ncclCommCount); VGPA_ERR_ARG for a table RCCL did not fill */
 int vgpa_rccl_comm_count(const vgpa_comm* comm, int* count);
 
+/* Device memory without a context -- what the callers of the row-sharded driver keep their operands and results in (the host
+ * mirror vgpa_amd/large_d.py needs no tensor library for it).  kind: 1 = host -> device, 2 = device -> host, 3 = device -> device;
+ * the copy is complete on return (it also waits for the device: results of an enqueued sweep are safe to read). */
+int vgpa_device_alloc(int device, uint64_t bytes, void** out);
+int vgpa_device_free(int device, void* ptr);
+int vgpa_device_memcpy(int device, void* dst, const void* src, uint64_t bytes, int kind);
+
 /* timing of the stepping kernel on the context's stream (HIP events), for bench.py's roofline */
 int vgpa_profile_begin(vgpa_ctx* ctx);
 int vgpa_profile_end(vgpa_ctx* ctx, double* fwd_ms, double* energy_ms, double* bwd_ms,

@@ -51,7 +51,7 @@ RAGGED_SHAPES = [
 
 def _run_gemm(transa, M, N, K, mid, lda_pad, misalign, cw_chunks, seed):
     import torch
-    from vgpa_amd.large_d import HipStageBackend
+    from legacy_sharded import HipStageBackend
     be = HipStageBackend()
     rng = np.random.default_rng(seed)
     rows, cols = (K, M) if transa else (M, K)            # storage of A (A^T product: A is [K][M])

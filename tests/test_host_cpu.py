@@ -28,13 +28,13 @@ def test_python_constants_agree_with_the_header():
     from vgpa_amd import _lib
     header = open(os.path.join(ROOT, "include", "vgpa_hip.h")).read()
     enums = {k: int(v) for k, v in re.findall(r"\b(VGPA_[A-Z0-9_]+)\s*=\s*(-?\d+)", header)}
-    for name in ("FORCE_GENERIC", "STREAM_LARGE_D", "LIBRARY_GEMM", "SYM_UNITS", "KEEP_PSI"):
+    for name in ("FORCE_GENERIC", "STREAM_LARGE_D", "LIBRARY_GEMM", "SYM_UNITS", "KEEP_PSI", "MATERIALIZE"):
         assert getattr(_lib, "FLAG_" + name) == enums["VGPA_FLAG_" + name], name
     fetch = {"mt": "MT", "st": "ST", "lamt": "LAMT", "psit": "PSIT", "Efx": "EFX", "Edf": "EDF", "dEsde_dm": "DESDE_DM",
              "dEsde_ds": "DESDE_DS", "Esde_t": "ESDE_T"}
     for key, sel in fetch.items():
         assert _lib.FETCH_IDS[key] == enums["VGPA_FETCH_" + sel], key
-    assert len({enums[k] for k in enums if k.startswith("VGPA_FLAG_")}) == 5          # distinct bits
+    assert len({enums[k] for k in enums if k.startswith("VGPA_FLAG_")}) == 6          # distinct bits
     assert _lib.SHARD_OPT_GATHER_CHUNKS == enums["VGPA_SHARD_OPT_GATHER_CHUNKS"]
     assert _lib.SHARD_OPT_TIMEOUT_MS == enums["VGPA_SHARD_OPT_TIMEOUT_MS"]
 

@@ -107,7 +107,7 @@ def test_row_sharded_hip_kernels_with_virtual_ranks(method, d, world):
     """The sharded recursion on the real HIP kernels: every virtual rank must reproduce the unsharded oracle."""
     import threading
     import torch
-    from vgpa_amd.large_d import ShardedRecursion
+    from legacy_sharded import ShardedRecursion
     n = 7
     a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(d, n)
     mt_o, st_o = vo.solve_fwd(method, 0.01, False, a, b, m0, s0, sigma)
@@ -142,7 +142,7 @@ def test_row_sharded_hip_kernels_with_virtual_ranks(method, d, world):
 def test_large_d_agrees_with_small_d_kernels_at_the_boundary():
     """D = 64 runs on the LDS-resident kernels, the per-stage GEMM path must give the same numbers."""
     import vgpa_amd as va
-    from vgpa_amd.large_d import ShardedRecursion
+    from legacy_sharded import ShardedRecursion
     a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(64, 20)
     mt, st = va.FwdOde(0.01, "rk4", False)(a, b, m0, s0, sigma)
     rec = ShardedRecursion("rk4", 0.01, 64)
@@ -242,7 +242,7 @@ def _worker(rank, world, port, out_dir, method):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from vgpa_amd import parallel as par
-    from vgpa_amd.large_d import ShardedRecursion
+    from legacy_sharded import ShardedRecursion
     par.init_from_env("gloo")
     a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(12, 7)
     rec = ShardedRecursion(method, 0.01, 12, backend=CpuStageStandIn())
@@ -268,7 +268,7 @@ def test_row_sharded_recursion_two_ranks_gloo(tmp_path, method):
 
 
 def test_single_rank_driver_with_standin_matches_oracle():
-    from vgpa_amd.large_d import ShardedRecursion
+    from legacy_sharded import ShardedRecursion
     a, b, m0, s0, sigma, gm, gs, jm, js = make_inputs(10, 6)
     for method in ("euler", "heun", "rk2", "rk4"):
         rec = ShardedRecursion(method, 0.01, 10, backend=CpuStageStandIn())
@@ -723,7 +723,7 @@ def test_stage_gemm_k_chunk_launches(M, D, world, chunks, transa):
     16-byte-load kernel) down to shapes that take the bounds-checked kernel."""
     import ctypes
     import torch
-    from vgpa_amd.large_d import HipStageBackend
+    from legacy_sharded import HipStageBackend
     be = HipStageBackend()
     lib, st = be._lib, be._stream()
     rng = np.random.default_rng(M + D + world)

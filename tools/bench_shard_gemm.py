@@ -18,7 +18,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
     import torch
-    from vgpa_amd.large_d import HipStageBackend
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from legacy_sharded import HipStageBackend
     be = HipStageBackend()
     lib = be._lib
     d, mp = args.dim, args.dim // args.world

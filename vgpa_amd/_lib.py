@@ -36,7 +36,8 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
            "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_shard_sweep_sharded", "vgpa_shard_set_option",
            "vgpa_shard_get_option", "vgpa_shard_time_collectives", "vgpa_ld_gemm_chunk", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
-           "vgpa_rccl_comm_destroy", "vgpa_rccl_comm_count", "vgpa_shard_time_stage", "vgpa_shard_phase_ms", "vgpa_time_slice"]
+           "vgpa_rccl_comm_destroy", "vgpa_rccl_comm_count", "vgpa_shard_time_stage", "vgpa_shard_phase_ms", "vgpa_time_slice",
+           "vgpa_device_alloc", "vgpa_device_free", "vgpa_device_memcpy"]
 
 P_DOUBLE = POINTER(c_double)
 
@@ -153,6 +154,9 @@ def load():
     lib.vgpa_shard_time_stage.argtypes = [c_void_p, c_int, c_int, P_DOUBLE]
     lib.vgpa_shard_phase_ms.argtypes = [c_void_p, P_DOUBLE]
     lib.vgpa_time_slice.argtypes = [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]
+    lib.vgpa_device_alloc.argtypes = [c_int, c_uint64, POINTER(c_void_p)]
+    lib.vgpa_device_free.argtypes = [c_int, c_void_p]
+    lib.vgpa_device_memcpy.argtypes = [c_int, c_void_p, c_void_p, c_uint64, c_int]
     lib.vgpa_vec_dot.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_absmax.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.vgpa_vec_asum.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
@@ -235,6 +239,88 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class HostArray:
+    """What `DeviceArray.cpu()` returns: the data on the host (`.numpy()`), so that callers written against a tensor
+    library's `.cpu().numpy()` read the same."""
+
+    def __init__(self, a):
+        self._a = a
+
+    def numpy(self):
+        return self._a
+
+
+class DeviceArray:
+    """An fp64 array in device memory owned by this object (vgpa_device_alloc; freed with it), with just enough surface for the
+    callers of the row-sharded driver: `.ptr` / `.data_ptr()`, `.shape`, `[:n]` views of the leading dimension, `.numpy()` /
+    `.cpu().numpy()` (download), and `__cuda_array_interface__`, through which a tensor library can wrap the memory without a copy
+    (`torch.as_tensor(arr, device="cuda")`)."""
+
+    def __init__(self, shape, device=0, _base=None, _ptr=None):
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.device = int(device)
+        self._lib = load()
+        self._base = _base                       # a view keeps its owner alive
+        if _base is None:
+            p = c_void_p()
+            rc = self._lib.vgpa_device_alloc(self.device, max(self.size, 1) * 8, byref(p))
+            if rc != 0:
+                _raise(rc, f"vgpa_device_alloc({self.size * 8} bytes) failed")
+            self.ptr = p.value
+        else:
+            self.ptr = int(_ptr)
+
+    @property
+    def size(self):
+        n = 1
+        for v in self.shape:
+            n *= v
+        return n
+
+    @classmethod
+    def from_host(cls, a, device=0):
+        a = _c64(a)
+        out = cls(a.shape, device)
+        rc = out._lib.vgpa_device_memcpy(out.device, c_void_p(out.ptr), _ptr(a), a.size * 8, 1)
+        if rc != 0:
+            _raise(rc, "vgpa_device_memcpy (host -> device) failed")
+        return out
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numpy(self):
+        out = np.empty(self.shape)
+        rc = self._lib.vgpa_device_memcpy(self.device, _ptr(out), c_void_p(self.ptr), out.size * 8, 2)
+        if rc != 0:
+            _raise(rc, "vgpa_device_memcpy (device -> host) failed")
+        return out
+
+    def cpu(self):
+        return HostArray(self.numpy())
+
+    def __getitem__(self, key):
+        if not (isinstance(key, slice) and key.step in (None, 1)):
+            raise TypeError("DeviceArray supports contiguous slices of the leading dimension only")
+        lo, hi, _ = key.indices(self.shape[0])
+        hi = max(hi, lo)
+        inner = self.size // self.shape[0] if self.shape[0] else 0
+        return DeviceArray((hi - lo,) + self.shape[1:], self.device, _base=self if self._base is None else self._base,
+                           _ptr=self.ptr + 8 * lo * inner)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def __del__(self):
+        try:
+            if self._base is None and getattr(self, "ptr", None):
+                self._lib.vgpa_device_free(self.device, c_void_p(self.ptr))
+                self.ptr = None
         except Exception:
             pass
 

@@ -1241,6 +1241,38 @@ int vgpa_memcpy_d2h(vgpa_ctx* c, void* dst, const void* src, uint64_t bytes) {
   return VGPA_OK;
 }
 
+// ---- device memory without a context (the row-sharded driver's callers: vgpa_amd/large_d.py keeps its buffers here) ----------------
+// Plain hipMalloc / hipFree / synchronous hipMemcpy on `device`; the calling thread's current device is put back.
+namespace {
+struct DeviceScope {
+  int prev = -1; bool ok = false;
+  explicit DeviceScope(int device) { (void)hipGetDevice(&prev); ok = hipSetDevice(device) == hipSuccess; }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+int vgpa_device_alloc(int device, uint64_t bytes, void** out) {
+  if (!out) return VGPA_ERR_ARG;
+  DeviceScope sc(device);
+  if (!sc.ok) return VGPA_ERR_DEVICE;
+  return hipMalloc(out, bytes ? bytes : 8) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+int vgpa_device_free(int device, void* ptr) {
+  if (!ptr) return VGPA_OK;
+  DeviceScope sc(device);
+  if (!sc.ok) return VGPA_ERR_DEVICE;
+  return hipFree(ptr) == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+int vgpa_device_memcpy(int device, void* dst, const void* src, uint64_t bytes, int kind) {
+  if ((!dst || !src) && bytes) return VGPA_ERR_ARG;
+  if (kind < 1 || kind > 3) return VGPA_ERR_ARG;
+  DeviceScope sc(device);
+  if (!sc.ok) return VGPA_ERR_DEVICE;
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+  if (bytes == 0) return VGPA_OK;
+  if (hipMemcpy(dst, src, bytes, k) != hipSuccess) return VGPA_ERR_DEVICE;
+  return hipDeviceSynchronize() == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
+}
+
 // ---- profiling ----------------------------------------------------------------------------------------
 int vgpa_profile_begin(vgpa_ctx* c) {
   if (!c) return VGPA_ERR_ARG;

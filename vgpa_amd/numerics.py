@@ -40,16 +40,28 @@ class OdeSolver(object):
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def _large(self, dim_d):
-        """D > 64: per-stage fp64 GEMM path (vgpa_amd/large_d.py), one GPU or the default process group."""
-        from .large_d import ShardedRecursion
-        key = ("large", dim_d)
+    def _large(self, dim_d, n_pts):
+        """D > 64 under a live process group: the row-sharded native driver (vgpa_amd/large_d.py) on the default group."""
+        from .large_d import NativeShardedRecursion
+        key = ("large", dim_d, n_pts)
         rec = self._ctx.get(key)
         if rec is None:
             self._ctx.clear()
-            rec = ShardedRecursion(self.method, self.dt, dim_d)
+            rec = NativeShardedRecursion(self.method, self.dt, dim_d, n_pts)
             self._ctx[key] = rec
         return rec
+
+    @staticmethod
+    def _gather_time(rec, v_own, m_own, n_pts):
+        """The driver's results are time-sharded; the reference's contract is the whole grid on the caller: gather the slices."""
+        import torch.distributed as dist
+        parts = [None] * rec.world
+        dist.all_gather_object(parts, (rec.time_slice, v_own.numpy(), m_own.numpy()))
+        d = rec.D
+        v, m = np.empty((n_pts, d)), np.empty((n_pts, d, d))
+        for (lo, hi), pv, pm in parts:
+            v[lo:hi], m[lo:hi] = pv, pm
+        return v, m
 
     def _context(self, dim_d, n_pts):
         key = (dim_d, n_pts, self.device, self.flags)
@@ -73,8 +85,8 @@ class OdeSolver(object):
             return mt.reshape(n), st.reshape(n)
         n, d = off_b.shape
         if d > SMALL_D_MAX and self._sharded():
-            mt, st = self._large(d).solve_fwd(lin_a, off_b, m0, s0, sigma)
-            return mt.cpu().numpy(), st.cpu().numpy()
+            rec = self._large(d, n)
+            return self._gather_time(rec, *rec.solve_fwd(lin_a, off_b, m0, s0, sigma), n)
         ctx = self._context(d, n)
         return ctx.solve_fwd(lin_a, off_b, m0, s0, sigma)
 
@@ -90,8 +102,8 @@ class OdeSolver(object):
             return lam.reshape(n), psi.reshape(n)
         n, d = dEsde_dm.shape
         if d > SMALL_D_MAX and self._sharded():
-            lam, psi = self._large(d).solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
-            return lam.cpu().numpy(), psi.cpu().numpy()
+            rec = self._large(d, n)
+            return self._gather_time(rec, *rec.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds), n)
         ctx = self._context(d, n)
         return ctx.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
 
