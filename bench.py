@@ -63,8 +63,8 @@ def parse():
     ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary Lorenz-63 block (BASELINE configs[1], the HBM-bound small-D path)")
-    ap.add_argument("--config2-batch", type=int, default=49152, help="independent Lorenz-63 problems of the config-2 block: 768 waves of 64 -- "
-                    "three per CU, what the fused lane pass's 49 KB of LDS per wave admits (any multiple fills the chip evenly)")
+    ap.add_argument("--config2-batch", type=int, default=65536, help="independent Lorenz-63 problems of the config-2 block: 1024 waves of 64 -- "
+                    "one per SIMD, what the lane kernels' registers admit (any multiple fills the chip evenly)")
     return ap.parse_args()
 
 
@@ -147,7 +147,9 @@ def peak_context():
 def config2_block(args, local_rank):
     """BASELINE configs[1]: Lorenz-63, D = 3, RK4, Np = 1001, the reference's seeded inputs -- the small-D path, which IS bound by
     HBM.  A batch of independent problems on the lane-per-problem kernels: forward moments (k_fwd_lane), observation
-    terms (k_obs), ONE fused backward pass (k_sweep_lane: closed-form E_sde terms in registers, (lam, Psi) recursion, gradient, F).
+    terms (k_obs_lane), ONE fused backward pass (k_sweep_lane: closed-form E_sde terms in registers, (lam, Psi) recursion, gradient, F);
+    (m_t, S_t) live in a time-major array of the context (problem fastest: coalesced straight into registers), x and the gradient
+    pass through LDS in chunks of six grid points.
     Roofline on SURVEY 8(d)'s algorithmic bytes 8 Np (5 D^2 + 6 D) per sweep against 8 TB/s; problem 0 must reproduce the
     reference's anchor; the numpy oracle is timed beside it (one sweep, one core).  Never raises."""
     try:
@@ -202,7 +204,7 @@ def config2_block(args, local_rank):
         gbs = alg * B / secs / 1e9
         return {"workload": f"Lorenz63 D=3, RK4, Np={n_pts} (BASELINE configs[1]), {B} independent problems, one lane per problem",
                 "sweeps_per_s": B / secs, "ms_per_step": 1e3 * secs, "batch": B,
-                "phase_ms_per_step": {"fwd (k_fwd_lane)": 1e3 * fwd_s, "obs (k_obs)": pr["energy_ms"] / steps,
+                "phase_ms_per_step": {"fwd (k_fwd_lane)": 1e3 * fwd_s, "obs (k_obs_lane)": pr["energy_ms"] / steps,
                                       "fused E_sde + bwd + grad + F (k_sweep_lane)": 1e3 * bwd_s},
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "alg_bytes_per_sweep": alg, "alg_bytes_per_step": alg * B,

@@ -50,6 +50,7 @@ struct EnergyL63 { double e_t, dm[3], ds[6], ef[3], hyp[6]; };
 template <bool HYP>
 __device__ __forceinline__ void energy_l63(const double* th, const double (&isg)[3], const double (&At)[9], const double (&bt)[3],
                                            const double (&mt)[3], const double (&St)[9], EnergyL63& r) {
+#pragma clang fp contract(fast)
   const double vS = th[0], vR = th[1], vB = th[2];
   const double iSx = isg[0], iSy = isg[1], iSz = isg[2];
   const double A11 = At[0], A12 = At[1], A13 = At[2], A21 = At[3], A22 = At[4], A23 = At[5];
@@ -152,6 +153,7 @@ __device__ __forceinline__ void grad_point(const double (&Av)[D * D], const doub
                                            const double (&Sv)[D * D], const double (&ef)[D], const double (&Ev)[D * D],
                                            const double (&Pv)[D * D], const double (&lm)[D], const double (&Iv)[D * D], double dt,
                                            double (&gA)[D * D], double (&gB)[D]) {
+#pragma clang fp contract(fast)
   constexpr int DD = D * D;
   double rv[D], uv[D], pa[DD], q[DD];
 #pragma unroll

@@ -75,6 +75,7 @@ __device__ __forceinline__ void rhs_fwd(const double (&AB)[D * D], const double 
 template <int D>
 __device__ __forceinline__ void rhs_bwd(const double (&AB)[D * D], const double (&X)[D * D], const double (&g)[D * D],
                                         double (&r)[D * D]) {
+#pragma clang fp contract(fast)
 #pragma unroll
   for (int i = 0; i < D; i++)
 #pragma unroll
@@ -136,8 +137,7 @@ struct ChunkMap {
   static constexpr int PG = NTS / G;                       // whole problems per instruction
   static constexpr int NG = (NTS + PG - 1) / PG;
   static constexpr int NI = NG * R;                        // instructions per chunk = doubles a lane holds between request and LDS
-  static constexpr int ROWS = (NG - 1) * PG + (NTS - 1) / G + 1;   // LDS rows incl. the scratch rows behind problem 63
-  static constexpr int LDS = ROWS * (N | 1);
+  static constexpr int LDS = NTS * (N | 1);                // (lanes that fall behind problem 63 work on problem 63 again)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -168,11 +168,14 @@ template <int N>
 __device__ __forceinline__ void chunk_to_lds(double* __restrict__ lds, const double (&v)[ChunkMap<N>::NI]) {
   using M = ChunkMap<N>;
   const unsigned lane = threadIdx.x;
-  double* mine = lds + (int)(lane / M::G) * row_stride<N>() + (int)(lane % M::G);
+  const int pl = (int)(lane / M::G), el = (int)(lane % M::G);
 #pragma unroll
-  for (int jg = 0; jg < M::NG; jg++)
+  for (int jg = 0; jg < M::NG; jg++) {
+    const int p = (jg * M::PG + NTS / M::G > NTS - 1) ? (jg * M::PG + pl < NTS ? jg * M::PG + pl : NTS - 1) : jg * M::PG + pl;
+    double* mine = lds + p * row_stride<N>() + el;
 #pragma unroll
-    for (int r = 0; r < M::R; r++) mine[jg * M::PG * row_stride<N>() + r * M::G] = v[jg * M::R + r];
+    for (int r = 0; r < M::R; r++) mine[r * M::G] = v[jg * M::R + r];
+  }
 }
 
 // results leave the way the operands came; lanes whose (problem, grid point) is out of range store a valid neighbour's value to
@@ -283,7 +286,7 @@ __device__ __forceinline__ void fwd_step(const double (&A0)[D * D], const double
 
 // Forward moments, one lane per problem, streams staged through LDS in chunks of T grid points.  Step k consumes the operands of
 // grid point k+1 (slot s of the chunk) and produces (m, S) of grid point k+1: the result takes the consumed slot.
-template <int METHOD, int D, int T>
+template <int METHOD, int D, int T, bool OUT_T = false>      // OUT_T: the moments go to OdeArgs::msT straight from the registers
 __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_fwd_lane(OdeArgs a) {
   constexpr int DD = D * D, NA = T * DD, NB = T * D;
   __shared__ double sA[ChunkMap<NA>::LDS];
@@ -301,7 +304,19 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   double sk[DD], sig[DD], mk[D], A0[DD], b0[D];
   ld_mat<D>(a.S0, sk); ld_mat<D>(a.Sigma, sig); ld_vec<D>(a.m0, mk);
   ld_mat<D>(A, A0); ld_vec<D>(b, b0);
-  if (live) { st_mat<D>(a.S + (size_t)prob * sS, sk); st_vec<D>(a.m + (size_t)prob * sm, mk); }
+  constexpr int W = DD + D;
+  double* const outT = OUT_T ? a.msT + prob : nullptr;       // entry e of grid point t: outT[(t * W + e) * bpad]
+  const size_t bp = (size_t)a.bpad;
+  auto store_t = [&](int t) {
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < DD; e++) outT[((size_t)t * W + e) * bp] = sk[e];
+#pragma unroll
+      for (int i = 0; i < D; i++) outT[((size_t)t * W + DD + i) * bp] = mk[i];
+    }
+  };
+  if (OUT_T) store_t(0);
+  else if (live) { st_mat<D>(a.S + (size_t)prob * sS, sk); st_vec<D>(a.m + (size_t)prob * sm, mk); }
 
   const int nchunks = (Np - 1 + T - 1) / T;
   double pa[ChunkMap<NA>::NI], pb[ChunkMap<NB>::NI];
@@ -322,7 +337,7 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
       chunk_request<NA>(Au, strA, nvalid, (long)((c + 1) * T + 1) * DD, (long)Np * DD, pa);
       chunk_request<NB>(bu, strB, nvalid, (long)((c + 1) * T + 1) * D, (long)Np * D, pb);
     }
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < T; s++) {
       if (c * T + s < Np - 1) {
         double A1[DD], b1[D];
@@ -331,16 +346,19 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int i = 0; i < D; i++) b1[i] = rowB[s * D + i];
         fwd_step<METHOD, D>(A0, A1, b0, b1, sig, dt, sk, mk);
+        if (OUT_T) store_t(c * T + s + 1);
 #pragma unroll
-        for (int e = 0; e < DD; e++) { rowA[s * DD + e] = sk[e]; A0[e] = A1[e]; }
+        for (int e = 0; e < DD; e++) { if (!OUT_T) rowA[s * DD + e] = sk[e]; A0[e] = A1[e]; }
 #pragma unroll
-        for (int i = 0; i < D; i++) { rowB[s * D + i] = mk[i]; b0[i] = b1[i]; }
+        for (int i = 0; i < D; i++) { if (!OUT_T) rowB[s * D + i] = mk[i]; b0[i] = b1[i]; }
       }
     }
     wave_sync();
-    chunk_flush<NA>(sA, Su, (unsigned)sS, nvalid, (long)(c * T + 1) * DD, (long)Np * DD);
-    chunk_flush<NB>(sB, mu, (unsigned)sm, nvalid, (long)(c * T + 1) * D, (long)Np * D);
-    wave_sync();
+    if (!OUT_T) {
+      chunk_flush<NA>(sA, Su, (unsigned)sS, nvalid, (long)(c * T + 1) * DD, (long)Np * DD);
+      chunk_flush<NB>(sB, mu, (unsigned)sm, nvalid, (long)(c * T + 1) * D, (long)Np * D);
+      wave_sync();
+    }
   }
 }
 
@@ -355,7 +373,12 @@ __device__ __forceinline__ void load_jump(const OdeArgs& a, int prob, int t1, do
     const int n = a.obs_idx ? ldu(a.obs_idx, t1) : -1;           // (scalar load: see vgpa_internal.h)
     if (n >= 0) {
       ld_mat<D>(a.js_const, js);
-      ld_vec<D>(a.jm_sparse + ((size_t)prob * a.n_obs + n) * D, jm);
+      if (a.jmT) {
+#pragma unroll
+        for (int i = 0; i < D; i++) jm[i] = a.jmT[((size_t)n * D + i) * (size_t)a.bpad + prob];
+      } else {
+        ld_vec<D>(a.jm_sparse + ((size_t)prob * a.n_obs + n) * D, jm);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < DD; e++) js[e] = 0.0;
@@ -371,6 +394,7 @@ __device__ __forceinline__ void bwd_step(const double (&At)[D * D], const double
                                          const double (&gsm)[D * D], const double (&gmt)[D], const double (&gmm)[D],
                                          const double (&js)[D * D], const double (&jm)[D], double dt, double (&pk)[D * D],
                                          double (&lk)[D]) {
+#pragma clang fp contract(fast)
   constexpr int DD = D * D;
   const double h = 0.5 * dt;
   double r[DD], y[D], X[DD], xv[D];
@@ -493,6 +517,7 @@ template <int MODEL, int D>
 __device__ __forceinline__ void point_terms(const LaneSweepArgs& q, const double (&Av)[D * D], const double (&bv)[D], const double (&mv)[D],
                                             const double (&Sv)[D * D], double (&gs)[D * D], double (&gm)[D], double& e_t, double (&ef)[D],
                                             double (&edf)[D * D]) {
+#pragma clang fp contract(fast)
   if constexpr (MODEL == VGPA_MODEL_L63) {
     EnergyL63 r;
     const double isg[3] = {q.isg[0], q.isg[1], q.isg[2]};
@@ -520,9 +545,7 @@ template <int METHOD, int MODEL, bool GRAD, int T>
 __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_sweep_lane(LaneSweepArgs q) {
   constexpr int D = (MODEL == VGPA_MODEL_L63) ? 3 : 1, DD = D * D, NA = T * DD, NV = T * D;
   __shared__ double sA[ChunkMap<NA>::LDS];
-  __shared__ double sS[ChunkMap<NA>::LDS];
   __shared__ double sB[ChunkMap<NV>::LDS];
-  __shared__ double sM[ChunkMap<NV>::LDS];
   const OdeArgs& a = q.o;
   const int lane = threadIdx.x, prob0 = blockIdx.x * NTS;
   const int nvalid = (a.batch - prob0) < NTS ? (a.batch - prob0) : NTS;
@@ -530,8 +553,19 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   const int prob = prob0 + (live ? lane : nvalid - 1);
   const int Np = a.Np;
   const double dt = a.dt;
-  const size_t sSs = (size_t)Np * DD, sms = (size_t)Np * D, len_x = a.strideA;
+  const size_t len_x = a.strideA;
   const long limA = (long)Np * DD, limV = (long)Np * D;
+  // the moments come from the context's time-major array (OdeArgs::msT): one coalesced 512-byte load per entry and wave, straight
+  // into registers, requested one step ahead
+  constexpr int W = DD + D;
+  const double* const msT = a.msT + prob;
+  const size_t bp = (size_t)a.bpad;
+  auto load_ms = [&](int t, double (&Sv)[DD], double (&mv)[D]) {
+#pragma unroll
+    for (int e = 0; e < DD; e++) Sv[e] = msT[((size_t)t * W + e) * bp];
+#pragma unroll
+    for (int i = 0; i < D; i++) mv[i] = msT[((size_t)t * W + DD + i) * bp];
+  };
 
   double Iv[DD];
 #pragma unroll
@@ -543,8 +577,7 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
     double bt[D], mt[D], St[DD], ef[D], edf[DD];
     ld_mat<D>(a.A + (size_t)prob * a.strideA + (size_t)(Np - 1) * DD, At);
     ld_vec<D>(a.b + (size_t)prob * a.strideB + (size_t)(Np - 1) * D, bt);
-    ld_vec<D>(a.m + (size_t)prob * sms + (size_t)(Np - 1) * D, mt);
-    ld_mat<D>(a.S + (size_t)prob * sSs + (size_t)(Np - 1) * DD, St);
+    load_ms(Np - 1, St, mt);
     point_terms<MODEL, D>(q, At, bt, mt, St, gst, gmt, e_t, ef, edf);
 #pragma unroll
     for (int e = 0; e < DD; e++) pk[e] = 0.0;
@@ -562,50 +595,47 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   double esum = 0.0;
 
   const int nchunks = (Np - 1 + T - 1) / T;
-  double pa[ChunkMap<NA>::NI], ps[ChunkMap<NA>::NI], pb[ChunkMap<NV>::NI], pm[ChunkMap<NV>::NI];
+  double pa[ChunkMap<NA>::NI], pb[ChunkMap<NV>::NI];
   const double* Au = a.A + (size_t)prob0 * a.strideA;        // wave-uniform stream bases
   const double* bu = a.b + (size_t)prob0 * a.strideB;
-  const double* Su = a.S + (size_t)prob0 * sSs;
-  const double* mu = a.m + (size_t)prob0 * sms;
   double* gAu = q.g + (size_t)prob0 * len_x;
   double* gBu = gAu + (size_t)Np * DD;
-  const unsigned strA = (unsigned)a.strideA, strB = (unsigned)a.strideB, strS = (unsigned)sSs, strM = (unsigned)sms;
+  const unsigned strA = (unsigned)a.strideA, strB = (unsigned)a.strideB;
   {
     const long lo = (long)(Np - 2) - T + 1;
     chunk_request<NA>(Au, strA, nvalid, lo * DD, limA, pa);
     chunk_request<NV>(bu, strB, nvalid, lo * D, limV, pb);
-    chunk_request<NV>(mu, strM, nvalid, lo * D, limV, pm);
-    chunk_request<NA>(Su, strS, nvalid, lo * DD, limA, ps);
   }
+  // moments of the next TWO grid points down: requested two steps ahead (under a full chip the memory round trip is longer
+  // than one step of a lone wave)
+  double Sn[DD], mn[D], Sn2[DD], mn2[D];
+  load_ms(Np > 1 ? Np - 2 : 0, Sn, mn);
+  load_ms(Np > 2 ? Np - 3 : 0, Sn2, mn2);
   double* rowA = sA + lane * row_stride<NA>();
-  double* rowS = sS + lane * row_stride<NA>();
   double* rowB = sB + lane * row_stride<NV>();
-  double* rowM = sM + lane * row_stride<NV>();
   for (int c = 0; c < nchunks; c++) {
     const int hi = Np - 2 - c * T;
     const long lo = (long)hi - T + 1;
     chunk_to_lds<NA>(sA, pa);
     chunk_to_lds<NV>(sB, pb);
-    chunk_to_lds<NV>(sM, pm);
-    chunk_to_lds<NA>(sS, ps);
     wave_sync();
     if (c + 1 < nchunks) {      // the next chunk travels while this one is stepped through
       const long lon = lo - T;
       chunk_request<NA>(Au, strA, nvalid, lon * DD, limA, pa);
       chunk_request<NV>(bu, strB, nvalid, lon * D, limV, pb);
-      chunk_request<NV>(mu, strM, nvalid, lon * D, limV, pm);
-      chunk_request<NA>(Su, strS, nvalid, lon * DD, limA, ps);
     }
-#pragma unroll
+    // (NOT unrolled: one step is ~11 KB of code -- the closed-form energy terms -- and six copies would not fit the instruction cache)
+#pragma unroll 1
     for (int s = 0; s < T; s++) {
       const int idx = hi - s;               // grid point t - 1 of this step
       if (idx >= 0) {
         const int slot = T - 1 - s;
         double Am[DD], bm[D], mm[D], Sm[DD], gsm[DD], gmm[D], e_m, ef[D], edf[DD];
 #pragma unroll
-        for (int e = 0; e < DD; e++) { Am[e] = rowA[slot * DD + e]; Sm[e] = rowS[slot * DD + e]; }
+        for (int e = 0; e < DD; e++) { Am[e] = rowA[slot * DD + e]; Sm[e] = Sn[e]; Sn[e] = Sn2[e]; }
 #pragma unroll
-        for (int i = 0; i < D; i++) { bm[i] = rowB[slot * D + i]; mm[i] = rowM[slot * D + i]; }
+        for (int i = 0; i < D; i++) { bm[i] = rowB[slot * D + i]; mm[i] = mn[i]; mn[i] = mn2[i]; }
+        load_ms(idx > 1 ? idx - 2 : 0, Sn2, mn2);
         point_terms<MODEL, D>(q, Am, bm, mm, Sm, gsm, gmm, e_m, ef, edf);
         esum += dt * (e_t + e_m) / 2.0;     // my_trapz, utilities.py:144 (interval [t-1, t])
         e_t = e_m;
@@ -640,15 +670,23 @@ template <int METHOD, bool FWD, int D>
 hipError_t launch_d(const OdeArgs& a, hipStream_t st) {
   dim3 grid((a.batch + NTS - 1) / NTS), block(NTS);
   constexpr int T = (D == 1) ? 16 : (D == 2 ? 8 : 4);      // grid points per chunk: the LDS of four waves per CU decides
+  if (FWD && a.msT) {
+    if constexpr (D == 1 || D == 3) {      // (the models of the fused lane pass)
+      constexpr int TT = D == 3 ? 6 : 16;
 #ifdef VGPA_LANE_T_EXPERIMENTS
-  if (FWD && D == 3 && METHOD == VGPA_ODE_RK4) {
-    const char* e = getenv("VGPA_LANE_T_FWD");
-    const int t = e ? atoi(e) : T;
-    if (t == 2) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 2>), grid, block, 0, st, a); return hipGetLastError(); }
-    if (t == 6) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 6>), grid, block, 0, st, a); return hipGetLastError(); }
-    if (t == 8) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 8>), grid, block, 0, st, a); return hipGetLastError(); }
-  }
+      if (D == 3 && METHOD == VGPA_ODE_RK4) {
+        const char* e = getenv("VGPA_LANE_T_FWD");
+        const int t = e ? atoi(e) : TT;
+        if (t == 4) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 4, true>), grid, block, 0, st, a); return hipGetLastError(); }
+        if (t == 8) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 8, true>), grid, block, 0, st, a); return hipGetLastError(); }
+        if (t == 12) { hipLaunchKernelGGL((k_fwd_lane<METHOD, D, 12, true>), grid, block, 0, st, a); return hipGetLastError(); }
+      }
 #endif
+      hipLaunchKernelGGL((k_fwd_lane<METHOD, D, TT, true>), grid, block, 0, st, a);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   if (FWD) hipLaunchKernelGGL((k_fwd_lane<METHOD, D, T>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_bwd_small<METHOD, D>), grid, block, 0, st, a);
   return hipGetLastError();
@@ -671,14 +709,14 @@ hipError_t launch_sweep_mm(const LaneSweepArgs& q, hipStream_t st) {
   // Lorenz-63: 4 grid points = 49 KB of LDS per wave, three waves per CU -- measured ahead of 2 grid points with four waves per CU
   // (4.3 against 5.0 ms per 49152 problems: fewer partial cache lines per chunk; EXPERIMENTS.md s.8); batches fill the chip in
   // multiples of 768 waves = 49152 problems
-  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 4 : 16;
+  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 6 : 16;
 #ifdef VGPA_LANE_T_EXPERIMENTS
   if (MODEL == VGPA_MODEL_L63 && METHOD == VGPA_ODE_RK4 && q.want_grad) {
     const char* e = getenv("VGPA_LANE_T_BWD");
     const int t = e ? atoi(e) : T;
-    if (t == 1) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 1>), grid, block, 0, st, q); return hipGetLastError(); }
-    if (t == 3) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 3>), grid, block, 0, st, q); return hipGetLastError(); }
-    if (t == 2) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 2>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 4) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 4>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 5) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 5>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 8) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 8>), grid, block, 0, st, q); return hipGetLastError(); }
   }
 #endif
   if (q.want_grad) hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, T>), grid, block, 0, st, q);
@@ -709,12 +747,93 @@ hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+namespace {
+// msT [Np][W][bpad] -> m [B][Np][D], S [B][Np][D][D]: one wave per (64 problems, grid point); coalesced reads, per-lane writes
+// (on demand only: vgpa_fetch and the separate kernels of the four-kernel path)
+__global__ void __launch_bounds__(NTS) k_ms_untranspose(int D, int Np, int batch, int bpad, const double* __restrict__ msT,
+                                                        double* __restrict__ m, double* __restrict__ S) {
+  const int prob = blockIdx.x * NTS + threadIdx.x, t = blockIdx.y;
+  if (prob >= batch) return;
+  const int DD = D * D, W = DD + D;
+  const double* src = msT + (size_t)t * W * bpad + prob;
+  double* so = S + ((size_t)prob * Np + t) * DD;
+  double* mo = m + ((size_t)prob * Np + t) * D;
+  for (int e = 0; e < DD; e++) so[e] = src[(size_t)e * bpad];
+  for (int i = 0; i < D; i++) mo[i] = src[(size_t)(DD + i) * bpad];
+}
+
+// Observation terms of the fused lane pass (gaussian_like.py:69-243; same expressions as assemble.hip::k_obs, one lane per problem
+// looping over the observations): E_obs and the sparse vector jumps, moments read from msT, jumps written to jmT -- both with the
+// problem fastest, so every access of a wave is one coalesced 512-byte transaction.  (Quirk Q4 kept: the covariance diagonal of
+// observation n is taken at grid index n, not at t_n; the 1-D models use S[t_n].)
+template <int D>
+__global__ void __launch_bounds__(NTS) k_obs_lane(ObsArgs a, const double* __restrict__ msT, int bpad, double* __restrict__ jmT) {
+  const int prob = blockIdx.x * NTS + threadIdx.x;
+  if (prob >= a.batch) return;
+  constexpr int DD = D * D, W = DD + D;
+  const size_t bp = (size_t)bpad;
+  const double* ms = msT + prob;
+  double* jo = jmT + prob;
+  const int M = a.n_obs;
+  double part = 0.0;
+  if (a.single) {
+    const double rinv = a.Q[0], k0 = a.K[0];
+    for (int n = 0; n < M; n++) {
+      const size_t tn = (size_t)a.obs_t[n];
+      const double y = a.obs_y[n], ss = ms[(tn * W) * bp], mm = ms[(tn * W + 1) * bp];
+      const double ex2 = mm * mm + ss;
+      part += (y * y) - 2.0 * y * mm + ex2;
+      jo[(size_t)n * bp] = -(y - k0 * mm) * rinv;
+    }
+    a.eobs[prob] = 0.5 * part * rinv + a.obs_const;
+    return;
+  }
+  for (int n = 0; n < M; n++) {
+    const size_t tn = (size_t)a.obs_t[n];
+    const double* y = a.obs_y + (size_t)n * D;
+    double w[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) w[j] = y[j] - ms[(tn * W + DD + j) * bp];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      double qrow = 0.0, krow = 0.0;
+      if (a.diag) {
+        qrow = __builtin_fma(a.Q[i * D + i], w[i], qrow);
+        krow = __builtin_fma(a.K[i * D + i], w[i], krow);
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+          qrow = __builtin_fma(a.Q[i * D + j], w[j], qrow);
+          krow = __builtin_fma(a.K[i * D + j], w[j], krow);
+        }
+      }
+      jo[((size_t)n * D + i) * bp] = -krow;
+      part += w[i] * qrow + a.rinv_diag[i] * ms[((size_t)n * W + i * D + i) * bp];
+    }
+  }
+  a.eobs[prob] = 0.5 * (part + a.obs_const);
+}
+}  // namespace
+
+hipError_t launch_ms_untranspose(int D, int Np, int batch, int bpad, const double* msT, double* m, double* S, hipStream_t st) {
+  hipLaunchKernelGGL(k_ms_untranspose, dim3((batch + NTS - 1) / NTS, Np), dim3(NTS), 0, st, D, Np, batch, bpad, msT, m, S);
+  return hipGetLastError();
+}
+
+hipError_t launch_obs_lane(const ObsArgs& a, const double* msT, int bpad, double* jmT, hipStream_t st) {
+  const dim3 grid((a.batch + NTS - 1) / NTS), block(NTS);
+  if (a.D == 1) hipLaunchKernelGGL(k_obs_lane<1>, grid, block, 0, st, a, msT, bpad, jmT);
+  else if (a.D == 3) hipLaunchKernelGGL(k_obs_lane<3>, grid, block, 0, st, a, msT, bpad, jmT);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 bool sweep_lane_supported(int model, int D) {
   return (model == VGPA_MODEL_L63 && D == 3) || ((model == VGPA_MODEL_OU || model == VGPA_MODEL_DW) && D == 1);
 }
 
 hipError_t launch_sweep_lane(int method, const LaneSweepArgs& q, hipStream_t st) {
-  if (!sweep_lane_supported(q.model, q.o.D) || q.o.js_dense || q.o.Np < 2) return hipErrorInvalidValue;
+  if (!sweep_lane_supported(q.model, q.o.D) || q.o.js_dense || q.o.Np < 2 || !q.o.msT) return hipErrorInvalidValue;
   switch (method) {
     case VGPA_ODE_EULER: return launch_sweep_m<VGPA_ODE_EULER>(q, st);
     case VGPA_ODE_HEUN: return launch_sweep_m<VGPA_ODE_HEUN>(q, st);

@@ -208,9 +208,10 @@ __host__ __device__ constexpr bool cover_diagonals_in_loop_units() {
 }
 static_assert(cover_diagonals_in_loop_units(), "single-chain loop units: every diagonal block in slot 2 of a triangle wave, slot 2 of the rectangle wave unused");
 
-template <int NB_>
+template <int NB_, int NW_ = 4>      // NW: waves per workgroup (4: two workgroups per CU; 8: one problem per CU, see k_ode_sym)
 struct SGeo {
   static constexpr int NB = NB_;
+  static constexpr int NW = NW_, NT = 64 * NW_;
   static constexpr int P = 4 * NB;                 // padded to 4x4 blocks
   static constexpr int NSB = (NB + 1) / 2;         // 8x8 super-blocks per dimension
   static constexpr int KKE = 2 * NSB;              // k-steps (4 rows each), even
@@ -224,19 +225,19 @@ struct SGeo {
   static constexpr int MAXS = 2 * NR;              // unit slots per wave
   // vector recursion
   static constexpr int XV = PP + 4;                // one copy of the stage vector per wave
-  static constexpr int NPARTF = cmin(256 / PP, RP);          // forward: lane = (column i, part of the row pairs)
+  static constexpr int NPARTF = cmin(NT / PP, RP);          // forward: lane = (column i, part of the row pairs)
   static constexpr int RPP = cdiv(RP, NPARTF);
   static constexpr int NPF = cmin(NPARTF, cdiv(RP, RPP));    // parts that hold a sum
   static constexpr int NCB = PP / 4;                         // backward: lane = (row pair, part of the 4-column blocks)
-  static constexpr int NPARTB = cmin(256 / RP, NCB);
+  static constexpr int NPARTB = cmin(NT / RP, NCB);
   static constexpr int CBP = cdiv(NCB, NPARTB);
   static constexpr int NPART = cmax(NPF, NPARTB);
   static constexpr int PV = NPART * PP;
-  static constexpr int NIT = cdiv((P / 2) * P, 256);         // row-pair items per thread (column fastest)
+  static constexpr int NIT = cdiv((P / 2) * P, NT);         // row-pair items per thread (column fastest)
   static constexpr int NTILE = cdiv(P / 2, 8) * cdiv(P, 8);  // forward staging: 8 x 8 tiles of (row pair, column)
-  static constexpr int NITF = cdiv(NTILE, 4);
-  static constexpr size_t LDS_DOUBLES = (size_t)4 * XS + 4 * XV + 2 * PV + 2 * 256;
-  static_assert(NPARTF >= 1 && NPARTB >= 1, "dimension too large for 256 threads");
+  static constexpr int NITF = cdiv(NTILE, NW);
+  static constexpr size_t LDS_DOUBLES = (size_t)4 * XS + NW * XV + 2 * PV + 2 * NT;
+  static_assert(NPARTF >= 1 && NPARTB >= 1, "dimension too large for the workgroup");
 };
 
 // element (k, c) of a buffer
@@ -251,20 +252,20 @@ __host__ __device__ constexpr int unit_off(int p, int c) {
 }
 
 // row-pair items, column fastest over the threads: the HBM side of the state stores and of the backward operand staging
-template <int NB>
+template <int NB, int NW = 4>
 struct ItemTab {
-  static constexpr int NIT = SGeo<NB>::NIT;
+  static constexpr int NIT = SGeo<NB, NW>::NIT;
   int lo[NIT];          // unit offset inside a buffer, or -1
   unsigned g0[NIT];     // byte offset of element (2p, c) in a D x D matrix
   unsigned g1[NIT];     // ... of element (2p+1, c); = g0 when that row does not exist (the value is dropped)
   bool two[NIT];        // row 2p+1 exists
 };
-template <int NB>
-__device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB>& T) {
-  using g = SGeo<NB>;
+template <int NB, int NW>
+__device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB, NW>& T) {
+  using g = SGeo<NB, NW>;
 #pragma unroll
   for (int q = 0; q < g::NIT; q++) {
-    const int e = tid + 256 * q;
+    const int e = tid + g::NT * q;
     const int p = e / g::P, c = e - p * g::P;
     const bool ok = 2 * p < D && c < D;
     T.lo[q] = ok ? unit_off<NB>(p, c) : -1;
@@ -276,20 +277,20 @@ __device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB>& T) {
 
 // forward operand staging (operand = A^T: unit (sp, so) = A[so][2sp], A[so][2sp+1]) in 8 x 8 tiles: the 8 lanes of a
 // ds_write_b128 group store 8 consecutive columns of one row pair (conflict-free), a wave reads 8 rows x 128 contiguous bytes
-template <int NB>
+template <int NB, int NW = 4>
 struct TileTab {
-  static constexpr int NIT = SGeo<NB>::NITF;
+  static constexpr int NIT = SGeo<NB, NW>::NITF;
   int lo[NIT];
   unsigned g0[NIT], g1[NIT];   // byte offsets of A[so][2sp], A[so][2sp+1] (g1 = g0 when column 2sp+1 does not exist)
   bool two[NIT];
 };
-template <int NB>
-__device__ __forceinline__ void build_tiles(int D, int wave, int lane, TileTab<NB>& T) {
-  using g = SGeo<NB>;
+template <int NB, int NW>
+__device__ __forceinline__ void build_tiles(int D, int wave, int lane, TileTab<NB, NW>& T) {
+  using g = SGeo<NB, NW>;
   constexpr int nsot = cdiv(g::P, 8);
 #pragma unroll
   for (int q = 0; q < g::NITF; q++) {
-    const int tile = wave + 4 * q;
+    const int tile = wave + NW * q;
     const int spt = tile / nsot, sot = tile - spt * nsot;
     const int sp = 8 * spt + (lane >> 3), so = 8 * sot + (lane & 7);
     const bool ok = 2 * sp < D && so < D;
@@ -309,19 +310,30 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // use of ANY value loaded in the previous iteration becomes s_waitcnt vmcnt(0) -- it waits for every load and store issued so
 // far.  So a step issues all its HBM loads at ONE point (behind the staging of stage min(1, NS-1): A, the forcing terms, the
 // jumps of two steps ahead) and consumes them at ONE point (the rotation at the top of the next step, >= 1 stage later).
-template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false>   // WPE: waves per SIMD the register budget allows for
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
+// NW = 8 (round 4 experiment; fragment cover only; opt-in, see eight_waves()): ONE problem per CU on EIGHT waves -- wave w and wave w + 4 (same SIMD) split the four units
+// of cover wave w at its half-step boundary: units (a0, b0), (a0, b1) | units (a1, b0), (a1, b1).  Each wave multiplies 40 instead of
+// 70 products per stage (both chains of every unit: the loop units' single-chain trick would make the two halves different
+// instruction streams), owns half the elements and does half the chores, so the per-stage latency chain of a lone problem --
+// products, stepper, publish, barrier, first fragments: ~2 300 cycles with four waves -- loses most of its product share.  For
+// batches up to one problem per CU (the reference's own use case is ONE optimisation); larger batches keep two four-wave
+// workgroups per CU, whose 256 registers per wave an eight-wave workgroup pair cannot have.
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4>   // WPE: waves per SIMD the register budget allows for
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using g = SGeo<NB>;
-  constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = g::MAXS, LD = g::LD, NKP = g::NKP;
+  using g = SGeo<NB, NW>;
+  constexpr bool W8 = (NW == 8);
+  constexpr int NT = g::NT;
+  constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = W8 ? 2 : g::MAXS, LD = g::LD, NKP = g::NKP;
   constexpr bool COVER = (GR == 0);      // fragment cover (NSB = 5) instead of runs: see kCoverMaps
-  constexpr bool LOOP1 = COVER && VGPA_SYM_LOOP1;      // single-chain loop units: see kCoverLoopSlot
-  static_assert(!COVER || (g::NSB == 5 && MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
+  constexpr bool LOOP1 = COVER && VGPA_SYM_LOOP1 && !W8;      // single-chain loop units: see kCoverLoopSlot
+  static_assert(!COVER || (g::NSB == 5 && g::MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
+  static_assert(!W8 || COVER, "eight waves per problem: fragment-cover kernels only");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
   constexpr double sixth = 1.0 / 6.0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave & 3, half = W8 ? (wave >> 2) : 0;      // cover wave whose units this wave multiplies; which half of them (W8)
   const int prob = (int)blockIdx.x;
   const int D = a.D, Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
   const double dt = a.dt, h = 0.5 * a.dt;
@@ -330,9 +342,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   double* const Rb = Xb1 + g::XS;
   double* const Mb = Rb + g::XS;
   double* const xvw = Mb + g::XS + wave * g::XV;           // this wave's copy of the stage vector
-  double* const pvb = Mb + g::XS + 4 * g::XV;              // [2][NPART][PP] partial inner products
+  double* const pvb = Mb + g::XS + NW * g::XV;             // [2][NPART][PP] partial inner products
   double* const trash = pvb + 2 * g::PV + 2 * tid;         // one 16-byte unit per thread
-  for (int i = tid; i < (int)g::LDS_DOUBLES; i += 256) smem[i] = 0.0;
+  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
   // QOUT (backward, mid-point methods, Sigma = sigma^2 I): the state store writes Q''_t = A_t / sigma^2 - 2 Psi_t in place of Psi_t --
   // the only combination of A_t and Psi_t the gradient assembly reads (assemble.hip), which then streams one matrix less.  (A
   // general diagonal would need its entries per row pair here: with them the kernel no longer fits its 256 registers.)
@@ -346,18 +358,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   int colm[4] = {0, 0, 0, 0};            // cover: LDS column offset of this lane's fragment element, per map
   unsigned gofs[MAXS];
   bool own[MAXS], wd[MAXS], wm[MAXS];
-  const int cov_used = COVER ? kCoverUsed[wave] : 0;
+  const int cov_used = COVER ? kCoverUsed[wq] : 0;
   const bool loop_diag = r4 == c4;                     // diagonal element of a diagonal block (loop unit)
   const int loop_src = 16 * c4 + 4 * bq + r4;          // the lane that holds element (c4, r4) of the same block
   if constexpr (COVER) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * kCoverMaps[wave][m][bq] + c4) ^ r4);
+    for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * kCoverMaps[wq][m][bq] + c4) ^ r4);
 #pragma unroll
     for (int s = 0; s < MAXS; s++) {
-      const int Ib = kCoverMaps[wave][kCoverPat[s][0]][bq], Jb = kCoverMaps[wave][kCoverPat[s][1]][bq];
+      const int so = W8 ? 2 * half + s : s;                       // unit slot of the cover wave
+      const int Ib = kCoverMaps[wq][kCoverPat[so][0]][bq], Jb = kCoverMaps[wq][kCoverPat[so][1]][bq];
       const int row = 4 * Ib + r4, col = 4 * Jb + c4;
-      const bool first = (kCoverOwner.m[wave][s] >> bq) & 1u;     // (a compile-time table, looked up with the run-time wave / block)
-      const bool act = ((cov_used >> s) & 1) && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
+      const bool first = (kCoverOwner.m[wq][so] >> bq) & 1u;      // (a compile-time table, looked up with the run-time wave / block)
+      const bool act = ((cov_used >> so) & 1) && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
       offD[s] = elem_off<NB>(row, col);
       offM[s] = elem_off<NB>(col, row);
       wd[s] = act;
@@ -395,10 +408,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     }
   }
   }
-  ItemTab<NB> IT;
-  build_items<NB>(D, tid, IT);
-  TileTab<NB> TT;
-  if (FWD) build_tiles<NB>(D, wave, lane, TT);
+  ItemTab<NB, NW> IT;
+  build_items<NB, NW>(D, tid, IT);
+  TileTab<NB, NW> TT;
+  if (FWD) build_tiles<NB, NW>(D, wave, lane, TT);
 
   // ---- operand staging --------------------------------------------------------------------------------------------------
   const double* A = a.A + (size_t)prob * a.strideA;
@@ -665,7 +678,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   // the group boundary (the next group's first fragments are on their way while this group's stepper runs) and across the
   // STAGE boundary: product_begin requests step 0 of the next stage right behind the barrier, in front of the vector work.
   constexpr int GRR = COVER ? 1 : GR;            // (array extents of the run layout; unused under the cover)
-  constexpr int NG = COVER ? 1 : cdiv(NR, GRR), NSL = COVER ? 4 : 2 * GRR, NSTEP = NG * NKP;
+  constexpr int NG = COVER ? 1 : cdiv(NR, GRR), NSL = COVER ? (W8 ? 2 : 4) : 2 * GRR, NSTEP = NG * NKP;
   static_assert(COVER || NR % GRR == 0, "a group of runs must be complete (the clamped tail group is not parity-clean)");
   d2_t fa1[2][GRR], fa2[2][GRR], fb1[2][COVER ? 1 : NSL], fb2[2][COVER ? 1 : NSL];
   // cover: fragments of the row-side maps a0, a1 (ONE buffer each: a0 is dead behind the first half of a step, a1 is not needed
@@ -679,10 +692,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 #ifndef VGPA_SYM_HALF_BWD
 #define VGPA_SYM_HALF_BWD 1
 #endif
-  constexpr bool HALF = COVER && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
+  constexpr bool HALF = COVER && !W8 && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
+  // W8: three maps per wave -- row side a0 (first half) or a1 (second half), column side b0, b1 -- of both operands, two buffers
+  d2_t fA8[2][W8 ? 3 : 1], fX8[2][W8 ? 3 : 1];
+  const int col8[3] = {half ? colm[1] : colm[0], colm[2], colm[3]};
+  auto frag8 = [&](int buf, int kp, const double* pa, const double* px) {
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      fA8[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + col8[m]);
+      fX8[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + col8[m]);
+    }
+  };
   d2_t fAa[COVER ? 2 : 1], fXa[COVER ? 2 : 1], fAb[2][COVER ? 2 : 1], fXb[2][COVER ? 2 : 1];
   d2_t fAa1[2], fXa1[2];                 // HALF + interleave: map a1 in two buffers (read half a step earlier than it is free)
-  d2_t fA[2][(COVER && !HALF) ? 4 : 1], fX[2][(COVER && !HALF) ? 4 : 1];
+  d2_t fA[2][(COVER && !HALF && !W8) ? 4 : 1], fX[2][(COVER && !HALF && !W8) ? 4 : 1];
   auto frag_all = [&](int buf, int kp, const double* pa, const double* px) {
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -709,7 +732,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     if constexpr (COVER) {
       // (only the first step of a stage comes through here: every other fragment is requested inside the step before it)
       const int kp = t % NKP;
-      if constexpr (HALF) {
+      if constexpr (W8) {
+        frag8(buf, kp, pa, px);
+      } else if constexpr (HALF) {
         frag_a(0, kp, pa, px);
         frag_b(buf, kp, pa, px);
         if (VGPA_SYM_INTERLEAVE) frag_a1(buf, kp, pa, px);
@@ -794,7 +819,27 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         // then X^T A of the first k-step of the pair, then of the second): same bits.  Straight-line code: a branch inside the
         // pipeline would end the scheduling region (the rectangle wave multiplies its unused fourth unit too; the triangle waves
         // read map a1 twice -- the LDS array is not what bounds this kernel, the exposed latency of its reads was).
-        if constexpr (!HALF) {
+        if constexpr (W8) {
+          // eight waves: unit u = (this half's row-side map, column-side map b_u), both chains; the six reads of the next step
+          // between the eight products
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < NSTEP) frag8(cur ^ 1, (t + 1) % NKP, pa, px);
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fA8[cur][0][hh], fX8[cur][1 + u][hh], w[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; u++) w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(fX8[cur][0][hh], fA8[cur][1 + u][hh], w[u], 0, 0, 0);
+          }
+          if (t + 1 < NSTEP) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one matrix-core product
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (!HALF) {
           // forward: unit u = (row-side map u >> 1, column-side map 2 + (u & 1)); eight products, the eight reads of the next
           // step, eight products
 #if VGPA_SYM_INTERLEAVE
@@ -978,9 +1023,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
   constexpr bool SPB = SPLIT && (FWD ? VGPA_SYM_SPLIT_B_FWD : VGPA_SYM_SPLIT_B_BWD);
   constexpr bool SPC = SPLIT && (FWD ? VGPA_SYM_SPLIT_C_FWD : VGPA_SYM_SPLIT_C_BWD);
   constexpr int TBU = NSTEP >= 5 ? NSTEP / 4 + 1 : (NSTEP > 1 ? 1 : 0), TCU = NSTEP >= 5 ? NSTEP / 2 + 1 : LAST;   // unsplit slots
-  constexpr int SA_F = 0, SA_R = SPA ? -1 : SA_F;
-  constexpr int SB_F = SPLIT ? cmin(1, LAST) : TBU, SB_R = SPB ? 0 : SB_F;
-  constexpr int SC_F = SPLIT ? cmin(2, LAST) : TCU, SC_R = SPC ? cmin(1, LAST) : SC_F;
+  // (W8: a pipeline step is eight products = 128 cycles, shorter than an LDS round trip under load: every chore's read and
+  //  finish are TWO steps apart, and the vector's partial products -- which read what the vector update wrote -- come last)
+  constexpr int SA_F = W8 ? cmin(1, LAST) : 0, SA_R = (SPA || W8) ? -1 : SA_F;
+  constexpr int SB_F = W8 ? LAST : (SPLIT ? cmin(1, LAST) : TBU), SB_R = W8 ? cmin(2, LAST) : (SPB ? 0 : SB_F);
+  constexpr int SC_F = W8 ? cmin(3, LAST) : (SPLIT ? cmin(2, LAST) : TCU), SC_R = W8 ? 0 : (SPC ? cmin(1, LAST) : SC_F);
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
 #pragma unroll
@@ -1046,6 +1093,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 }
 
 
+// Eight waves per problem (k_ode_sym, NW = 8) are an EXPERIMENT kept reachable: VGPA_SYM_WAVES=8 in the environment selects them
+// (tools/ab_waves.sh, tests).  They measured slower than four waves at every batch size -- the product phase is bound by the LDS
+// fragment traffic as much as by the matrix pipe, and the split raises the fragment reads per product from 0.5 to 0.75.
+inline bool eight_waves(int batch) {
+  static const int forced = [] { const char* e = getenv("VGPA_SYM_WAVES"); return e ? atoi(e) : 0; }();
+  (void)batch;
+  return forced == 8;      // measured slower at every batch size (EXPERIMENTS.md s.9): opt-in only
+}
+
 template <int METHOD, bool FWD, int NB>
 hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr size_t lds = SGeo<NB>::LDS_DOUBLES * sizeof(double);
@@ -1058,6 +1114,23 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
   if constexpr (can_cover) {
+    if (!runs_only && !dense && eight_waves(a.batch)) {
+      // up to one problem per CU: eight waves per problem (k_ode_sym, NW = 8), two per SIMD, all 256 registers each
+      constexpr size_t lds_8 = SGeo<NB, 8>::LDS_DOUBLES * sizeof(double);
+      static_assert(lds_8 <= 160 * 1024, "LDS budget");
+      if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
+        if (a.q_on) {
+          auto kq8 = k_ode_sym<METHOD, FWD, NB, false, 0, 2, true, 8>;
+          (void)hipFuncSetAttribute((const void*)kq8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+          hipLaunchKernelGGL(kq8, dim3(a.batch), dim3(512), lds_8, st, a);
+          return hipGetLastError();
+        }
+      }
+      auto k8 = k_ode_sym<METHOD, FWD, NB, false, 0, 2, false, 8>;
+      (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_8);
+      hipLaunchKernelGGL(k8, dim3(a.batch), dim3(512), lds_8, st, a);
+      return hipGetLastError();
+    }
     if (!runs_only) {
       constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
       constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;

@@ -63,6 +63,10 @@ struct vgpa_ctx {
   double obs_const = 0.0, sigma1 = 1.0;
   bool have_state = false;
   bool derived_valid = true;     // dEsde_dm / dEsde_dS / <f> / E_sde(t) / lam / Psi belong to the cached (m, S): false behind a fused lane pass
+  double* d_msT = nullptr;       // fused lane pass: the moments time-major, problem fastest (OdeArgs::msT), [Np][D*D + D][bpad]
+  double* d_jmT = nullptr;       // ... and its sparse vector jumps, [M][D][bpad]
+  int bpad = 0;
+  bool ms_valid = true;          // d_m / d_S hold the cached moments (false: only d_msT does; untransposed on demand)
   bool sym_units = false;        // stepping-kernel family of this context (pick_kernel_family)
   // profiling
   bool prof = false;
@@ -246,6 +250,7 @@ struct LdBatch {
 
 static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double* Sigma, bool sym) {
   ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
+  c->ms_valid = true;                  // (every path below writes the [B][Np] arrays m / S)
   if (c->D > kMaxSmallD) {
     int rc = ensure_ld_ws(c);
     if (rc) return rc;
@@ -502,6 +507,7 @@ static int run_lane_pass(vgpa_ctx* c, double* g_dev) {
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S;
+  a.msT = c->d_msT; a.bpad = c->bpad; a.jmT = c->d_jmT;
   a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M;
   q.model = c->cfg.model; q.want_grad = g_dev ? 1 : 0;
   for (int i = 0; i < kMaxTheta; i++) q.theta[i] = c->theta[i];
@@ -521,9 +527,23 @@ static int enqueue_lane_sweep(vgpa_ctx* c, double* g_dev) {
   prof_collect(c);
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
   prof_mark(c, 0);
-  if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
+  if (!c->d_msT) {
+    c->bpad = 64 * ((c->B + 63) / 64);
+    if ((rc = dev_alloc(c, &c->d_msT, (size_t)c->Np * (c->DD + c->D) * c->bpad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_jmT, (size_t)(c->M > 0 ? c->M : 1) * c->D * c->bpad))) return rc;
+  }
+  {
+    OdeArgs a{};
+    a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
+    a.strideA = a.strideB = c->len_x;
+    a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = c->d_m0; a.S0 = c->d_S0; a.Sigma = c->d_Sigma; a.m = c->d_m; a.S = c->d_S;
+    a.msT = c->d_msT; a.bpad = c->bpad;
+    hipError_t ef = launch_ode_small(c->cfg.method, true, a, c->stream);
+    if (ef != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "forward lane kernel launch failed: %s", hipGetErrorString(ef));
+  }
+  c->ms_valid = false;
   prof_mark(c, 1);
-  hipError_t e = launch_obs(obs_args(c), c->stream);
+  hipError_t e = launch_obs_lane(obs_args(c), c->d_msT, c->bpad, c->d_jmT, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
   prof_mark(c, 2);
   if ((rc = run_lane_pass(c, g_dev))) return rc;
@@ -535,9 +555,22 @@ static int enqueue_lane_sweep(vgpa_ctx* c, double* g_dev) {
 }
 
 // what vgpa_fetch wants of the arrays the fused lane pass never wrote: the separate kernels over the cached (m, S)
+static int materialize_moments(vgpa_ctx* c) {
+  if (c->ms_valid) return VGPA_OK;
+  hipError_t e = launch_ms_untranspose(c->D, c->Np, c->B, c->bpad, c->d_msT, c->d_m, c->d_S, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "moment untranspose launch failed: %s", hipGetErrorString(e));
+  c->ms_valid = true;
+  return VGPA_OK;
+}
+
 static int materialize_derived(vgpa_ctx* c) {
   if (c->derived_valid) return VGPA_OK;
   int rc;
+  if ((rc = materialize_moments(c))) return rc;
+  {      // the separate backward kernel reads the jumps in the [B][M][D] layout: the observation kernel over the [B][Np] moments
+    hipError_t e = launch_obs(obs_args(c), c->stream);
+    if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "obs launch failed: %s", hipGetErrorString(e));
+  }
   if ((rc = run_energy(c, nullptr, false))) return rc;
   if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
   c->derived_valid = true;
@@ -885,6 +918,7 @@ int vgpa_energy_full(vgpa_ctx* c, const double* lin_a, const double* off_b, cons
     if ((rc = dev_alloc(c, &c->d_hypT, (size_t)c->B * H))) return rc;
   }
   if ((rc = ingest_ab(c, lin_a, off_b))) return rc;
+  c->ms_valid = true;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
@@ -940,6 +974,7 @@ int vgpa_obs_energy(vgpa_ctx* c, const double* mt, const double* st, double* eob
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t BN = (size_t)c->B * c->Np;
   int rc;
+  c->ms_valid = true;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   ObsArgs a = obs_args(c);
@@ -1075,6 +1110,7 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
   HIP_TRY(c, hipSetDevice(c->cfg.device));
   const size_t BN = (size_t)c->B * c->Np;
   int rc = VGPA_OK;
+  if ((rc = materialize_moments(c))) return rc;
   if (which != VGPA_FETCH_MT && which != VGPA_FETCH_ST && which != VGPA_FETCH_EDF && (rc = materialize_derived(c))) return rc;
   switch (which) {
     case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;

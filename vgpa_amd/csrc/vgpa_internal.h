@@ -53,6 +53,12 @@ struct OdeArgs {
   // `psi` receives Q''_t = q_scale A_t - 2 Psi_t (what the gradient assembly needs of A_t and Psi_t) instead of Psi_t
   int q_on;
   double q_scale;
+  // lane-per-problem kernels of the fused small-D sweep (ode_small.hip): the moments in a layout the context owns, TIME-major with the
+  // problem fastest -- entry e (S row-major, then m) of grid point t of problem p at msT[(t * (D*D + D) + e) * bpad + p] -- so that a
+  // wave's 64 lanes read / write 512 contiguous bytes per entry straight from / into registers; nullptr: the [B][Np] arrays m / S
+  double* msT;
+  int bpad;
+  const double* jmT;     // sparse vector jumps in the same spirit: entry i of observation n of problem p at jmT[(n * D + i) * bpad + p]
 };
 
 // Fused lane-per-problem pass of the models with closed-form moments (OU, double well, Lorenz-63; ode_small.hip::k_sweep_lane):
@@ -142,6 +148,10 @@ hipError_t launch_ode_generic(int method, bool fwd, const OdeArgs& a, hipStream_
 hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t st);     // D <= kMaxLaneD
 bool sweep_lane_supported(int model, int D);
 hipError_t launch_sweep_lane(int method, const LaneSweepArgs& a, hipStream_t st);
+// msT -> the [B][Np] arrays: all grid points (vgpa_fetch, the separate kernels) or only what the observation terms read
+hipError_t launch_ms_untranspose(int D, int Np, int batch, int bpad, const double* msT, double* m, double* S, hipStream_t st);
+// observation terms (E_obs, sparse vector jumps) of the fused lane pass: one lane per problem, moments from msT, jumps to jmT
+hipError_t launch_obs_lane(const ObsArgs& a, const double* msT, int bpad, double* jmT, hipStream_t st);
 hipError_t launch_ode_wave(int method, bool fwd, const OdeArgs& a, hipStream_t st);      // 2 <= D <= kMaxLaneD, few problems
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
