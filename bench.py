@@ -208,7 +208,7 @@ def config2_block(args, local_rank):
                                       "fused E_sde + bwd + grad + F (k_sweep_lane)": 1e3 * bwd_s},
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "alg_bytes_per_sweep": alg, "alg_bytes_per_step": alg * B,
-                             "traffic": tj.get(f"config2_sweep_B{B}"),
+                             "traffic": tj.get(f"L63_sweep_B{B}"),
                              "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_small.sh; not measured in this run)",
                              "kernels": {"k_fwd_lane": {"launch_ms": 1e3 * fwd_s, "alg_GBs": 8.0 * n_pts * (2 * d * d + 2 * d) * B / fwd_s / 1e9},
                                          "k_sweep_lane": {"launch_ms": 1e3 * bwd_s, "alg_GBs": 8.0 * n_pts * (3 * d * d + 4 * d) * B / bwd_s / 1e9}}},

@@ -8,5 +8,5 @@ rocprofv3 --pmc WRITE_SIZE -d gpurun_out/ps_write -- python3 tools/bench_small_c
 S=$(find gpurun_out/ps_stats -name "*results.db" | head -1); F=$(find gpurun_out/ps_fetch -name "*results.db" | head -1); W=$(find gpurun_out/ps_write -name "*results.db" | head -1)
 python3 tools/rocprof_db.py stats $S gpurun_out/${TAG}_small_${MODEL}_B${BATCH}_kernel_stats.csv
 cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
-python3 tools/rocprof_db.py traffic_all $F $W gpurun_out/${TAG}_small_${MODEL}_B${BATCH}_pmc_fetch_write.csv "python tools/bench_small_configs.py $BATCH $MODEL" gpurun_out/pmc_traffic.json config2_sweep_B${BATCH} "k_fwd_lane|k_obs|k_sweep_lane"
+python3 tools/rocprof_db.py traffic_all $F $W gpurun_out/${TAG}_small_${MODEL}_B${BATCH}_pmc_fetch_write.csv "python tools/bench_small_configs.py $BATCH $MODEL" gpurun_out/pmc_traffic.json ${MODEL}_sweep_B${BATCH} "k_fwd_lane|k_obs|k_sweep_lane"
 rm -rf gpurun_out/ps_stats gpurun_out/ps_fetch gpurun_out/ps_write
