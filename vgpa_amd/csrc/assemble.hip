@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(NT) k_obs(ObsArgs a) {
   __shared__ double red[NT];
   const int D = a.D, M = a.n_obs, prob = blockIdx.x, tid = threadIdx.x;
   const double* m = a.m + (size_t)prob * a.Np * D;
-  const double* S = a.S + (size_t)prob * a.Np * D * D;
+  const int MS = a.s_packed ? tri_off(D) : D * D;          // doubles per stored S_t (packed lower triangle: OdeArgs::s_packed)
+  const double* S = a.S + (size_t)prob * a.Np * MS;
   double* jm = a.jm_sparse + (size_t)prob * M * D;
   double part = 0.0;
   if (a.single) {
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(NT) k_obs(ObsArgs a) {
     }
     jm[u] = -krow;
     // Q4: the covariance diagonal is taken at index n (observation counter), not at t_n
-    part += (y[i] - mt[i]) * qrow + a.rinv_diag[i] * S[((size_t)n * D + i) * D + i];
+    part += (y[i] - mt[i]) * qrow + a.rinv_diag[i] * S[(size_t)n * MS + (a.s_packed ? tri_off(i) + i : i * D + i)];
   }
   const double tot = block_sum(part, red);
   if (tid == 0) a.eobs[prob] = 0.5 * (tot + a.obs_const);
@@ -429,18 +430,29 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
       ig[q] = e < DD ? a.isig[i * D + i] : 0.0;
     }
   }
+  // packed S_t (GradArgs::s_packed): this thread's flat indices e = tid + q NT of the lower triangle and their (row, column)
+  const bool spk = a.s_packed != 0;
+  const int PK = tri_off(D);
+  int pi[EPT], pj[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; q++) {
+    const int e = tid + q * NT;
+    pi[q] = tri_row(e < PK ? e : 0);
+    pj[q] = (e < PK ? e : 0) - tri_off(pi[q]);
+  }
   auto request = [&](int t) {
     const size_t o = (size_t)prob * a.Np + t;
     const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * DD;
-    const double* St = a.S + o * DD;
+    const double* St = a.S + o * (spk ? PK : DD);
     const double* Pt = a.psi + o * DD;
     const double* Edf = a.Edf ? a.Edf + o * DD : nullptr;
     (void)At; (void)Edf;
+    const int ns = spk ? PK : DD;
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
       const int e = tid + q * NT;
       const bool in = e < DD;
-      sv[q] = in ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0;
+      sv[q] = e < ns ? St[e] : 0.0; pv[q] = in ? Pt[e] : 0.0;
       if constexpr (!QMODE) { av[q] = in ? At[e] : 0.0; ev[q] = (in && Edf) ? Edf[e] : 0.0; }
     }
     v_m = vt ? a.m[o * D + tid] : 0.0;
@@ -484,9 +496,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
       const int e = tid + q * NT;
+      if (spk && e < PK) { Ss[pi[q] * LD + pj[q]] = sv[q]; Ss[pj[q] * LD + pi[q]] = sv[q]; }      // both triangles from the packed lower one
       if (e < DD) {
         const int i = (int)(((unsigned)e * magic) >> 20), j = e - i * D;
-        Ss[i * LD + j] = sv[q];
+        if (!spk) Ss[i * LD + j] = sv[q];
         // (QMODE: the backward kernel left Q''_t = Sigma^-1 A_t - 2 Psi_t where Psi_t would be -- one stream less)
         if constexpr (QMODE) QT[j * LD + i] = pv[q];
         else QT[j * LD + i] = __builtin_fma(ig[q], has_edf ? ev[q] + av[q] : av[q], -2.0 * pv[q]);
@@ -666,6 +679,21 @@ __global__ void __launch_bounds__(NT) k_mirror_upper(int D, double* m) {
     const int i = e / D, j = e - i * D;
     if (i > j) q[e] = q[j * D + i];
   }
+}
+
+// packed lower triangle -> full symmetric matrix, one workgroup per matrix (vgpa_fetch and every consumer that wants S_t whole)
+__global__ void __launch_bounds__(NT) k_unpack_lower(int D, const double* __restrict__ packed, double* __restrict__ full) {
+  const double* src = packed + (size_t)blockIdx.x * tri_off(D);
+  double* dst = full + (size_t)blockIdx.x * D * D;
+  for (int e = threadIdx.x; e < D * D; e += NT) {
+    const int i = e / D, j = e - i * D;
+    dst[e] = src[tri_idx(i, j)];
+  }
+}
+
+hipError_t launch_unpack_lower(size_t n_mat, int D, const double* packed, double* full, hipStream_t st) {
+  hipLaunchKernelGGL(k_unpack_lower, dim3((unsigned)n_mat), dim3(NT), 0, st, D, packed, full);
+  return hipGetLastError();
 }
 
 hipError_t launch_mirror_upper(size_t n_mat, int D, double* m, hipStream_t st) {

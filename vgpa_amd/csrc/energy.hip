@@ -558,6 +558,18 @@ __host__ __device__ inline size_t l96r_lds_doubles(int D) {
   return dp * l96_ld(D) + 6 * dp + 9 * dp;       // L + 6 vectors + scratch (4 + 4 partial rows, 1 row of G; later xdiag)
 }
 
+// row of flat index e of a packed lower triangle (D <= 64: e < 2080), as a table: the staging of a packed S_t looks its (row, column)
+// up instead of computing a square root per element
+struct TriRowTab { unsigned char r[2080]; };
+constexpr TriRowTab make_tri_row_tab() {
+  TriRowTab t{};
+  int e = 0;
+  for (int r = 0; r < 64; r++)
+    for (int c = 0; c <= r; c++) t.r[e++] = (unsigned char)r;
+  return t;
+}
+__device__ __constant__ TriRowTab kTriRow = make_tri_row_tab();
+
 #ifdef VGPA_ENERGY_TRACE
 // diagnostic build only: cycles per phase of k_energy_l96_r summed over all waves (tools/trace_energy.py)
 __device__ unsigned long long g_energy_trace[16];
@@ -588,7 +600,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   double* gb2 = pw + 4 * Dp;         // [Dp] row D-1 of G (rows 0 and 1: S.dl, S.qq)
   double* xdiag = pv;                // phase 4 (the partial sums are dead by then)
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
-  const double* St = a.S + o * D * D;
+  const bool spk = a.s_packed != 0;                // S_t as its packed lower triangle (OdeArgs::s_packed): all the factorisation reads
+  const int PK = tri_off(D);
+  const double* St = a.S + o * (spk ? PK : D * D);
   const double theta = a.theta[0];
   const double kappa = 1.05 * D, c = D + kappa;
   const bool act = l < D;
@@ -622,8 +636,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   auto load_vectors = [&]() {
     if (act) {
       const int ip1 = wrap(l + 1, D), im1 = wrap(l - 1, D), im2 = wrap(l - 2, D);
-      sxa = St[ip1 * D + im1];
-      sxb = St[im2 * D + im1];
+      sxa = St[spk ? tri_idx(ip1, im1) : ip1 * D + im1];
+      sxb = St[spk ? tri_idx(im2, im1) : im2 * D + im1];
       v_m = a.m[o * D + l];
       v_b = a.b[(size_t)prob * a.strideB + (size_t)t * D + l];
       v_sg = a.isg[l];
@@ -632,7 +646,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
 
   // ---- stage c*S into LDS (coalesced); padding: identity.  Every HBM load of the wave (the vectors too) is requested
   //      before the first one is consumed: a lone wave pays each dependent round trip in full.  S_t's requests go first.
-  if (D == Dp) {
+  if (spk) {
+    // packed lower triangle: flat, fully coalesced loads (lane = double e of the triangle: 13 requests at D = 40 instead of 40
+    // row loads), each value to its (row, column) of the LDS matrix; the strict upper triangle is never read before the
+    // factorisation's pivots zero it (chol_panel_pivots)
+    constexpr int EPK = (Dp * (Dp + 1) / 2 + 63) / 64;
+    if (D != Dp) {
+      for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
+      wave_sync();
+    }
+    double sv[EPK];
+    int rr[EPK];
+#pragma unroll
+    for (int q = 0; q < EPK; q++) {
+      const int e = l + 64 * q;
+      sv[q] = e < PK ? St[e] : 0.0;
+      rr[q] = kTriRow.r[e < PK ? e : 0];
+    }
+    load_vectors();
+#pragma unroll
+    for (int q = 0; q < EPK; q++) {
+      const int e = l + 64 * q;
+      if (e < PK) S.Lm[rr[q] * LD + (e - tri_off(rr[q]))] = c * sv[q];
+    }
+  } else if (D == Dp) {
     // no padding (D = 40 of the headline): one row per load, lane = column -- every HBM and LDS offset is an immediate, no index
     // arithmetic per element; rows in flight per round trip are bounded by the registers (the A fragments are not in flight yet)
     constexpr int RCH = Dp <= 44 ? Dp : 32;

@@ -259,9 +259,10 @@ struct ItemTab {
   unsigned g0[NIT];     // byte offset of element (2p, c) in a D x D matrix
   unsigned g1[NIT];     // ... of element (2p+1, c); = g0 when that row does not exist (the value is dropped)
   bool two[NIT];        // row 2p+1 exists
+  bool st0[NIT], st1[NIT];   // the state store writes element (2p, c) / (2p+1, c): all that exist, or -- packed lower triangle -- c <= row
 };
 template <int NB, int NW>
-__device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB, NW>& T) {
+__device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB, NW>& T, bool packed_lower = false) {
   using g = SGeo<NB, NW>;
 #pragma unroll
   for (int q = 0; q < g::NIT; q++) {
@@ -272,6 +273,14 @@ __device__ __forceinline__ void build_items(int D, int tid, ItemTab<NB, NW>& T) 
     T.g0[q] = ok ? 8u * (unsigned)(2 * p * D + c) : 0u;
     T.two[q] = ok && 2 * p + 1 < D;
     T.g1[q] = T.two[q] ? T.g0[q] + 8u * (unsigned)D : T.g0[q];
+    T.st0[q] = ok; T.st1[q] = T.two[q];
+    if (packed_lower) {        // element (r, c), c <= r, at r (r + 1) / 2 + c
+      const int r0 = 2 * p, r1 = 2 * p + 1;
+      T.st0[q] = ok && c <= r0;
+      T.st1[q] = T.two[q] && c <= r1;
+      T.g0[q] = T.st0[q] ? 8u * (unsigned)(r0 * (r0 + 1) / 2 + c) : 0u;
+      T.g1[q] = T.st1[q] ? 8u * (unsigned)(r1 * (r1 + 1) / 2 + c) : 0u;
+    }
   }
 }
 
@@ -408,8 +417,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
     }
   }
   }
+  const bool spk = FWD && a.s_packed;                       // S_t leaves as its packed lower triangle (OdeArgs::s_packed)
+  const int MS = spk ? D * (D + 1) / 2 : DD;                // doubles per stored matrix
   ItemTab<NB, NW> IT;
-  build_items<NB, NW>(D, tid, IT);
+  build_items<NB, NW>(D, tid, IT, spk);
   TileTab<NB, NW> TT;
   if (FWD) build_tiles<NB, NW>(D, wave, lane, TT);
 
@@ -437,7 +448,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   };
   // ---- matrix state -----------------------------------------------------------------------------------------------------
   const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
-  double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * DD;
+  double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * (spk ? D * (D + 1) / 2 : DD);
   double xk[MAXS], acc[MAXS], fc[MAXS], fn[MAXS], fnn[MAXS];
 #pragma unroll
   for (int s = 0; s < MAXS; s++) {
@@ -489,13 +500,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   // S_k / Psi_t and m_k / lam_t of grid point t to HBM: the matrix from the stage buffer that holds it
   auto store_items = [&](const d2_t (&v)[g::NIT], int t) {
     if (VGPA_ABL_NOSTORE && t > 1) return;
-    double* so = mout + (size_t)t * DD;
+    double* so = mout + (size_t)t * MS;
 #pragma unroll
     for (int q = 0; q < g::NIT; q++) {
-      if (IT.lo[q] >= 0) {
-        stg(so, IT.g0[q], v[q][0]);
-        if (IT.two[q]) stg(so, IT.g1[q], v[q][1]);
-      }
+      if (IT.st0[q]) stg(so, IT.g0[q], v[q][0]);
+      if (IT.st1[q]) stg(so, IT.g1[q], v[q][1]);
     }
     if (wave == 0 && vl) stg(vout + vec(t), lane8, vk);
   };

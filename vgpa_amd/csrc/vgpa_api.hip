@@ -66,6 +66,8 @@ struct vgpa_ctx {
   double* d_msT = nullptr;       // fused lane pass: the moments time-major, problem fastest (OdeArgs::msT), [Np][D*D + D][bpad]
   double* d_jmT = nullptr;       // ... and its sparse vector jumps, [M][D][bpad]
   int bpad = 0;
+  bool s_packed = false;         // d_S holds packed lower triangles (OdeArgs::s_packed): the fused batched sweeps of the cover kernels
+  double* d_Sfull = nullptr;     // ... and their unpacked copy, made when vgpa_fetch (or a kernel that wants S_t whole) asks
   bool ms_valid = true;          // d_m / d_S hold the cached moments (false: only d_msT does; untransposed on demand)
   bool sym_units = false;        // stepping-kernel family of this context (pick_kernel_family)
   // profiling
@@ -266,6 +268,7 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
   a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.b = ctx_b(c); a.m0 = m0; a.S0 = S0; a.Sigma = Sigma; a.m = c->d_m; a.S = c->d_S;
+  a.s_packed = c->s_packed ? 1 : 0;
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, true, a, c->stream)
                  : use_wave(c) ? launch_ode_wave(c->cfg.method, true, a, c->stream)
                  : use_mfma(c, true, sym) ? launch_ode_mfma(c->cfg.method, true, a, c->stream)
@@ -317,6 +320,7 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
 static EnergyArgs energy_args(vgpa_ctx* c, double* edf, bool ds_upper = false) {
   EnergyArgs a{};
   a.ds_upper = ds_upper ? 1 : 0;
+  a.s_packed = c->s_packed ? 1 : 0;
   a.model = c->cfg.model; a.D = c->D; a.Np = c->Np; a.batch = c->B; a.dt = c->cfg.dt;
   for (int i = 0; i < kMaxTheta; i++) a.theta[i] = c->theta[i];
   a.sigma1 = c->sigma1; a.isg = c->d_isg;
@@ -366,6 +370,7 @@ static ObsArgs obs_args(vgpa_ctx* c) {
   a.obs_t = c->d_obs_t; a.obs_y = c->d_obs_y; a.Q = c->d_Q; a.K = c->d_K; a.rinv_diag = c->d_rinv;
   a.obs_const = c->obs_const; a.m = c->d_m; a.S = c->d_S; a.jm_sparse = c->d_jm; a.eobs = c->d_eobs;
   a.diag = c->obs_diag ? 1 : 0; a.part = c->d_obs_part;
+  a.s_packed = c->s_packed ? 1 : 0;
   return a;
 }
 
@@ -378,6 +383,8 @@ static int run_reduce(vgpa_ctx* c) {
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "reduce launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;
 }
+
+static int unpack_S(vgpa_ctx* c, const double** full);
 
 static int run_grad(vgpa_ctx* c, double* g_dev) {
   if (c->D > kMaxSmallD) {
@@ -401,6 +408,13 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.isig = c->d_isig; a.A = ctx_A(c); a.b = ctx_b(c); a.m = c->d_m; a.S = c->d_S; a.lam = c->d_lam; a.psi = c->d_psi;
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
   a.psi_is_q = c->psi_is_q ? 1 : 0;
+  a.s_packed = (c->s_packed && c->psi_is_q) ? 1 : 0;
+  if (c->s_packed && !c->psi_is_q) {      // (an assembly kernel that wants S_t whole: cannot happen while s_packed_ok mirrors run_bwd's choice)
+    const double* full = nullptr;
+    int rc = unpack_S(c, &full);
+    if (rc) return rc;
+    a.S = full;
+  }
   a.Am = c->d_Am;                                  // written by the L96 energy kernel of the same sweep (else null)
   a.scalar_product = (c->cfg.flags & VGPA_FLAG_FORCE_GENERIC) ? 1 : 0;
   hipError_t e = launch_grad(a, c->stream);
@@ -475,6 +489,7 @@ static int enqueue_stream_sweep(vgpa_ctx* c, double* g_dev) {
   int rc;
   prof_collect(c);
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
+  c->s_packed = false;
   prof_mark(c, 0);
   if ((rc = run_fwd(c, c->d_m0, c->d_S0, c->d_Sigma, c->sym_inputs))) return rc;
   prof_mark(c, 1);
@@ -577,6 +592,29 @@ static int materialize_derived(vgpa_ctx* c) {
   return VGPA_OK;
 }
 
+// S_t as its packed lower triangle between the kernels of a fused sweep: exactly where the gradient assembly will be k_grad_mfma_q
+// (the condition of run_bwd's Q'' stream: fragment-cover kernels, 33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I, Lorenz-96) and the
+// energy terms come from k_energy_l96_r; VGPA_S_PACKED=0 in the environment keeps whole matrices (comparison runs)
+static bool s_packed_ok(vgpa_ctx* c) {
+  static const bool off = [] { const char* e = getenv("VGPA_S_PACKED"); return e && e[0] == '0'; }();
+  return !off && c->sym_units && !use_lane(c) && !use_wave(c) && use_mfma(c, false, c->sym_inputs) && use_mfma(c, true, c->sym_inputs) &&
+         c->sigma_diag && c->isg_iso && c->cfg.model == VGPA_MODEL_L96 && !(c->cfg.flags & (VGPA_FLAG_KEEP_PSI | VGPA_FLAG_FORCE_GENERIC)) &&
+         sym_stores_q(c->cfg.method, c->D) && !c->hyp_on && c->D <= kMaxSmallD;
+}
+
+// consumers that want S_t whole (vgpa_fetch, the operator-level kernels): the unpacked copy
+static int unpack_S(vgpa_ctx* c, const double** full) {
+  *full = c->d_S;
+  if (!c->s_packed) return VGPA_OK;
+  const size_t BN = (size_t)c->B * c->Np;
+  int rc;
+  if ((rc = ensure(c, &c->d_Sfull, BN * c->DD))) return rc;
+  hipError_t e = launch_unpack_lower(BN, c->D, c->d_S, c->d_Sfull, c->stream);
+  if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "unpack launch failed: %s", hipGetErrorString(e));
+  *full = c->d_Sfull;
+  return VGPA_OK;
+}
+
 // fwd -> E_obs -> E_sde terms -> bwd -> F     (VarGP.free_energy, variational.py:141-200)
 static int enqueue_free_energy(vgpa_ctx* c) {
   if (c->stream_ld) return enqueue_stream_sweep(c, nullptr);
@@ -584,6 +622,7 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   if (lane_fused(c)) return enqueue_lane_sweep(c, nullptr);
   int rc;
   prof_collect(c);
+  c->s_packed = s_packed_ok(c);
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
   prof_mark(c, 0);
   for (int r = diag_repeat("fwd"); r > 0; r--)
@@ -864,6 +903,7 @@ int vgpa_solve_fwd(vgpa_ctx* c, const double* lin_a, const double* off_b, const 
   if ((rc = upload(c, c->d_op_S0, s0, c->DD))) return rc;
   if ((rc = upload(c, c->d_op_Sigma, sigma, c->DD))) return rc;
   const bool sym = is_symmetric(s0, c->D) && is_symmetric(sigma, c->D);
+  c->s_packed = false;                 // operator-level results are whole matrices
   if ((rc = run_fwd(c, c->d_op_m0, c->d_op_S0, c->d_op_Sigma, sym))) return rc;
   if ((rc = download(c, mt, c->d_m, BN * c->D))) return rc;
   if ((rc = download(c, st, c->d_S, BN * c->DD))) return rc;
@@ -919,6 +959,7 @@ int vgpa_energy_full(vgpa_ctx* c, const double* lin_a, const double* off_b, cons
   }
   if ((rc = ingest_ab(c, lin_a, off_b))) return rc;
   c->ms_valid = true;
+  c->s_packed = false;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->B, c->stream));
@@ -975,6 +1016,7 @@ int vgpa_obs_energy(vgpa_ctx* c, const double* mt, const double* st, double* eob
   const size_t BN = (size_t)c->B * c->Np;
   int rc;
   c->ms_valid = true;
+  c->s_packed = false;
   if ((rc = upload(c, c->d_m, mt, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_S, st, BN * c->DD))) return rc;
   ObsArgs a = obs_args(c);
@@ -1114,7 +1156,12 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
   if (which != VGPA_FETCH_MT && which != VGPA_FETCH_ST && which != VGPA_FETCH_EDF && (rc = materialize_derived(c))) return rc;
   switch (which) {
     case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;
-    case VGPA_FETCH_ST: rc = download(c, out, c->d_S, BN * c->DD); break;
+    case VGPA_FETCH_ST: {
+      const double* full = nullptr;
+      if ((rc = unpack_S(c, &full))) return rc;
+      rc = download(c, out, full, BN * c->DD);
+      break;
+    }
     case VGPA_FETCH_LAMT: rc = download(c, out, c->d_lam, BN * c->D); break;
     case VGPA_FETCH_PSIT:
       if (!c->d_psi || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "Psi_t is not kept by the time-chunked large-D sweep");

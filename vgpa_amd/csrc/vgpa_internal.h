@@ -20,6 +20,18 @@ __device__ __forceinline__ int ldu(const int32_t* p, int i) {
 }
 #endif
 
+#ifdef __HIPCC__
+// packed lower triangles (OdeArgs::s_packed): element (r, c), c <= r, at tri_off(r) + c; tri_row(e) = the row of flat index e
+__host__ __device__ __forceinline__ int tri_off(int r) { return r * (r + 1) / 2; }
+__device__ __forceinline__ int tri_row(int e) {                     // e < 2^20
+  int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+  i += (tri_off(i + 1) <= e) ? 1 : 0;
+  i -= (tri_off(i) > e) ? 1 : 0;
+  return i;
+}
+__host__ __device__ __forceinline__ int tri_idx(int r, int c) { return r >= c ? tri_off(r) + c : tri_off(c) + r; }
+#endif
+
 constexpr int kMaxSmallD = 64;   // single-workgroup (LDS resident) stepping kernels
 constexpr int kMaxLaneD = 4;     // one-lane-per-problem stepping kernels (ode_small.hip)
 constexpr int kMaxTheta = 4;
@@ -58,6 +70,10 @@ struct OdeArgs {
   // wave's 64 lanes read / write 512 contiguous bytes per entry straight from / into registers; nullptr: the [B][Np] arrays m / S
   double* msT;
   int bpad;
+  // fused batched sweeps of the fragment-cover kernels (33 <= D <= 40): S_t leaves the forward kernel as its packed LOWER triangle,
+  // row-major -- element (r, c), c <= r, of grid point t of problem p at S[(p * Np + t) * D (D + 1) / 2 + r (r + 1) / 2 + c] -- which is
+  // all the energy kernel factorises and half of what the gradient assembly streams (vgpa_fetch unpacks it on demand)
+  int s_packed;
   const double* jmT;     // sparse vector jumps in the same spirit: entry i of observation n of problem p at jmT[(n * D + i) * bpad + p]
 };
 
@@ -94,6 +110,7 @@ struct EnergyArgs {
   double* Edf;              // [B][Np][D][D] or nullptr
   double* dEm;              // [B][Np][D]
   double* dEs;              // [B][Np][D][D]
+  int s_packed;             // S holds packed lower triangles (OdeArgs::s_packed)
   int ds_upper;             // L96, D <= 64: write only the upper triangle of dEs (row <= col) -- the consumer is a symmetric-unit backward
                             // kernel, which reads nothing else (fused sweeps; VGPA_FETCH_DESDE_DS mirrors it on the way out)
   double* hyp;              // [B][Np][H] per-grid-point integrands of dEsde/dtheta, dEsde/dSigma (nullptr: skipped)
@@ -113,6 +130,7 @@ struct ObsArgs {
   const double* S;          // [B][Np][D][D]
   double* jm_sparse;        // [B][M][D]
   double* eobs;             // [B]
+  int s_packed;             // S holds packed lower triangles (OdeArgs::s_packed)
   int diag;                 // Q and K are diagonal (diagonal R, H = I)
   double* part;             // [B][M] per-observation terms of the n-D energy (grid-parallel variant) or nullptr
 };
@@ -127,6 +145,7 @@ struct GradArgs {
   const double* A; const double* b;
   const double* m; const double* S;
   const double* lam; const double* psi;
+  int s_packed;             // S holds packed lower triangles (OdeArgs::s_packed)
   int psi_is_q;             // `psi` holds Q''_t = Sigma^-1 A_t - 2 Psi_t (OdeArgs::q_on): A is not read
   const double* Ef;
   const double* Am;         // [B][Np][D] A_t m_t left by the energy kernel, or nullptr (then recomputed)
@@ -159,6 +178,8 @@ bool sym_stores_q(int method, int D);      // the backward kernel launch_ode_mfm
 // Psi_t = (diag(isg) A_t - Q''_t) / 2 in place (A: problem stride strideA, grid-point stride D*D)
 // the strict lower triangle of [batch * Np] D x D matrices from their upper one, in place
 hipError_t launch_mirror_upper(size_t n_mat, int D, double* m, hipStream_t st);
+// n_mat packed lower triangles [D (D + 1) / 2] -> full symmetric D x D matrices
+hipError_t launch_unpack_lower(size_t n_mat, int D, const double* packed, double* full, hipStream_t st);
 hipError_t launch_psi_from_q(int batch, int Np, int D, size_t strideA, const double* A, const double* isg, double* psi_q, hipStream_t st);
 hipError_t launch_energy(const EnergyArgs& a, hipStream_t st);
 hipError_t launch_obs(const ObsArgs& a, hipStream_t st);   // uses the grid-parallel variant when a.part != nullptr
