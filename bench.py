@@ -575,7 +575,7 @@ def main():
     traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
                       "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-single-problem "
                              "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
-                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r03_pmc_fetch_write_B512.csv"}
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r04p_pmc_fetch_write_B512.csv"}
 
     # streams of the default batched path (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I, B > #CUs): the backward kernel writes
     # Q''_t = A_t / sigma^2 - 2 Psi_t where Psi_t would be, the gradient assembly reads Q''_t and S_t only, and dEsde_dS exists as its
@@ -585,16 +585,18 @@ def main():
                and not args.generic and not args.keep_psi
     q_mode = sym_path and 33 <= d <= 40 and args.method.upper() in ("RK2", "RK4") and os.environ.get("VGPA_SYM_RUNS") != "1"
     tri = d * (d + 1) / 2.0 if sym_path else float(d * d)
+    # ... and (round 4) S_t travels between the kernels as its packed lower triangle (OdeArgs::s_packed; VGPA_S_PACKED=0 keeps whole matrices)
+    s_tri = d * (d + 1) / 2.0 if (q_mode and os.environ.get("VGPA_S_PACKED") != "0") else float(d * d)
     kernels = {
         # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
         "solve_fwd": dict(bound="mfma", seconds=fwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
-                          alg_bytes=B * 8.0 * n_pts * (2 * d * d + 2 * d)),       # read A,b ; write S,m
+                          alg_bytes=B * 8.0 * n_pts * (d * d + s_tri + 2 * d)),   # read A,b ; write S (packed lower triangle), m
         "solve_bwd": dict(bound="mfma", seconds=bwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
                           alg_bytes=B * 8.0 * n_pts * (2 * d * d + tri + 2 * d)),  # read A, dEsde/dS (upper), dEsde/dm ; write Psi | Q'', lam
         # per-grid-point kernels: HBM (energy: AI = 4 D^3 / (24 D^2) = D/6 flop/B; gradient: 2 D^3 / (32 D^2) = D/16)
-        "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (2 * d * d + tri + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
+        "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (d * d + s_tri + tri + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
                            unit="GB/s"),                                          # read S, A, m, b ; write dEsde/dS (upper), dEsde/dm, <f>, A m, e_t
-        "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * ((3 if q_mode else 4) * d * d + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
+        "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * ((2 if q_mode else 3) * d * d + s_tri + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
                      unit="GB/s"),                                                # read Q'' (or A and Psi), S + vectors ; write gLa, gLb
     }
     nb_blocks = (d + 3) // 4
@@ -608,7 +610,7 @@ def main():
     cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
     # (last parameter: the backward cover kernels of RK2 / RK4 store Q''_t = Sigma^-1 A_t - 2 Psi_t for the gradient assembly)
     q_out = lambda fwd: "true" if (fwd == "false" and cover == 0 and method_id in (2, 3) and not args.keep_psi) else "false"
-    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}>") if sym_units else \
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
                "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma{'_q' if (sym_units and q_out('false') == 'true') else ''}<{nb_blocks}> (+ k_reduce)"}
