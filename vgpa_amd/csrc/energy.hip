@@ -578,18 +578,32 @@ __device__ unsigned long long g_energy_trace[16];
 #define VGPA_TRACE_STAMP(k) do { } while (0)
 #endif
 
-template <int NB>
+// TPW > 1 (packed S_t only): the wave takes TPW consecutive grid points of one problem and requests the next point's S_t (13
+// registers of packed triangle at D = 40) and vector entries before the triangular inverse of the current one -- the phases behind
+// that point need few registers, and the wave's entry and the memory round trip of its operands, 23 % of a one-point wave's time
+// (profiles/r03_energy_kernel_phase_trace.json), run under them.
+// (EXPERIMENT, off: -DVGPA_ENERGY_TPW=4 builds the persistent variant.  Measured 11.2 ms against 5.5 ms per 512-problem launch: with a
+//  loop around the body the register allocator spills ~90 values (352 bytes of scratch per lane at the 168-register budget of three
+//  waves per SIMD) wherever the request for the next point is placed -- EXPERIMENTS.md s.10.)
+#ifndef VGPA_ENERGY_TPW
+#define VGPA_ENERGY_TPW 1
+#endif
+constexpr int kEnergyTPW = VGPA_ENERGY_TPW;
+template <int NB, int TPW = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 10 ? 3 : 2, NB <= 10 ? 3 : 2))) k_energy_l96_r(EnergyArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int D = a.D, M = 2 * D + 1;
   constexpr int Dp = 4 * NB, LD = Dp + 1, NUU = (NB + 3) / 4;
-  const int l = threadIdx.x;
+  int l = threadIdx.x;
 #ifdef VGPA_ENERGY_TRACE
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
   const long long wid = blockIdx.x;
-  const int prob = (int)(wid / a.Np), t = (int)(wid - (long long)prob * a.Np);
-  const size_t o = (size_t)prob * a.Np + t;
+  const int per = (a.Np + TPW - 1) / TPW;            // waves per problem
+  const int prob = (int)(wid / per);
+  int t = (int)(wid - (long long)prob * per) * TPW;
+  const int t_last = t + TPW < a.Np ? t + TPW : a.Np;
+  size_t o = (size_t)prob * a.Np + t;
   L96Lds S;
   // (Sigma^-1's diagonal is kept in registers, not in LDS; rows 0 and 1 of the parked G share the space of dl and qq,
   //  which are written after the boundary pass: 17.9 KB per grid point at D = 40, nine waves per CU)
@@ -599,16 +613,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   double* pw = pv + 4 * Dp;          // [4][Dp] ... of the minus points
   double* gb2 = pw + 4 * Dp;         // [Dp] row D-1 of G (rows 0 and 1: S.dl, S.qq)
   double* xdiag = pv;                // phase 4 (the partial sums are dead by then)
-  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;
+  const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;       // (advanced per grid point)
   const bool spk = a.s_packed != 0;                // S_t as its packed lower triangle (OdeArgs::s_packed): all the factorisation reads
   const int PK = tri_off(D);
   const double* St = a.S + o * (spk ? PK : D * D);
+  static_assert(TPW >= 1, "grid points per wave");
   const double theta = a.theta[0];
   const double kappa = 1.05 * D, c = D + kappa;
-  const bool act = l < D;
-  const bool pad = l < Dp;
-  const int li = pad ? l : Dp - 1;
-  const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+  bool act = l < D;
+  bool pad = l < Dp;
+  int li = pad ? l : Dp - 1;
+  int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
 
   // ---- A-operand fragments of A, straight from HBM: unit u = block-rows 4u + b, fragment [i = c4][k = r4]
   // (the last unit's fragments are requested after the Cholesky instead: with them in flight the factorisation would not fit the
@@ -633,41 +648,66 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   // the two entries of S_t that <f>_i needs at the very end (E96_drift): requested now -- at the end they would cost a
   // full memory round trip per wave
   double sxa = 0.0, sxb = 0.0, v_m = 0.0, v_b = 0.0, v_sg = 0.0;
+  double nsxa = 0.0, nsxb = 0.0;          // packed path: the two entries of the grid point whose operands are in flight
+  const int f_ip1 = wrap(l + 1, D), f_im1 = wrap(l - 1, D), f_im2 = wrap(l - 2, D);
+  if (act) v_sg = a.isg[l];
   auto load_vectors = [&]() {
     if (act) {
-      const int ip1 = wrap(l + 1, D), im1 = wrap(l - 1, D), im2 = wrap(l - 2, D);
-      sxa = St[spk ? tri_idx(ip1, im1) : ip1 * D + im1];
-      sxb = St[spk ? tri_idx(im2, im1) : im2 * D + im1];
+      sxa = St[f_ip1 * D + f_im1];
+      sxb = St[f_im2 * D + f_im1];
       v_m = a.m[o * D + l];
       v_b = a.b[(size_t)prob * a.strideB + (size_t)t * D + l];
-      v_sg = a.isg[l];
     }
   };
+  // packed lower triangle: flat, fully coalesced loads (lane = double e of the triangle: 13 requests at D = 40 instead of 40 row
+  // loads); `request` asks for everything of grid point tn the wave reads from HBM except A
+  constexpr int EPK = (Dp * (Dp + 1) / 2 + 63) / 64;
+  double sv[EPK];
+  int rr[TPW == 1 ? EPK : 1];              // rows of this lane's flat indices: looked up (kTriRow) beside the loads they belong to
+  auto request = [&](int tn) {
+    const size_t on = (size_t)prob * a.Np + tn;
+    const double* Sn = a.S + on * PK;
+#pragma unroll
+    for (int q = 0; q < EPK; q++) {
+      const int e = l + 64 * q;
+      sv[q] = e < PK ? Sn[e] : 0.0;
+      if (TPW == 1) rr[q] = kTriRow.r[e < PK ? e : 0];
+    }
+    if (act) {
+      nsxa = Sn[tri_idx(f_ip1, f_im1)];
+      nsxb = Sn[tri_idx(f_im2, f_im1)];
+      v_m = a.m[on * D + l];
+      v_b = a.b[(size_t)prob * a.strideB + (size_t)tn * D + l];
+    }
+  };
+  if (spk) request(t);
 
+  for (;;) {      // the grid points of this wave (one, unless TPW > 1)
+  if (TPW > 1) {
+    // The lane index is made opaque per grid point: everything a lane addresses derives from it, and with a loop around the body
+    // the compiler otherwise hoists every per-lane LDS / HBM offset of every phase out of the loop -- ~300 registers of "invariants"
+    // that a one-grid-point wave computes where it needs them (1.2 KB of scratch per lane before this line).
+    asm volatile("" : "+v"(l));
+    act = l < D; pad = l < Dp; li = pad ? l : Dp - 1;
+    r4 = l >> 4; c4 = l & 3; b = (l >> 2) & 3;
+  }
   // ---- stage c*S into LDS (coalesced); padding: identity.  Every HBM load of the wave (the vectors too) is requested
   //      before the first one is consumed: a lone wave pays each dependent round trip in full.  S_t's requests go first.
   if (spk) {
-    // packed lower triangle: flat, fully coalesced loads (lane = double e of the triangle: 13 requests at D = 40 instead of 40
-    // row loads), each value to its (row, column) of the LDS matrix; the strict upper triangle is never read before the
-    // factorisation's pivots zero it (chol_panel_pivots)
-    constexpr int EPK = (Dp * (Dp + 1) / 2 + 63) / 64;
+    // each value to its (row, column) of the LDS matrix; the strict upper triangle is never read before the factorisation's
+    // pivots zero it (chol_panel_pivots)
     if (D != Dp) {
       for (int e = l; e < Dp * LD; e += 64) S.Lm[e] = 0.0;
       wave_sync();
     }
-    double sv[EPK];
-    int rr[EPK];
+    sxa = nsxa; sxb = nsxb;
 #pragma unroll
     for (int q = 0; q < EPK; q++) {
       const int e = l + 64 * q;
-      sv[q] = e < PK ? St[e] : 0.0;
-      rr[q] = kTriRow.r[e < PK ? e : 0];
-    }
-    load_vectors();
-#pragma unroll
-    for (int q = 0; q < EPK; q++) {
-      const int e = l + 64 * q;
-      if (e < PK) S.Lm[rr[q] * LD + (e - tri_off(rr[q]))] = c * sv[q];
+      if (e < PK) {
+        const int r = (TPW > 1) ? tri_row(e) : rr[TPW == 1 ? q : 0];      // (persistent waves: arithmetic instead of 13 more registers)
+        S.Lm[r * LD + (e - tri_off(r))] = c * sv[q];
+      }
     }
   } else if (D == Dp) {
     // no padding (D = 40 of the headline): one row per load, lane = column -- every HBM and LDS offset is an immediate, no index
@@ -944,6 +984,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   wave_sync();
 
   VGPA_TRACE_STAMP(4);
+#ifndef VGPA_ENERGY_PF
+#define VGPA_ENERGY_PF 4
+#endif
+  if (VGPA_ENERGY_PF == 4 && TPW > 1 && spk && t + 1 < t_last) request(t + 1);      // the next grid point's operands travel under phases 4 and 5
   // ---- 4. X = L^-1 IN PLACE by blocked forward substitution on the matrix cores (see k_energy_l96): block-row I of X
   //         overwrites block-row I of L, which only step I reads; LDS operations of one wave execute in order.
   const double* l4_a = S.Lm + c4 * LD + r4;
@@ -980,6 +1024,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   }
 
   VGPA_TRACE_STAMP(5);
+  if (VGPA_ENERGY_PF == 5 && TPW > 1 && spk && t + 1 < t_last) request(t + 1);
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
@@ -1030,6 +1075,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     }
   }
   VGPA_TRACE_STAMP(7);
+  if (TPW == 1) break;
+  if (VGPA_ENERGY_PF == 7 && spk && t + 1 < t_last) request(t + 1);
+  t++;
+  if (t >= t_last) break;
+  o++;
+  At += (size_t)D * D;
+  St += spk ? PK : D * D;
+  wave_sync();                                   // every lane is done with this grid point's LDS before the next one is staged
+  }
 }
 
 // dense <df/dx> only (used by vgpa_fetch(EDF) when the fused sweep skipped it)
@@ -1084,7 +1138,16 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     if (lds > 48 * 1024)                                                                                            \
       (void)hipFuncSetAttribute(one_matrix ? (const void*)k_energy_l96_r<NBV> : (const void*)k_energy_l96<NBV>,       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    if (one_matrix) hipLaunchKernelGGL(k_energy_l96_r<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);            \
+    if constexpr (NBV == 9 || NBV == 10) {       /* packed S_t (the batched fused sweeps): persistent waves, see k_energy_l96_r */ \
+      if (one_matrix && a.s_packed && kEnergyTPW > 1) {                                                              \
+        constexpr int TPW = kEnergyTPW > 1 ? kEnergyTPW : 2;                                                         \
+        (void)hipFuncSetAttribute((const void*)k_energy_l96_r<NBV, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        const long long nw = (long long)((a.Np + TPW - 1) / TPW) * a.batch;                                          \
+        hipLaunchKernelGGL((k_energy_l96_r<NBV, TPW>), dim3((unsigned)nw), dim3(64), lds, st, a);                    \
+        break;                                                                                                      \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (one_matrix) hipLaunchKernelGGL(k_energy_l96_r<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);          \
     else hipLaunchKernelGGL(k_energy_l96<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);                        \
     break;
     switch ((a.D + 3) / 4) {
