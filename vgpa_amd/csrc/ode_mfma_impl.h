@@ -21,7 +21,7 @@
 //     the VALU while the P waves are in the product), stage A(t) HBM -> registers -> LDS one step ahead and stream
 //     S_k / Psi_t back to HBM.
 //   * One workgroup (4 P + 4 E waves, one of each per SIMD) per problem; the phases alternate product / element-wise
-//     stage with ONE workgroup barrier each.  Also built and measured in round 2, not kept: two problems
+//     stage with ONE workgroup barrier each.  Also built and measured in round 2, not kept (EXPERIMENTS.md s.1): two problems
 //     per workgroup in alternating phases -- with separate E waves per problem and with every E wave serving both --
 //     (the matrix pipe has work in every phase, but LDS traffic and the fp64 VALU work of the other problem's element-wise
 //     stage stretch the product by what the overlap saves: +4 % forward, slower backward), and counters in LDS instead of

@@ -3,7 +3,7 @@
 // problem is sequential in t, so its latency is one lane's instruction latency (comparable to the workgroup-per-problem
 // kernel of ode_generic.hip at D = 3), but 64 problems share a wave instead of each occupying a workgroup of four
 // waves that synchronises six times per step: BASELINE configs[1] (Lorenz-63, RK4, Np = 1001), 65536 problems:
-// forward + backward 236 ms -> see DESIGN.md s.4.2.
+// forward + backward 236 ms -> see DESIGN.md s.4.3.
 //
 // Same arithmetic, in the same order, as ode_generic.hip (which restates the reference):
 //   forward : euler.py:27-92, heun.py:28-111, runge_kutta2.py:25-102 (incl. quirk Q2 at :96), runge_kutta4.py:25-113

@@ -29,7 +29,7 @@
 //     vector, so no second barrier orders "vector published" before "next partial sums".
 //   * A(t) is staged HBM -> registers -> LDS one step ahead; S_k / Psi_t go back to HBM from the stage buffer (coalesced
 //     row-pair items).  Everything of a stage that is not the product is ONE LDS round trip behind it (`tail`).
-// Measurements, what was tried and what bounds the kernel: DESIGN.md s.4.1b; micro-benchmark tools/ubench/sym_product.hip.
+// Measurements, what was tried and what bounds the kernel: DESIGN.md s.4.1, s.7, EXPERIMENTS.md s.2, s.9, s.11; micro-benchmark tools/ubench/sym_product.hip.
 #pragma once
 #include "ode_mfma_impl.h"
 #include <cstdlib>
@@ -325,7 +325,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // instruction streams), owns half the elements and does half the chores, so the per-stage latency chain of a lone problem --
 // products, stepper, publish, barrier, first fragments: ~2 300 cycles with four waves -- loses most of its product share.  For
 // batches up to one problem per CU (the reference's own use case is ONE optimisation); larger batches keep two four-wave
-// workgroups per CU, whose 256 registers per wave an eight-wave workgroup pair cannot have (DESIGN.md s.4.1d).
+// workgroups per CU, whose 256 registers per wave an eight-wave workgroup pair cannot have (DESIGN.md s.7).
 template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4>   // WPE: waves per SIMD the register budget allows for
 __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
