@@ -71,6 +71,9 @@ constexpr int kMaxNB = 16;          // D <= 64
 #ifndef VGPA_ABL_NOVEC
 #define VGPA_ABL_NOVEC 0               // DIAGNOSTIC (wrong results): no vector recursion (partial inner products, per-wave update)
 #endif
+#ifndef VGPA_SYM_OP_PIN
+#define VGPA_SYM_OP_PIN 0              // outer-product cover: 1 = the written order of products, rotations and reads is pinned (slower)
+#endif
 #ifndef VGPA_SYM_LOOP1
 #define VGPA_SYM_LOOP1 1               // cover kernels: the loop unit (diagonal blocks) runs one chain + an in-block transpose
 #endif
@@ -208,6 +211,102 @@ __host__ __device__ constexpr bool cover_diagonals_in_loop_units() {
 }
 static_assert(cover_diagonals_in_loop_units(), "single-chain loop units: every diagonal block in slot 2 of a triangle wave, slot 2 of the rectangle wave unused");
 
+// ---- outer-product cover (round 4): NSB = 5 (D = 33 .. 40) ------------------------------------------------------------------
+// The product phase of the fragment cover above is bound by its LDS fragment reads as much as by the matrix pipe (EXPERIMENTS.md
+// s.9): 8 (6) ds_read_b128 per k-pair and wave for 14 products.  A fragment register of a map m also holds, up to a rotation of
+// its four 4-lane block groups inside every 16-lane row, the fragment of every ROTATED map rot_r(m)[q] = m[(q - r) & 3] -- and a
+// rotation of lanes inside a row is what the DPP operand of a v_mov does (row_ror:4r, no LDS).  So a wave reads the fragments of
+// only TWO maps (P, Q) of both operand buffers -- 4 reads per k-pair -- and multiplies the units
+//   slot 0: (P, P)          the loop unit: four diagonal blocks, one chain + in-block transpose (as kCoverLoopSlot above)
+//   slot 1: (rot_1 P, P)    the 4-cycle P0-P1-P2-P3 of block pairs inside P
+//   slot 2: (rot_1 Q, Q)    ... inside Q
+//   slot 3: (P, Q)          P[q] with Q[q]
+// with ONE instruction stream for all four waves: 14 products per k-pair as before, 16 fragment reads per k-pair and workgroup
+// instead of 26, 16 v_mov_dpp per k-pair and wave for the rotated row sides.  The maps below were found by simulated annealing
+// (cover all 55 block pairs, every diagonal block in a loop unit; the ds_read_b128 bank condition (i) above on every map; as few
+// publish bank conflicts (ii)/(iii) as possible).
+struct OpUnit { int rmap, rot, cmap; };              // unit = (rot_rot(map rmap), map cmap); maps: 0 = P, 1 = Q
+constexpr OpUnit kOpUnits[4] = {{0, 0, 0}, {0, 1, 0}, {1, 1, 1}, {0, 0, 1}};
+constexpr int kOpLoopSlot = 0;
+constexpr int kOpMaps[4][2][4] = {                   // [wave][P, Q][block q]
+    {{7, 4, 6, 1}, {3, 8, 2, 9}},
+    {{8, 9, 8, 9}, {1, 5, 0, 4}},
+    {{5, 8, 6, 3}, {6, 7, 9, 0}},
+    {{2, 3, 1, 0}, {5, 4, 2, 7}}};
+__host__ __device__ constexpr int op_row_block(int w, int s, int q) { return kOpMaps[w][kOpUnits[s].rmap][(q - kOpUnits[s].rot) & 3]; }
+__host__ __device__ constexpr int op_col_block(int w, int s, int q) { return kOpMaps[w][kOpUnits[s].cmap][q]; }
+__host__ __device__ constexpr bool op_owner(int w, int s, int q) {      // first occurrence of the block pair in (w, s, q) order
+  const int I = op_row_block(w, s, q), J = op_col_block(w, s, q);
+  const int lo = I < J ? I : J, hi = I < J ? J : I;
+  for (int w2 = 0; w2 <= w; w2++)
+    for (int s2 = 0; s2 < 4; s2++)
+      for (int q2 = 0; q2 < 4; q2++) {
+        if (w2 == w && (s2 > s || (s2 == s && q2 >= q))) return true;
+        const int I2 = op_row_block(w2, s2, q2), J2 = op_col_block(w2, s2, q2);
+        if ((I2 < J2 ? I2 : J2) == lo && (I2 < J2 ? J2 : I2) == hi) return false;
+      }
+  return true;
+}
+__host__ __device__ constexpr CoverOwnerTab op_owner_tab() {
+  CoverOwnerTab t{};
+  for (int w = 0; w < 4; w++)
+    for (int s = 0; s < 4; s++) {
+      unsigned char bits = 0;
+      for (int q = 0; q < 4; q++)
+        if (op_owner(w, s, q)) bits = (unsigned char)(bits | (1u << q));
+      t.m[w][s] = bits;
+    }
+  return t;
+}
+__device__ constexpr CoverOwnerTab kOpOwner = op_owner_tab();
+__host__ __device__ constexpr int op_pairs_owned() {
+  int n = 0;
+  for (int w = 0; w < 4; w++)
+    for (int s = 0; s < 4; s++)
+      for (int q = 0; q < 4; q++) n += op_owner(w, s, q) ? 1 : 0;
+  return n;
+}
+__host__ __device__ constexpr bool op_pairs_in_range() {
+  for (int w = 0; w < 4; w++)
+    for (int m = 0; m < 2; m++)
+      for (int q = 0; q < 4; q++)
+        if (kOpMaps[w][m][q] < 0 || kOpMaps[w][m][q] > 9) return false;
+  return true;
+}
+// every diagonal block must be owned by a loop unit (the single-chain trick is applied to slot kOpLoopSlot and to nothing else;
+// a diagonal block in a two-chain unit would be right too, but the count below is what proves the 10 diagonals are covered)
+__host__ __device__ constexpr int op_diagonals_in_loop_units() {
+  int n = 0;
+  for (int w = 0; w < 4; w++)
+    for (int q = 0; q < 4; q++) n += op_owner(w, kOpLoopSlot, q) ? 1 : 0;
+  return n;
+}
+static_assert(op_pairs_in_range() && op_pairs_owned() == 55, "the outer-product cover must own every block pair of the 10 x 10 upper triangle exactly once");
+static_assert(kOpUnits[kOpLoopSlot].rmap == kOpUnits[kOpLoopSlot].cmap && kOpUnits[kOpLoopSlot].rot == 0 && op_diagonals_in_loop_units() == 10,
+              "the loop unit is (m, m) unrotated and the loop units own all ten diagonal blocks");
+
+template <int R>
+__device__ __forceinline__ double rot_d(double v) {          // one double of a fragment, rotated like rot_blocks below
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  i2_t x = __builtin_bit_cast(i2_t, v), y;
+  y[0] = __builtin_amdgcn_mov_dpp(x[0], 0x120 + 4 * R, 0xf, 0xf, false);
+  y[1] = __builtin_amdgcn_mov_dpp(x[1], 0x120 + 4 * R, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, y);
+}
+// the four 4-lane block groups of every 16-lane row rotated by R: lane of block q receives the lane of block q - R
+// (v_mov_b32 ... row_ror:4R: destination lane l reads lane (l - 4R) mod 16 of its row, tools/ubench/dpp_ror.hip)
+template <int R>
+__device__ __forceinline__ d2_t rot_blocks(d2_t v) {
+  if constexpr (R == 0) return v;
+  else {
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    i4_t x = __builtin_bit_cast(i4_t, v), y;
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = __builtin_amdgcn_mov_dpp(x[i], 0x120 + 4 * R, 0xf, 0xf, false);
+    return __builtin_bit_cast(d2_t, y);
+  }
+}
+
 template <int NB_, int NW_ = 4>      // NW: waves per workgroup (4: two workgroups per CU; 8: one problem per CU, see k_ode_sym)
 struct SGeo {
   static constexpr int NB = NB_;
@@ -334,8 +433,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   constexpr bool W8 = (NW == 8);
   constexpr int NT = g::NT;
   constexpr int NS = n_stages<METHOD>(), NR = g::NR, MAXS = W8 ? 2 : g::MAXS, LD = g::LD, NKP = g::NKP;
-  constexpr bool COVER = (GR == 0);      // fragment cover (NSB = 5) instead of runs: see kCoverMaps
-  constexpr bool LOOP1 = COVER && VGPA_SYM_LOOP1 && !W8;      // single-chain loop units: see kCoverLoopSlot
+  constexpr bool COVER = (GR <= 0);      // fragment cover (NSB = 5) instead of runs: see kCoverMaps
+  constexpr bool OPC = (GR == -1);       // ... the outer-product cover (two maps per wave, rotated row sides): see kOpMaps
+  constexpr bool LOOP1 = COVER && (OPC || VGPA_SYM_LOOP1) && !W8;      // single-chain loop units: see kCoverLoopSlot
+  constexpr int LSLOT = OPC ? kOpLoopSlot : kCoverLoopSlot;
+  static_assert(!OPC || !W8, "the outer-product cover runs on four waves");
   static_assert(!COVER || (g::NSB == 5 && g::MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
   static_assert(!W8 || COVER, "eight waves per problem: fragment-cover kernels only");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
@@ -367,18 +469,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   int colm[4] = {0, 0, 0, 0};            // cover: LDS column offset of this lane's fragment element, per map
   unsigned gofs[MAXS];
   bool own[MAXS], wd[MAXS], wm[MAXS];
-  const int cov_used = COVER ? kCoverUsed[wq] : 0;
+  const int cov_used = OPC ? 0xF : (COVER ? kCoverUsed[wq] : 0);
   const bool loop_diag = r4 == c4;                     // diagonal element of a diagonal block (loop unit)
   const int loop_src = 16 * c4 + 4 * bq + r4;          // the lane that holds element (c4, r4) of the same block
   if constexpr (COVER) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * kCoverMaps[wq][m][bq] + c4) ^ r4);
+    for (int m = 0; m < 4; m++) colm[m] = 2 * ((4 * (OPC ? kOpMaps[wq][m & 1][bq] : kCoverMaps[wq][m][bq]) + c4) ^ r4);
 #pragma unroll
     for (int s = 0; s < MAXS; s++) {
       const int so = W8 ? 2 * half + s : s;                       // unit slot of the cover wave
-      const int Ib = kCoverMaps[wq][kCoverPat[so][0]][bq], Jb = kCoverMaps[wq][kCoverPat[so][1]][bq];
+      const int Ib = OPC ? kOpMaps[wq][kOpUnits[so].rmap][(bq - kOpUnits[so].rot) & 3] : kCoverMaps[wq][kCoverPat[so][0]][bq];
+      const int Jb = OPC ? kOpMaps[wq][kOpUnits[so].cmap][bq] : kCoverMaps[wq][kCoverPat[so][1]][bq];
       const int row = 4 * Ib + r4, col = 4 * Jb + c4;
-      const bool first = (kCoverOwner.m[wq][so] >> bq) & 1u;      // (a compile-time table, looked up with the run-time wave / block)
+      const bool first = ((OPC ? kOpOwner.m[wq][so] : kCoverOwner.m[wq][so]) >> bq) & 1u;      // (a compile-time table, looked up with the run-time wave / block)
       const bool act = ((cov_used >> so) & 1) && first && (Ib != Jb || row <= col);     // diagonal blocks: the upper half represents
       offD[s] = elem_off<NB>(row, col);
       offM[s] = elem_off<NB>(col, row);
@@ -701,7 +804,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
 #ifndef VGPA_SYM_HALF_BWD
 #define VGPA_SYM_HALF_BWD 1
 #endif
-  constexpr bool HALF = COVER && !W8 && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
+  constexpr bool HALF = COVER && !OPC && !W8 && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
   // W8: three maps per wave -- row side a0 (first half) or a1 (second half), column side b0, b1 -- of both operands, two buffers
   d2_t fA8[2][W8 ? 3 : 1], fX8[2][W8 ? 3 : 1];
   const int col8[3] = {half ? colm[1] : colm[0], colm[2], colm[3]};
@@ -714,7 +817,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   };
   d2_t fAa[COVER ? 2 : 1], fXa[COVER ? 2 : 1], fAb[2][COVER ? 2 : 1], fXb[2][COVER ? 2 : 1];
   d2_t fAa1[2], fXa1[2];                 // HALF + interleave: map a1 in two buffers (read half a step earlier than it is free)
-  d2_t fA[2][(COVER && !HALF && !W8) ? 4 : 1], fX[2][(COVER && !HALF && !W8) ? 4 : 1];
+  d2_t fA[2][(COVER && !OPC && !HALF && !W8) ? 4 : 1], fX[2][(COVER && !OPC && !HALF && !W8) ? 4 : 1];
+  d2_t foA[2][2], foX[2][2];             // outer-product cover: maps P, Q of both operand buffers, two pipeline buffers
+  auto frag_op = [&](int buf, int kp, const double* pa, const double* px) {
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      foA[buf][m] = *reinterpret_cast<const d2_t*>(pa + kp * 4 * LD + colm[m]);
+      foX[buf][m] = *reinterpret_cast<const d2_t*>(px + kp * 4 * LD + colm[m]);
+    }
+  };
   auto frag_all = [&](int buf, int kp, const double* pa, const double* px) {
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -741,7 +852,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
     if constexpr (COVER) {
       // (only the first step of a stage comes through here: every other fragment is requested inside the step before it)
       const int kp = t % NKP;
-      if constexpr (W8) {
+      if constexpr (OPC) {
+        frag_op(buf, kp, pa, px);
+      } else if constexpr (W8) {
         frag8(buf, kp, pa, px);
       } else if constexpr (HALF) {
         frag_a(0, kp, pa, px);
@@ -810,7 +923,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
             else if (METHOD == VGPA_ODE_RK2) f = j == 0 ? fc[s] : 0.5 * (fn[s] + fc[s]);
             else f = j == 0 ? fc[s] : (j == 3 ? fn[s] : 0.5 * (fn[s] + fc[s]));
             f = own[s] ? -f : 0.0;
-            if (LOOP1 && s == kCoverLoopSlot) f = loop_diag ? 0.5 * f : f;     // (the in-block transpose below adds the diagonal to itself)
+            if (LOOP1 && s == LSLOT) f = loop_diag ? 0.5 * f : f;     // (the in-block transpose below adds the diagonal to itself)
           }
           w[u] = f;
         }
@@ -828,7 +941,52 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
         // then X^T A of the first k-step of the pair, then of the second): same bits.  Straight-line code: a branch inside the
         // pipeline would end the scheduling region (the rectangle wave multiplies its unused fourth unit too; the triangle waves
         // read map a1 twice -- the LDS array is not what bounds this kernel, the exposed latency of its reads was).
-        if constexpr (W8) {
+        if constexpr (OPC) {
+          // outer-product cover: the four reads of the next step between this step's fourteen products; the row sides of the
+          // rotated units come out of the fragments by DPP moves (kOpUnits)
+          // Pinned order (the scheduler, left alone, rotates every fragment at the top of the step -- behind a wait for the LAST
+          // read of the step before): the loop unit and the unrotated unit first, a rotation right in front of the product that
+          // needs it, the four reads of the next step behind the first four products.  Per unit the products keep the order
+          // A^T X, X^T A of the first k-step, then of the second.
+          static_assert(kOpUnits[0].rmap == 0 && kOpUnits[0].cmap == 0 && kOpUnits[1].rmap == 0 && kOpUnits[1].rot == 1 && kOpUnits[1].cmap == 0 &&
+                        kOpUnits[2].rmap == 1 && kOpUnits[2].rot == 1 && kOpUnits[2].cmap == 1 && kOpUnits[3].rmap == 0 && kOpUnits[3].rot == 0 &&
+                        kOpUnits[3].cmap == 1, "the product order below is written for the units (P,P) (rot1 P,P) (rot1 Q,Q) (P,Q)");
+          const bool more = t + 1 < NSTEP && !VGPA_ABL_NOFRAG;
+          const int kn = (t + 1) % NKP, nb = cur ^ 1;
+          const d2_t PA = foA[cur][0], PX = foX[cur][0], QA = foA[cur][1], QX = foX[cur][1];
+          auto SB = [] { if (VGPA_SYM_OP_PIN) __builtin_amdgcn_sched_barrier(0); };
+          auto MF = [&](int u, double ra, double rb) { w[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ra, rb, w[u], 0, 0, 0); };
+          double rPA[2], rPX[2], rQA[2], rQX[2];
+          __builtin_amdgcn_sched_barrier(0);
+          MF(0, PA[0], PX[0]); rPA[0] = rot_d<1>(PA[0]);
+          if (more) foA[nb][0] = *reinterpret_cast<const d2_t*>(pa + kn * 4 * LD + colm[0]);
+          SB();
+          MF(0, PA[1], PX[1]); rPX[0] = rot_d<1>(PX[0]);
+          if (more) foX[nb][0] = *reinterpret_cast<const d2_t*>(px + kn * 4 * LD + colm[0]);
+          SB();
+          MF(1, rPA[0], PX[0]); rPA[1] = rot_d<1>(PA[1]);
+          if (more) foX[nb][1] = *reinterpret_cast<const d2_t*>(px + kn * 4 * LD + colm[1]);
+          SB();
+          MF(3, PA[0], QX[0]); rPX[1] = rot_d<1>(PX[1]);
+          if (more) foA[nb][1] = *reinterpret_cast<const d2_t*>(pa + kn * 4 * LD + colm[1]);
+          SB();
+          MF(1, rPX[0], PA[0]); rQA[0] = rot_d<1>(QA[0]);
+          SB();
+          MF(3, PX[0], QA[0]); rQX[0] = rot_d<1>(QX[0]);
+          SB();
+          MF(1, rPA[1], PX[1]); rQA[1] = rot_d<1>(QA[1]);
+          SB();
+          MF(2, rQA[0], QX[0]); rQX[1] = rot_d<1>(QX[1]);
+          SB();
+          MF(3, PA[1], QX[1]);
+          MF(2, rQX[0], QA[0]);
+          MF(1, rPX[1], PA[1]);
+          MF(3, PX[1], QA[1]);
+          MF(2, rQA[1], QX[1]);
+          SB();
+          MF(2, rQX[1], QA[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (W8) {
           // eight waves: unit u = (this half's row-side map, column-side map b_u), both chains; the six reads of the next step
           // between the eight products
           __builtin_amdgcn_sched_barrier(0);
@@ -968,7 +1126,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
       chore(t);                          // everything of the stage that is not the product rides between the products
       if (kp == NKP - 1) {
         if constexpr (LOOP1) {           // Z = M + M^T - F on the diagonal blocks: element (r4, c4) of a block adds element (c4, r4)
-          w[kCoverLoopSlot] += __shfl(w[kCoverLoopSlot], loop_src, 64);
+          w[LSLOT] += __shfl(w[LSLOT], loop_src, 64);
         }
 #pragma unroll
         for (int u = 0; u < NSL; u++) {
@@ -1111,6 +1269,34 @@ inline bool eight_waves(int batch) {
   return forced == 8;      // measured slower at every batch size (EXPERIMENTS.md s.9): opt-in only
 }
 
+// The outer-product cover (kOpMaps: two maps per wave, rotated row sides by DPP) is an EXPERIMENT kept reachable: VGPA_SYM_COVER=op.
+// It measured slower than the round-3 fragment cover (EXPERIMENTS.md s.12): a rotated operand costs two v_mov_dpp, which do not
+// issue under a running fp64 product, where the fragment read it replaces costs LDS cycles beside the matrix pipe.
+inline bool old_cover() {
+  static const bool op = [] { const char* e = getenv("VGPA_SYM_COVER"); return e && !strcmp(e, "op"); }();
+  return !op;
+}
+template <int METHOD, bool FWD, int NB, int GRC>
+hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
+  constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
+  constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;
+  if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
+    if (a.q_on) {
+      if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)
+      auto kq = k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C, true>;
+      if (lds_c > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+      hipLaunchKernelGGL(kq, dim3(a.batch), dim3(256), lds_c, st, a);
+      return hipGetLastError();
+    }
+  }
+  auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, GRC, WPE_C> : k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C>;
+  if (lds_c > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+  hipLaunchKernelGGL(kc, dim3(a.batch), dim3(256), lds_c, st, a);
+  return hipGetLastError();
+}
+
 template <int METHOD, bool FWD, int NB>
 hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr size_t lds = SGeo<NB>::LDS_DOUBLES * sizeof(double);
@@ -1140,26 +1326,7 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(k8, dim3(a.batch), dim3(512), lds_8, st, a);
       return hipGetLastError();
     }
-    if (!runs_only) {
-      constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
-      constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;
-      if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
-        if (a.q_on) {
-          if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)
-          constexpr size_t lds_q = lds_c;
-          auto kq = k_ode_sym<METHOD, FWD, NB, false, 0, WPE_C, true>;
-          if (lds_q > 48 * 1024)
-            (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-          hipLaunchKernelGGL(kq, dim3(a.batch), dim3(256), lds_q, st, a);
-          return hipGetLastError();
-        }
-      }
-      auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, 0, WPE_C> : k_ode_sym<METHOD, FWD, NB, false, 0, WPE_C>;
-      if (lds_c > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-      hipLaunchKernelGGL(kc, dim3(a.batch), dim3(256), lds_c, st, a);
-      return hipGetLastError();
-    }
+    if (!runs_only) return old_cover() ? launch_cover<METHOD, FWD, NB, 0>(a, st, dense) : launch_cover<METHOD, FWD, NB, -1>(a, st, dense);
   }
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
   auto kern = dense ? k_ode_sym<METHOD, FWD, NB, true, GR, WPE> : k_ode_sym<METHOD, FWD, NB, false, GR, WPE>;
