@@ -6,10 +6,10 @@ set -u
 out=gpurun_out/ab_$(date +%H%M%S).txt
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  touch vgpa_amd/csrc/ode_sym_impl.h vgpa_amd/csrc/energy.hip vgpa_amd/csrc/assemble.hip
+  touch ${AB_FILES:-vgpa_amd/csrc/ode_sym_impl.h vgpa_amd/csrc/energy.hip vgpa_amd/csrc/assemble.hip}      # AB_FILES: only the sources the flags concern
   VGPA_EXTRA_CFLAGS="$flags" python -m vgpa_amd.build > gpurun_out/ab_build_$name.log 2>&1 || { echo "$name: build failed" | tee -a $out; continue; }
   for rep in 1 2; do
-    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-single-problem > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-config2 --no-single-problem > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
     python - "$name" "$flags" <<PY | tee -a $out
 import json, sys
 d = json.loads(open("gpurun_out/ab_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
