@@ -613,7 +613,7 @@ def main():
     step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
-               "energy_l96": f"vgpa::k_energy_l96_r<{nb_blocks}> (+ k_obs)", "grad": f"vgpa::k_grad_mfma{'_q' if (sym_units and q_out('false') == 'true') else ''}<{nb_blocks}> (+ k_reduce)"}
+               "energy_l96": f"vgpa::(anonymous namespace)::k_energy_l96_r<{nb_blocks}, 1> (+ k_obs)", "grad": f"vgpa::k_grad_mfma{'_q' if (sym_units and q_out('false') == 'true') else ''}<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():
         ach = k["alg"] / max(k["seconds"], 1e-12) / k["scale"]

@@ -554,7 +554,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
       // (the next grid point's operands are in flight in registers: keep the scheduler from hoisting every fragment read of the product)
       if (kk % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- gLa = dt (Q S - u m^T), straight from the accumulators (16 contiguous doubles per lane group)
+    // ---- gLa = dt (Q S - u m^T): through LDS (the operand buffer of Q^T is dead behind the product) and out as whole 128-byte lines.
+    // Straight from the accumulators a 320-byte row is written as 128 + 128 + 64 bytes by up to three store instructions of two
+    // waves; odd rows start in the middle of a line.  The partial lines do not always meet in L2 before they are evicted: the
+    // kernel's WRITE_SIZE was 17 % above the bytes of its two outputs (profiles/r04r_pmc_fetch_write_B512.csv).
+#ifndef VGPA_GRAD_STAGE_OUT
+#define VGPA_GRAD_STAGE_OUT 1
+#endif
+    double* const outb = VGPA_GRAD_STAGE_OUT ? QT : gA;
+    const int ldo = VGPA_GRAD_STAGE_OUT ? LD : D;      // (in LDS with the operand's leading dimension: its zero padding, D < P, stays untouched)
+    if (VGPA_GRAD_STAGE_OUT) __syncthreads();      // every wave has read its fragments of Q^T
 #pragma unroll
     for (int ii = 0; ii < RW; ii++) {
       const int I = wave + 4 * ii;
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int col = 16 * q + 4 * b + c4;
-        if (I < NB && row < D && col < D) gA[row * D + col] = a.dt * (acc[q * RW + ii] - uv[row] * mv[col]);
+        if (I < NB && row < D && col < D) outb[row * ldo + col] = a.dt * (acc[q * RW + ii] - uv[row] * mv[col]);
       }
     }
 #pragma unroll
@@ -570,7 +579,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const int v = wave + 4 * vv;
       const int Ib = v * G + b / rem;
       const int row = 4 * Ib + r4, col = 4 * (4 * NQ + b % rem) + c4;
-      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) gA[row * D + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
+      if (v < NLEFT && b < G * REM && Ib < NB && row < D && col < D) outb[row * ldo + col] = a.dt * (accl[vv] - uv[row] * mv[col]);
+    }
+    if (VGPA_GRAD_STAGE_OUT) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < EPT; q++) {
+        const int e = tid + q * NT;
+        if (e < DD) {
+          const int i = (int)(((unsigned)e * magic) >> 20);
+          gA[e] = QT[i * LD + (e - i * D)];
+        }
+      }
     }
     if (!QMODE && t + 1 < t_end) request(t + 1);
   }

@@ -182,8 +182,9 @@ struct WaveGemmGeo {
   static constexpr int NU = NB * NQ + NLEFT;
 };
 
-// UPPER: only the units that hold an element with row <= col (a symmetric result of which the caller keeps the upper triangle)
-template <int NB, int MODE, bool UPPER = false>
+// TRI = 1: only the units that hold an element with row <= col (a symmetric result of which the caller keeps the upper triangle);
+// TRI = 2: ... with row >= col (the lower triangle)
+template <int NB, int MODE, int TRI = 0>
 __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const double* __restrict__ Bm, int LD,
                                           double (&acc)[WaveGemmGeo<NB>::NU], const double* __restrict__ bscale = nullptr) {
   using g = WaveGemmGeo<NB>;
@@ -210,17 +211,18 @@ __device__ __forceinline__ void wave_gemm(const double* __restrict__ Aop, const 
       if (MODE == 1 && kk < I) continue;
       bool any = false;
 #pragma unroll
-      for (int q = 0; q < g::NQ; q++) any = any || (kk >= 4 * q && !(UPPER && 4 * q + 3 < I));
+      for (int q = 0; q < g::NQ; q++) any = any || (kk >= 4 * q && !(TRI == 1 && 4 * q + 3 < I) && !(TRI == 2 && 4 * q > I));
       if (!any) continue;
       const double af = pa[kk * 4 * LD + 4 * I];
 #pragma unroll
       for (int q = 0; q < g::NQ; q++)
-        if (kk >= 4 * q && !(UPPER && 4 * q + 3 < I)) acc[q * NB + I] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * NB + I], 0, 0, 0);
+        if (kk >= 4 * q && !(TRI == 1 && 4 * q + 3 < I) && !(TRI == 2 && 4 * q > I)) acc[q * NB + I] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bq[q], acc[q * NB + I], 0, 0, 0);
     }
     if (g::NLEFT > 0 && kk >= 4 * g::NQ) {
 #pragma unroll
       for (int v = 0; v < g::NLEFT; v++) {
         if (MODE == 1 && kk < v * g::G) continue;
+        if (TRI == 2 && v * g::G + g::G - 1 < 4 * g::NQ) continue;      // every row block of the unit lies above its column blocks
         int ib = v * g::G + ileft;
         ib = ib < NB ? ib : NB - 1;                          // spare block slots read valid memory; result unused
         const double af = pa[kk * 4 * LD + 4 * ib];
@@ -1034,8 +1036,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   double* ds = a.dEs + o * D * D;
   {
     double acc[WaveGemmGeo<NB>::NU];
-    if (a.ds_upper) {                 // (units below the diagonal are not even computed: -22 % of the SYRK's products at NB = 10)
-      wave_gemm<NB, 1, true>(S.Lm, S.Lm, LD, acc, S.qq);
+    if (a.ds_packed) {                // the lower triangle, packed (a row's 16-column segment of a unit is contiguous): the units above the
+      using gg = WaveGemmGeo<NB>;     // diagonal are not computed
+      double* dsp = a.dEs + o * PK;
+      wave_gemm<NB, 1, 2>(S.Lm, S.Lm, LD, acc, S.qq);
+#pragma unroll
+      for (int u = 0; u < gg::NU; u++) {
+        if (u < NB * gg::NQ && 4 * (u / NB) > u % NB) continue;
+        if (u >= NB * gg::NQ && (u - NB * gg::NQ) * gg::G + gg::G - 1 < 4 * gg::NQ) continue;
+        int row, col; bool ok;
+        wave_gemm_elem<NB>(u, row, col, ok);
+        if (ok && row < D && col <= row) dsp[tri_off(row) + col] = 0.5 * c * acc[u];
+      }
+    } else if (a.ds_upper) {          // (units below the diagonal are not even computed: -22 % of the SYRK's products at NB = 10)
+      wave_gemm<NB, 1, 1>(S.Lm, S.Lm, LD, acc, S.qq);
 #pragma unroll
       for (int u = 0; u < WaveGemmGeo<NB>::NU; u++) {
         if (u < NB * WaveGemmGeo<NB>::NQ && 4 * (u / NB) + 3 < u % NB) continue;

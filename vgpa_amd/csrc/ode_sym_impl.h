@@ -489,6 +489,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
       wm[s] = act && row != col;
       own[s] = act && row < D && col < D;
       gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? row * D + col : col * D + row) : 0u;     // (the upper triangle: all that EnergyArgs::ds_upper writes)
+      if (!FWD && a.ds_packed) gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? tri_off(col) + row : tri_off(row) + col) : 0u;      // (packed lower triangle, EnergyArgs::ds_packed)
       colJ[s] = 0;
     }
 #pragma unroll
@@ -517,6 +518,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
       wm[s] = act && row != col;
       own[s] = act && row < D && col < D;
       gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? row * D + col : col * D + row) : 0u;     // (the upper triangle: all that EnergyArgs::ds_upper writes)
+      if (!FWD && a.ds_packed) gofs[s] = own[s] ? 8u * (unsigned)(row <= col ? tri_off(col) + row : tri_off(row) + col) : 0u;      // (packed lower triangle, EnergyArgs::ds_packed)
     }
   }
   }
@@ -550,13 +552,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
     }
   };
   // ---- matrix state -----------------------------------------------------------------------------------------------------
-  const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * DD;
+  const int GS = (!FWD && a.ds_packed) ? D * (D + 1) / 2 : DD;      // doubles per matrix of the forcing-term stream
+  const double* G = FWD ? a.Sigma : a.dEs + (size_t)prob * Np * GS;
   double* const mout = (FWD ? a.S : a.psi) + (size_t)prob * Np * (spk ? D * (D + 1) / 2 : DD);
   double xk[MAXS], acc[MAXS], fc[MAXS], fn[MAXS], fnn[MAXS];
 #pragma unroll
   for (int s = 0; s < MAXS; s++) {
-    fc[s] = ldg(G + (FWD ? 0 : (size_t)tidx(0) * DD), gofs[s]);
-    fn[s] = FWD ? 0.0 : ldg(G + (size_t)tclamp(1) * DD, gofs[s]);
+    fc[s] = ldg(G + (FWD ? 0 : (size_t)tidx(0) * GS), gofs[s]);
+    fn[s] = FWD ? 0.0 : ldg(G + (size_t)tclamp(1) * GS, gofs[s]);
     fnn[s] = 0.0;
     xk[s] = (FWD && own[s]) ? ldg(a.S0, gofs[s]) : 0.0;
     acc[s] = 0.0;
@@ -622,7 +625,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
     c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
     if (!FWD) {
 #pragma unroll
-      for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * DD, gofs[s]);
+      for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * GS, gofs[s]);
       jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
       n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
     }

@@ -39,6 +39,8 @@ struct vgpa_ctx {
   double *d_dEs_c = nullptr, *d_psi_c = nullptr;
   bool psi_is_q = false;       // d_psi holds Q''_t = A_t / sigma^2 - 2 Psi_t (fused batched sweeps, OdeArgs::q_on)
   bool des_upper = false;      // d_dEs holds the upper triangles only (EnergyArgs::ds_upper)
+  bool des_packed = false;     // d_dEs holds packed lower triangles (EnergyArgs::ds_packed); d_jscp = the constant matrix jump in the same layout
+  double* d_jscp = nullptr;
   bool isg_iso = false;        // Sigma = sigma^2 I
   double isg0 = 1.0;           // 1 / sigma^2 then
   std::vector<int32_t> h_obs_idx; // host copy of obs_idx [Np]
@@ -302,7 +304,8 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
   a.strideA = a.strideB = c->len_x;
   a.A = ctx_A(c); a.dEm = c->d_dEm; a.dEs = c->d_dEs; a.lam = c->d_lam; a.psi = c->d_psi;
   if (dense_jumps) { a.jm_dense = c->d_jm_dense; a.js_dense = c->d_js_dense; }
-  else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->d_jsc; a.n_obs = c->M; }
+  else { a.obs_idx = c->d_obs_idx; a.jm_sparse = c->d_jm; a.js_const = c->des_packed ? c->d_jscp : c->d_jsc; a.n_obs = c->M; }
+  a.ds_packed = c->des_packed ? 1 : 0;
   // fused sweeps on the fragment-cover kernels: Q''_t instead of Psi_t (the gradient assembly then does not read A_t; see
   // VGPA_FLAG_KEEP_PSI).  Same condition as the kernel choice below and as run_grad's matrix-core assembly.
   c->psi_is_q = !dense_jumps && a.sym_units && !use_lane(c) && !use_wave(c) && use_mfma(c, false, sym) && c->sigma_diag && c->isg_iso &&
@@ -339,8 +342,9 @@ static int ensure_lde_ws(vgpa_ctx* c) {
   return dev_alloc(c, &c->d_lde_ws, ld::lde_workspace_doubles(c->D, c->lde_nb));
 }
 
-static int run_energy(vgpa_ctx* c, double* edf, bool ds_upper = false) {
+static int run_energy(vgpa_ctx* c, double* edf, bool ds_upper = false, bool ds_packed = false) {
   c->des_upper = false;
+  c->des_packed = false;
   { int rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD); if (rc) return rc; }
   if (c->D > kMaxSmallD) {
     if (c->cfg.model != VGPA_MODEL_L96) return fail(c, VGPA_ERR_UNSUPPORTED, "large-D energy terms exist for Lorenz-96 only");
@@ -358,7 +362,10 @@ static int run_energy(vgpa_ctx* c, double* edf, bool ds_upper = false) {
     return VGPA_OK;
   }
   c->des_upper = ds_upper && c->cfg.model == VGPA_MODEL_L96 && c->D >= 5;       // (the L96 kernels of 5 <= D <= 64 honour it)
+  c->des_packed = c->des_upper && ds_packed && c->s_packed;                     // (k_energy_l96_r, the kernel that reads packed S_t, does)
+  if (c->des_packed) c->des_upper = false;
   EnergyArgs a = energy_args(c, edf, c->des_upper);
+  a.ds_packed = c->des_packed ? 1 : 0;
   hipError_t e = launch_energy(a, c->stream);
   if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "energy launch failed: %s", hipGetErrorString(e));
   return VGPA_OK;
@@ -602,6 +609,13 @@ static bool s_packed_ok(vgpa_ctx* c) {
          sym_stores_q(c->cfg.method, c->D) && !c->hyp_on && c->D <= kMaxSmallD;
 }
 
+// dEsde_dS between the energy kernel and the backward cover kernel as packed lower triangles: wherever S_t is packed (the same two
+// kernels sit on either side); VGPA_DS_PACKED=0 in the environment keeps the upper triangles in whole matrices (comparison runs)
+static bool ds_packed_ok(vgpa_ctx* c) {
+  static const bool off = [] { const char* e = getenv("VGPA_DS_PACKED"); return e && e[0] == '0'; }();
+  return !off && c->s_packed && c->d_jscp != nullptr;
+}
+
 // consumers that want S_t whole (vgpa_fetch, the operator-level kernels): the unpacked copy
 static int unpack_S(vgpa_ctx* c, const double** full) {
   *full = c->d_S;
@@ -634,7 +648,7 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   const bool sym_bwd = use_sym_units(c) && !use_lane(c) && !use_wave(c) && use_mfma(c, false, c->sym_inputs) && c->D <= kMaxSmallD &&
                        !(c->cfg.flags & VGPA_FLAG_KEEP_PSI);
   for (int r = diag_repeat("energy"); r > 0; r--)
-    if ((rc = run_energy(c, nullptr, sym_bwd))) return rc;
+    if ((rc = run_energy(c, nullptr, sym_bwd, ds_packed_ok(c)))) return rc;
   prof_mark(c, 2);
   for (int r = diag_repeat("bwd"); r > 0; r--)
     if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
@@ -875,6 +889,13 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   TRY(upload(c, c->d_K, K.data(), DD));
   TRY(upload(c, c->d_rinv, rinv.data(), (size_t)D));
   TRY(upload(c, c->d_jsc, jsc.data(), DD));
+  {      // the same (symmetric) matrix as a packed lower triangle, for the backward kernels that read a packed dEsde_dS stream
+    std::vector<double> jp((size_t)DD, 0.0);
+    for (int r = 0; r < D; r++)
+      for (int q = 0; q <= r; q++) jp[(size_t)r * (r + 1) / 2 + q] = jsc[(size_t)r * D + q];
+    TRY(dev_alloc(c, &c->d_jscp, DD));
+    TRY(upload(c, c->d_jscp, jp.data(), DD));
+  }
   HTRY(hipStreamSynchronize(c->stream));
 #undef TRY
 #undef HTRY
@@ -927,6 +948,7 @@ int vgpa_solve_bwd(vgpa_ctx* c, const double* lin_a, const double* desde_dm, con
   if ((rc = ensure(c, &c->d_psi, BN * c->DD))) return rc;
   if ((rc = upload(c, c->d_dEs, desde_ds, BN * c->DD))) return rc;
   c->des_upper = false;                  // the caller's array is complete
+  c->des_packed = false;
   if ((rc = upload(c, c->d_jm_dense, deobs_dm, BN * c->D))) return rc;
   if ((rc = upload(c, c->d_js_dense, deobs_ds, BN * c->DD))) return rc;
   const bool sym = stack_symmetric(desde_ds, BN, c->D) && stack_symmetric(deobs_ds, BN, c->D);
@@ -1175,6 +1197,13 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
     case VGPA_FETCH_DESDE_DM: rc = download(c, out, c->d_dEm, BN * c->D); break;
     case VGPA_FETCH_DESDE_DS:
       if (!c->d_dEs || c->stream_ld) return fail(c, VGPA_ERR_UNSUPPORTED, "dEsde_dS is not kept by the time-chunked large-D sweep");
+      if (c->des_packed) {             // whole matrices into the scratch copy the unpacked S_t uses too (the packed stream stays as it is)
+        if ((rc = ensure(c, &c->d_Sfull, BN * c->DD))) return rc;
+        hipError_t e = launch_unpack_lower(BN, c->D, c->d_dEs, c->d_Sfull, c->stream);
+        if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "unpack launch failed: %s", hipGetErrorString(e));
+        rc = download(c, out, c->d_Sfull, BN * c->DD);
+        break;
+      }
       if (c->des_upper) {
         hipError_t e = launch_mirror_upper(BN, c->D, c->d_dEs, c->stream);
         if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "mirror launch failed: %s", hipGetErrorString(e));

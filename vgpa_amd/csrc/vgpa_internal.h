@@ -74,6 +74,7 @@ struct OdeArgs {
   // row-major -- element (r, c), c <= r, of grid point t of problem p at S[(p * Np + t) * D (D + 1) / 2 + r (r + 1) / 2 + c] -- which is
   // all the energy kernel factorises and half of what the gradient assembly streams (vgpa_fetch unpacks it on demand)
   int s_packed;
+  int ds_packed;            // dEs holds packed lower triangles (EnergyArgs::ds_packed): symmetric-unit cover kernels, backward
   const double* jmT;     // sparse vector jumps in the same spirit: entry i of observation n of problem p at jmT[(n * D + i) * bpad + p]
 };
 
@@ -113,6 +114,8 @@ struct EnergyArgs {
   int s_packed;             // S holds packed lower triangles (OdeArgs::s_packed)
   int ds_upper;             // L96, D <= 64: write only the upper triangle of dEs (row <= col) -- the consumer is a symmetric-unit backward
                             // kernel, which reads nothing else (fused sweeps; VGPA_FETCH_DESDE_DS mirrors it on the way out)
+  int ds_packed;            // ... as PACKED lower triangles (element (r, c), c <= r, of the symmetric matrix at tri_off(r) + c; matrix
+                            // stride tri_off(D)): k_energy_l96_r with the cover kernels behind it (OdeArgs::ds_packed)
   double* hyp;              // [B][Np][H] per-grid-point integrands of dEsde/dtheta, dEsde/dSigma (nullptr: skipped)
   double* Am;               // [B][Np][D] A_t m_t, a by-product the gradient assembly reuses (L96 kernel; may be nullptr)
   int32_t* status;          // [B] device status word (bit0: S_t not positive definite)
