@@ -304,15 +304,18 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   double sk[DD], sig[DD], mk[D], A0[DD], b0[D];
   ld_mat<D>(a.S0, sk); ld_mat<D>(a.Sigma, sig); ld_vec<D>(a.m0, mk);
   ld_mat<D>(A, A0); ld_vec<D>(b, b0);
-  constexpr int W = DD + D;
+  // (S_t as its packed lower triangle, then m_t: D (D + 1) / 2 + D entries per grid point -- 9 instead of 12 at D = 3)
+  constexpr int TRI = D * (D + 1) / 2, W = TRI + D;
   double* const outT = OUT_T ? a.msT + prob : nullptr;       // entry e of grid point t: outT[(t * W + e) * bpad]
   const size_t bp = (size_t)a.bpad;
   auto store_t = [&](int t) {
     if (live) {
 #pragma unroll
-      for (int e = 0; e < DD; e++) outT[((size_t)t * W + e) * bp] = sk[e];
+      for (int i = 0; i < D; i++)
 #pragma unroll
-      for (int i = 0; i < D; i++) outT[((size_t)t * W + DD + i) * bp] = mk[i];
+        for (int j = 0; j <= i; j++) outT[((size_t)t * W + tri_off(i) + j) * bp] = sk[i * D + j];
+#pragma unroll
+      for (int i = 0; i < D; i++) outT[((size_t)t * W + TRI + i) * bp] = mk[i];
     }
   };
   if (OUT_T) store_t(0);
@@ -557,14 +560,19 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   const long limA = (long)Np * DD, limV = (long)Np * D;
   // the moments come from the context's time-major array (OdeArgs::msT): one coalesced 512-byte load per entry and wave, straight
   // into registers, requested one step ahead
-  constexpr int W = DD + D;
+  constexpr int TRI = D * (D + 1) / 2, W = TRI + D;      // (packed lower triangle of S_t, then m_t: see k_fwd_lane)
   const double* const msT = a.msT + prob;
   const size_t bp = (size_t)a.bpad;
   auto load_ms = [&](int t, double (&Sv)[DD], double (&mv)[D]) {
 #pragma unroll
-    for (int e = 0; e < DD; e++) Sv[e] = msT[((size_t)t * W + e) * bp];
+    for (int i = 0; i < D; i++)
 #pragma unroll
-    for (int i = 0; i < D; i++) mv[i] = msT[((size_t)t * W + DD + i) * bp];
+      for (int j = 0; j <= i; j++) {
+        const double v = msT[((size_t)t * W + tri_off(i) + j) * bp];
+        Sv[i * D + j] = v; Sv[j * D + i] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < D; i++) mv[i] = msT[((size_t)t * W + TRI + i) * bp];
   };
 
   double Iv[DD];
@@ -748,18 +756,22 @@ hipError_t launch_ode_small(int method, bool fwd, const OdeArgs& a, hipStream_t 
 }
 
 namespace {
-// msT [Np][W][bpad] -> m [B][Np][D], S [B][Np][D][D]: one wave per (64 problems, grid point); coalesced reads, per-lane writes
+// msT [Np][W][bpad] (W = D (D + 1) / 2 + D: packed lower triangle of S_t, m_t) -> m [B][Np][D], S [B][Np][D][D] (both triangles): one wave per (64 problems, grid point); coalesced reads, per-lane writes
 // (on demand only: vgpa_fetch and the separate kernels of the four-kernel path)
 __global__ void __launch_bounds__(NTS) k_ms_untranspose(int D, int Np, int batch, int bpad, const double* __restrict__ msT,
                                                         double* __restrict__ m, double* __restrict__ S) {
   const int prob = blockIdx.x * NTS + threadIdx.x, t = blockIdx.y;
   if (prob >= batch) return;
-  const int DD = D * D, W = DD + D;
+  const int DD = D * D, TRI = D * (D + 1) / 2, W = TRI + D;
   const double* src = msT + (size_t)t * W * bpad + prob;
   double* so = S + ((size_t)prob * Np + t) * DD;
   double* mo = m + ((size_t)prob * Np + t) * D;
-  for (int e = 0; e < DD; e++) so[e] = src[(size_t)e * bpad];
-  for (int i = 0; i < D; i++) mo[i] = src[(size_t)(DD + i) * bpad];
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j <= i; j++) {
+      const double v = src[(size_t)(tri_off(i) + j) * bpad];
+      so[i * D + j] = v; so[j * D + i] = v;
+    }
+  for (int i = 0; i < D; i++) mo[i] = src[(size_t)(TRI + i) * bpad];
 }
 
 // Observation terms of the fused lane pass (gaussian_like.py:69-243; same expressions as assemble.hip::k_obs, one lane per problem
@@ -770,7 +782,7 @@ template <int D>
 __global__ void __launch_bounds__(NTS) k_obs_lane(ObsArgs a, const double* __restrict__ msT, int bpad, double* __restrict__ jmT) {
   const int prob = blockIdx.x * NTS + threadIdx.x;
   if (prob >= a.batch) return;
-  constexpr int DD = D * D, W = DD + D;
+  constexpr int TRI = D * (D + 1) / 2, W = TRI + D;
   const size_t bp = (size_t)bpad;
   const double* ms = msT + prob;
   double* jo = jmT + prob;
@@ -793,7 +805,7 @@ __global__ void __launch_bounds__(NTS) k_obs_lane(ObsArgs a, const double* __res
     const double* y = a.obs_y + (size_t)n * D;
     double w[D];
 #pragma unroll
-    for (int j = 0; j < D; j++) w[j] = y[j] - ms[(tn * W + DD + j) * bp];
+    for (int j = 0; j < D; j++) w[j] = y[j] - ms[(tn * W + TRI + j) * bp];
 #pragma unroll
     for (int i = 0; i < D; i++) {
       double qrow = 0.0, krow = 0.0;
@@ -808,7 +820,7 @@ __global__ void __launch_bounds__(NTS) k_obs_lane(ObsArgs a, const double* __res
         }
       }
       jo[((size_t)n * D + i) * bp] = -krow;
-      part += w[i] * qrow + a.rinv_diag[i] * ms[((size_t)n * W + i * D + i) * bp];
+      part += w[i] * qrow + a.rinv_diag[i] * ms[((size_t)n * W + tri_off(i) + i) * bp];
     }
   }
   a.eobs[prob] = 0.5 * (part + a.obs_const);

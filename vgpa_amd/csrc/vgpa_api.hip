@@ -65,7 +65,7 @@ struct vgpa_ctx {
   double obs_const = 0.0, sigma1 = 1.0;
   bool have_state = false;
   bool derived_valid = true;     // dEsde_dm / dEsde_dS / <f> / E_sde(t) / lam / Psi belong to the cached (m, S): false behind a fused lane pass
-  double* d_msT = nullptr;       // fused lane pass: the moments time-major, problem fastest (OdeArgs::msT), [Np][D*D + D][bpad]
+  double* d_msT = nullptr;       // fused lane pass: the moments time-major, problem fastest (OdeArgs::msT), [Np][D(D+1)/2 + D][bpad]: packed lower triangle of S_t, then m_t
   double* d_jmT = nullptr;       // ... and its sparse vector jumps, [M][D][bpad]
   int bpad = 0;
   bool s_packed = false;         // d_S holds packed lower triangles (OdeArgs::s_packed): the fused batched sweeps of the cover kernels
@@ -551,7 +551,7 @@ static int enqueue_lane_sweep(vgpa_ctx* c, double* g_dev) {
   prof_mark(c, 0);
   if (!c->d_msT) {
     c->bpad = 64 * ((c->B + 63) / 64);
-    if ((rc = dev_alloc(c, &c->d_msT, (size_t)c->Np * (c->DD + c->D) * c->bpad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_msT, (size_t)c->Np * (c->D * (c->D + 1) / 2 + c->D) * c->bpad))) return rc;
     if ((rc = dev_alloc(c, &c->d_jmT, (size_t)(c->M > 0 ? c->M : 1) * c->D * c->bpad))) return rc;
   }
   {

@@ -66,7 +66,7 @@ struct OdeArgs {
   int q_on;
   double q_scale;
   // lane-per-problem kernels of the fused small-D sweep (ode_small.hip): the moments in a layout the context owns, TIME-major with the
-  // problem fastest -- entry e (S row-major, then m) of grid point t of problem p at msT[(t * (D*D + D) + e) * bpad + p] -- so that a
+  // problem fastest -- entry e (the packed lower triangle of S_t, then m_t: W = D (D + 1) / 2 + D entries) of grid point t of problem p at msT[(t * W + e) * bpad + p] -- so that a
   // wave's 64 lanes read / write 512 contiguous bytes per entry straight from / into registers; nullptr: the [B][Np] arrays m / S
   double* msT;
   int bpad;
