@@ -425,8 +425,18 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // products, stepper, publish, barrier, first fragments: ~2 300 cycles with four waves -- loses most of its product share.  For
 // batches up to one problem per CU (the reference's own use case is ONE optimisation); larger batches keep two four-wave
 // workgroups per CU, whose 256 registers per wave an eight-wave workgroup pair cannot have.
-template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4>   // WPE: waves per SIMD the register budget allows for
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
+// HLP (round 4; fragment cover, four product waves): FOUR HELPER WAVES beside the four product waves of a problem, one of each per SIMD.
+// A wave issues one instruction at a time and an fp64 product holds its issue slot for all 16 cycles (a v_mov between two products costs
+// its full 8 cycles, tools/ubench/mfma_dpp_overlap.hip), so everything of a stage that is not the product -- the vector recursion,
+// operand staging, the state's way to HBM, the step's HBM loads: the "chores" -- lengthens a lone workgroup's stage by what it
+// issues (1 120 cycles of products in a 2 500-cycle stage).  With helpers the product waves keep the products, the element-wise
+// stepper and the publish; helper wave w + 4 does the chores of product wave w (same thread -> item tables), concurrently, on the
+// same SIMD's other issue slot; both meet at the one barrier per stage that was there before.  Nothing a chore writes is read during
+// its stage and nothing it reads is written (see tailC), so no new synchronisation.  512 threads, 256 registers each: ONE workgroup
+// per CU -- the shape for up to one problem per CU (the reference's own use case is one optimisation); larger batches keep two
+// four-wave workgroups per CU.
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4, bool HLP = false>   // WPE: waves per SIMD the register budget allows for
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 1), 64 * NW * (HLP ? 2 : 1)), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = SGeo<NB, NW>;
@@ -440,10 +450,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
   static_assert(!OPC || !W8, "the outer-product cover runs on four waves");
   static_assert(!COVER || (g::NSB == 5 && g::MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
   static_assert(!W8 || COVER, "eight waves per problem: fragment-cover kernels only");
+  static_assert(!HLP || (COVER && NW == 4), "helper waves: fragment-cover kernels on four product waves");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
   constexpr double sixth = 1.0 / 6.0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool helper = HLP && (int)threadIdx.x >= 64 * NW;     // (wave-uniform) this wave does the chores of product wave `wave`
+  const int tid = helper ? (int)threadIdx.x - 64 * NW : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave & 3, half = W8 ? (wave >> 2) : 0;      // cover wave whose units this wave multiplies; which half of them (W8)
   const int prob = (int)blockIdx.x;
   const int D = a.D, Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
@@ -621,12 +633,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
 
   // every HBM load of a step, issued together (see "Memory waits"): what the step after the next one needs
   auto prefetch = [&](int step) {
-    load_a(A + (size_t)tclamp(step + 2) * DD);
-    c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+    const bool chores = !HLP || helper, units = !HLP || !helper;      // (helper waves: the operand and the vector; product waves: G_t)
+    if (chores) {
+      load_a(A + (size_t)tclamp(step + 2) * DD);
+      c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+    }
     if (!FWD) {
+      if (units) {
 #pragma unroll
-      for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * GS, gofs[s]);
-      jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
+        for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * GS, gofs[s]);
+      }
+      if (chores) jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
       n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
     }
   };
@@ -1154,7 +1171,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
     const int op = stage_op<METHOD, FWD>(j, matrix, k);
     return op == OP_X ? xcur(k, j) : (op == OP_M ? Mb : Rb);
   };
-  product_begin(aop(0, 0, true), xcur(0, 0));
+  if (!(HLP && helper)) product_begin(aop(0, 0, true), xcur(0, 0));
   VGPA_STAMP_DECL;
   // Chores between the products (round 3).  Nothing of a stage but the stepper depends on the stage's product, so everything
   // else is issued INSIDE the product pipeline, where its LDS and HBM latencies run under matrix-core work instead of behind it
@@ -1215,7 +1232,27 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
       double* pv = pvb + (Xc == Xb0 ? 0 : g::PV);
       double* pv_prev = pvb + (Xc == Xb0 ? g::PV : 0);         // where the previous stage left its partial sums
       const double* Aopv = aop(k, j, false);
+      if (HLP && helper) {
+        // every chore of the stage, requests first: the partial sums of the previous stage and (stage 0) the start-point operand and
+        // the stage state; then the vector update, its partial products (they read the vector just written, same wave, in order),
+        // the staging, the HBM stores and loads
+        if (j > 0 || k > 0) vecA_read(pv_prev);
+        tailC_read(j, Xc);
+        if (j > 0) vecA_finish(j - 1);
+        else if (k > 0) {
+          vecA_finish(NS - 1);
+          c0 = c1; c1 = c2;
+          if (!FWD) jm = jm_next;
+        }
+        tailB_read(Aopv);
+        tailB_finish(pv);
+        tailC_finish(j, k);
+      } else
       product_stage(j, k, aop(k, j, true), Xc, Xn, [&](int t) {
+        if (HLP) {                       // (product waves beside helpers: only their own HBM loads -- G_t of the step after the next)
+          if (t == SC_F && j == JSEC) prefetch(k);
+          return;
+        }
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
         if (!VGPA_ABL_NOVEC) {
         if (t == SA_R && (j > 0 || k > 0)) vecA_read(pv_prev);
@@ -1240,11 +1277,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), am
       VGPA_STAMP(0, 2);
       // the next stage's first fragments (Xn is complete now; past the last stage of the sweep they are read and dropped)
       const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
-      product_begin(aop(kn, jn, true), Xn);
+      if (!(HLP && helper)) product_begin(aop(kn, jn, true), Xn);
       __builtin_amdgcn_s_setprio(0);
       VGPA_STAMP(0, 3);
     }
   }
+  if (HLP && !helper) return;             // (the last state and the last vector leave through the helper waves)
   if (n_steps > 0) {                     // the last stage's vector update
     vecA_read(pvb + (xcur(n_steps, 0) == Xb0 ? g::PV : 0));
     vecA_finish(NS - 1);
@@ -1279,25 +1317,39 @@ inline bool old_cover() {
   static const bool op = [] { const char* e = getenv("VGPA_SYM_COVER"); return e && !strcmp(e, "op"); }();
   return !op;
 }
-template <int METHOD, bool FWD, int NB, int GRC>
+template <int METHOD, bool FWD, int NB, int GRC, bool HLP = false>
 hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
   constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
-  constexpr int WPE_C = 2 * lds_c <= 160 * 1024 ? 2 : 1;
+  constexpr int WPE_C = (HLP || 2 * lds_c <= 160 * 1024) ? 2 : 1;
+  constexpr int threads = HLP ? 512 : 256;
   if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
     if (a.q_on) {
       if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)
-      auto kq = k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C, true>;
+      auto kq = k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C, true, 4, HLP>;
       if (lds_c > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-      hipLaunchKernelGGL(kq, dim3(a.batch), dim3(256), lds_c, st, a);
+      hipLaunchKernelGGL(kq, dim3(a.batch), dim3(threads), lds_c, st, a);
       return hipGetLastError();
     }
   }
-  auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, GRC, WPE_C> : k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C>;
+  auto kc = dense ? k_ode_sym<METHOD, FWD, NB, true, GRC, WPE_C, false, 4, HLP> : k_ode_sym<METHOD, FWD, NB, false, GRC, WPE_C, false, 4, HLP>;
   if (lds_c > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-  hipLaunchKernelGGL(kc, dim3(a.batch), dim3(256), lds_c, st, a);
+  hipLaunchKernelGGL(kc, dim3(a.batch), dim3(threads), lds_c, st, a);
   return hipGetLastError();
+}
+
+// Helper waves (k_ode_sym, HLP): up to one problem per CU.  VGPA_SYM_HELPERS=0 / 1 in the environment forces them off / on for
+// every batch size (comparison runs, tests).
+inline bool helper_waves(int batch) {
+  static const int forced = [] { const char* e = getenv("VGPA_SYM_HELPERS"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+  }();
+  return batch <= n_cu;
 }
 
 template <int METHOD, bool FWD, int NB>
@@ -1329,6 +1381,7 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(k8, dim3(a.batch), dim3(512), lds_8, st, a);
       return hipGetLastError();
     }
+    if (!runs_only && old_cover() && helper_waves(a.batch)) return launch_cover<METHOD, FWD, NB, 0, true>(a, st, dense);
     if (!runs_only) return old_cover() ? launch_cover<METHOD, FWD, NB, 0>(a, st, dense) : launch_cover<METHOD, FWD, NB, -1>(a, st, dense);
   }
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
