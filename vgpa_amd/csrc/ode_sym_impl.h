@@ -31,6 +31,7 @@
 //     row-pair items).  Everything of a stage that is not the product is ONE LDS round trip behind it (`tail`).
 // Measurements, what was tried and what bounds the kernel: DESIGN.md s.4.1, s.7, EXPERIMENTS.md s.2, s.9, s.11; micro-benchmark tools/ubench/sym_product.hip.
 #pragma once
+#include <type_traits>
 #include "ode_mfma_impl.h"
 #include <cstdlib>
 #include <cstring>
@@ -632,8 +633,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   };
 
   // every HBM load of a step, issued together (see "Memory waits"): what the step after the next one needs
-  auto prefetch = [&](int step) {
-    const bool chores = !HLP || helper, units = !HLP || !helper;      // (helper waves: the operand and the vector; product waves: G_t)
+  auto prefetch = [&](int step, auto helper_role) {
+    constexpr bool HR = decltype(helper_role)::value;
+    constexpr bool chores = !HLP || HR, units = !HLP || !HR;         // (helper waves: the operand and the vector; product waves: G_t)
     if (chores) {
       load_a(A + (size_t)tclamp(step + 2) * DD);
       c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
@@ -754,7 +756,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
       store_items(tc_items, tidx(step));
     }
     if (j == JSEC && NS > 1) store_a(Rb, an);
-    if (j == JSEC) prefetch(step);       // (overwrites an[]: behind its last use of the step)
+    if (j == JSEC) prefetch(step, std::true_type{});       // (overwrites an[]: behind its last use of the step; with helper waves: their part)
   };
 
   // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
@@ -824,7 +826,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
 #ifndef VGPA_SYM_HALF_BWD
 #define VGPA_SYM_HALF_BWD 1
 #endif
-  constexpr bool HALF = COVER && !OPC && !W8 && (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD);
+  #ifndef VGPA_SYM_HALF_HLP
+#define VGPA_SYM_HALF_HLP 0            // helper-wave kernels: the product waves have the registers for two buffers of all four maps, backward too
+#endif
+  constexpr bool HALF = COVER && !OPC && !W8 && (HLP ? VGPA_SYM_HALF_HLP : (FWD ? VGPA_SYM_HALF_FWD : VGPA_SYM_HALF_BWD));
   // W8: three maps per wave -- row side a0 (first half) or a1 (second half), column side b0, b1 -- of both operands, two buffers
   d2_t fA8[2][W8 ? 3 : 1], fX8[2][W8 ? 3 : 1];
   const int col8[3] = {half ? colm[1] : colm[0], colm[2], colm[3]};
@@ -1215,13 +1220,21 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   constexpr int SA_F = W8 ? cmin(1, LAST) : 0, SA_R = (SPA || W8) ? -1 : SA_F;
   constexpr int SB_F = W8 ? LAST : (SPLIT ? cmin(1, LAST) : TBU), SB_R = W8 ? cmin(2, LAST) : (SPB ? 0 : SB_F);
   constexpr int SC_F = W8 ? cmin(3, LAST) : (SPLIT ? cmin(2, LAST) : TCU), SC_R = W8 ? 0 : (SPC ? cmin(1, LAST) : SC_F);
+  // (helper waves: the loop exists twice, once per role, so that each role's loop carries only its own state -- one loop with a role
+  //  branch inside keeps the union of both alive across the back-edge, and the backward instantiations spill)
+  auto time_loop = [&](auto helper_role) {
+  constexpr bool HR = HLP && decltype(helper_role)::value;      // this copy is the helper waves'
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
+      if (!HLP || HR) {
 #pragma unroll
-      for (int q = 0; q < NITS; q++) settle(an[q]);
+        for (int q = 0; q < NITS; q++) settle(an[q]);
+      }
       if (!FWD) {
+        if (!HR) {
 #pragma unroll
-        for (int s = 0; s < MAXS; s++) { fc[s] = fn[s]; fn[s] = fnn[s]; }
+          for (int s = 0; s < MAXS; s++) { fc[s] = fn[s]; fn[s] = fnn[s]; }
+        }
         n_obs_cur = n_obs_next; n_obs_next = n_obs_nn;
       }
     }
@@ -1232,7 +1245,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
       double* pv = pvb + (Xc == Xb0 ? 0 : g::PV);
       double* pv_prev = pvb + (Xc == Xb0 ? g::PV : 0);         // where the previous stage left its partial sums
       const double* Aopv = aop(k, j, false);
-      if (HLP && helper) {
+      if constexpr (HR) {
         // every chore of the stage, requests first: the partial sums of the previous stage and (stage 0) the start-point operand and
         // the stage state; then the vector update, its partial products (they read the vector just written, same wave, in order),
         // the staging, the HBM stores and loads
@@ -1250,7 +1263,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
       } else
       product_stage(j, k, aop(k, j, true), Xc, Xn, [&](int t) {
         if (HLP) {                       // (product waves beside helpers: only their own HBM loads -- G_t of the step after the next)
-          if (t == SC_F && j == JSEC) prefetch(k);
+          if (t == SC_F && j == JSEC) prefetch(k, std::false_type{});
           return;
         }
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
@@ -1277,11 +1290,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
       VGPA_STAMP(0, 2);
       // the next stage's first fragments (Xn is complete now; past the last stage of the sweep they are read and dropped)
       const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
-      if (!(HLP && helper)) product_begin(aop(kn, jn, true), Xn);
+      if (!HR) product_begin(aop(kn, jn, true), Xn);
       __builtin_amdgcn_s_setprio(0);
       VGPA_STAMP(0, 3);
     }
   }
+  };
+  if (HLP && helper) time_loop(std::true_type{});
+  else time_loop(std::false_type{});
   if (HLP && !helper) return;             // (the last state and the last vector leave through the helper waves)
   if (n_steps > 0) {                     // the last stage's vector update
     vecA_read(pvb + (xcur(n_steps, 0) == Xb0 ? g::PV : 0));
