@@ -616,9 +616,39 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
   // moments of the next TWO grid points down: requested two steps ahead (under a full chip the memory round trip is longer
   // than one step of a lone wave)
-  double Sn[DD], mn[D], Sn2[DD], mn2[D];
-  load_ms(Np > 1 ? Np - 2 : 0, Sn, mn);
-  load_ms(Np > 2 ? Np - 3 : 0, Sn2, mn2);
+  // (Sc: the step's own grid point; the rotation and the request for three points down sit at the END of a step, so that the wait the
+  //  rotation needs -- across the loop's back-edge the compiler makes it cover every load in flight -- comes a whole step of arithmetic
+  //  behind the requests of the next chunk, which are issued in front of a chunk's first step)
+  double Sc[DD], mc[D], Sn[DD], mn[D], Sn2[DD], mn2[D];
+  load_ms(Np > 1 ? Np - 2 : 0, Sc, mc);
+  load_ms(Np > 2 ? Np - 3 : 0, Sn, mn);
+  load_ms(Np > 3 ? Np - 4 : 0, Sn2, mn2);
+  // The jumps (dE_obs behind the step that ends at an observation) are requested a step ahead like the moments and rotated at the same
+  // place, the END of a step.  A conditional load in the middle of the step made the compiler wait, at the TOP of every step, for the
+  // previous step's possible jump loads before it overwrote their registers -- s_waitcnt vmcnt(0), i.e. for the moment requests issued
+  // a few instructions earlier: one exposed memory round trip per grid point (7 600 of a step's 11 700 cycles).
+  // The constant matrix jump comes through scalar loads, once; w = 1 behind an observation, else 0.
+  double jsc[DD];
+#pragma unroll
+  for (int e = 0; e < DD; e++) jsc[e] = a.js_const ? lds_const(a.js_const, e) : 0.0;
+  auto obs_at = [&](int t1) -> int { return (a.obs_idx && t1 >= 0) ? ldu(a.obs_idx, t1) : -1; };
+  auto request_jump = [&](int n, double (&jm)[D]) {          // (n: wave-uniform)
+    if (n >= 0) {
+      if (a.jmT) {
+#pragma unroll
+        for (int i = 0; i < D; i++) jm[i] = a.jmT[((size_t)n * D + i) * (size_t)a.bpad + prob];
+      } else {
+        ld_vec<D>(a.jm_sparse + ((size_t)prob * a.n_obs + n) * D, jm);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; i++) jm[i] = 0.0;
+    }
+  };
+  double jm_cur[D], jm_nxt[D];
+  int n_cur = obs_at(Np - 2), n_nxt = obs_at(Np - 3), n_pre = obs_at(Np - 4);      // observation index of the step's, the next step's, ... grid point
+  request_jump(n_cur, jm_cur);
+  request_jump(n_nxt, jm_nxt);
   double* rowA = sA + lane * row_stride<NA>();
   double* rowB = sB + lane * row_stride<NV>();
   for (int c = 0; c < nchunks; c++) {
@@ -640,17 +670,25 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int slot = T - 1 - s;
         double Am[DD], bm[D], mm[D], Sm[DD], gsm[DD], gmm[D], e_m, ef[D], edf[DD];
 #pragma unroll
-        for (int e = 0; e < DD; e++) { Am[e] = rowA[slot * DD + e]; Sm[e] = Sn[e]; Sn[e] = Sn2[e]; }
+        for (int e = 0; e < DD; e++) { Am[e] = rowA[slot * DD + e]; Sm[e] = Sc[e]; }
 #pragma unroll
-        for (int i = 0; i < D; i++) { bm[i] = rowB[slot * D + i]; mm[i] = mn[i]; mn[i] = mn2[i]; }
-        load_ms(idx > 1 ? idx - 2 : 0, Sn2, mn2);
+        for (int i = 0; i < D; i++) { bm[i] = rowB[slot * D + i]; mm[i] = mc[i]; }
         point_terms<MODEL, D>(q, Am, bm, mm, Sm, gsm, gmm, e_m, ef, edf);
         esum += dt * (e_t + e_m) / 2.0;     // my_trapz, utilities.py:144 (interval [t-1, t])
         e_t = e_m;
         if (GRAD) {
-          double js[DD], jm[D];
-          load_jump<D>(a, prob, idx, js, jm);
-          bwd_step<METHOD, D>(At, Am, gst, gsm, gmt, gmm, js, jm, dt, pk, lk);
+#ifndef VGPA_LANE_JUMP_PREFETCH
+#define VGPA_LANE_JUMP_PREFETCH 1
+#endif
+          double js[DD];
+#if VGPA_LANE_JUMP_PREFETCH
+          const double wj = n_cur >= 0 ? 1.0 : 0.0;
+#pragma unroll
+          for (int e = 0; e < DD; e++) js[e] = wj * jsc[e];
+#else
+          load_jump<D>(a, prob, idx, js, jm_cur);
+#endif
+          bwd_step<METHOD, D>(At, Am, gst, gsm, gmt, gmm, js, jm_cur, dt, pk, lk);
           double gA[DD], gB[D];
           grad_point<D>(Am, bm, mm, Sm, ef, edf, pk, lk, Iv, dt, gA, gB);
 #pragma unroll
@@ -658,6 +696,22 @@ __global__ void __launch_bounds__(NTS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
           for (int i = 0; i < D; i++) { rowB[slot * D + i] = gB[i]; gmt[i] = gmm[i]; }
         }
+        // everything loaded a step ago is consumed here ...
+#pragma unroll
+        for (int e = 0; e < DD; e++) { Sc[e] = Sn[e]; Sn[e] = Sn2[e]; }
+#pragma unroll
+        for (int i = 0; i < D; i++) { mc[i] = mn[i]; mn[i] = mn2[i]; }
+#if VGPA_LANE_JUMP_PREFETCH
+#pragma unroll
+        for (int i = 0; i < D; i++) jm_cur[i] = jm_nxt[i];
+        n_cur = n_nxt; n_nxt = n_pre;
+#endif
+        // ... and everything the steps after the next one need is requested behind it
+        load_ms(idx > 2 ? idx - 3 : 0, Sn2, mn2);
+#if VGPA_LANE_JUMP_PREFETCH
+        request_jump(n_nxt, jm_nxt);
+        n_pre = obs_at(idx - 3);
+#endif
       }
     }
     if (GRAD) {
@@ -714,15 +768,16 @@ hipError_t launch_m(const OdeArgs& a, hipStream_t st) {
 template <int METHOD, int MODEL>
 hipError_t launch_sweep_mm(const LaneSweepArgs& q, hipStream_t st) {
   dim3 grid((q.o.batch + NTS - 1) / NTS), block(NTS);
-  // Lorenz-63: 4 grid points = 49 KB of LDS per wave, three waves per CU -- measured ahead of 2 grid points with four waves per CU
-  // (4.3 against 5.0 ms per 49152 problems: fewer partial cache lines per chunk; EXPERIMENTS.md s.8); batches fill the chip in
-  // multiples of 768 waves = 49152 problems
-  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 6 : 16;
+  // Lorenz-63: chunks of 4 grid points.  6 (round 4, first version) keeps 108 registers of the next chunk in flight and, with the
+  // moments and jumps of the steps ahead, spills 6-19 of the wave's 512 -- and every reload of a spilled value inside the step loop is
+  // a vector memory operation the compiler waits for with vmcnt(0), i.e. together with every request in flight.  Same box, T = 4 | 6:
+  // 4.67 | 5.16-5.49 ms per 65536 problems (tools/lane_t_scan.sh).
+  constexpr int T = (MODEL == VGPA_MODEL_L63) ? 4 : 16;
 #ifdef VGPA_LANE_T_EXPERIMENTS
   if (MODEL == VGPA_MODEL_L63 && METHOD == VGPA_ODE_RK4 && q.want_grad) {
     const char* e = getenv("VGPA_LANE_T_BWD");
     const int t = e ? atoi(e) : T;
-    if (t == 4) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 4>), grid, block, 0, st, q); return hipGetLastError(); }
+    if (t == 6) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 6>), grid, block, 0, st, q); return hipGetLastError(); }
     if (t == 5) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 5>), grid, block, 0, st, q); return hipGetLastError(); }
     if (t == 8) { hipLaunchKernelGGL((k_sweep_lane<METHOD, MODEL, true, 8>), grid, block, 0, st, q); return hipGetLastError(); }
   }

@@ -18,6 +18,11 @@ __device__ __forceinline__ int ldu(const int32_t* p, int i) {
   typedef const int32_t __attribute__((address_space(4))) * cptr;
   return ((cptr)p)[i];
 }
+// ... and a wave-uniform double (constant matrices read once per kernel: they stay in SGPRs)
+__device__ __forceinline__ double lds_const(const double* p, int i) {
+  typedef const double __attribute__((address_space(4))) * cptr;
+  return ((cptr)p)[i];
+}
 #endif
 
 #ifdef __HIPCC__
