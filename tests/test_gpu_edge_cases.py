@@ -333,6 +333,45 @@ def test_diagnostic_phase_repeat_leaves_the_results_alone():
     assert all(o == outs[0] for o in outs[1:]), outs
 
 
+def test_stepper_variants_of_the_fragment_cover_agree():
+    """33 <= D <= 40 on the fragment-cover steppers: with four helper waves beside the four product waves of a workgroup (the default up
+    to one problem per CU: the chores of a stage off the product waves' issue slots) and without them the same operations run in the same
+    order -- F and the gradient must not differ in any bit; the outer-product cover (VGPA_SYM_COVER=op, a measured-and-rejected
+    experiment: rotated operands by DPP, other block orientations) agrees to rounding.  The switches are read once per process: child
+    processes; RK4 and Heun, an unpadded and a padded dimension, one problem and a small batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_gpu_edge_cases as t\n"
+        "out = {}\n"
+        "for d, method, batch in ((40, 'rk4', 1), (37, 'heun', 3), (33, 'rk2', 2)):\n"
+        "    p, x = t.make_problem('L96', d, 14, method=method)\n"
+        "    ctx = t.gpu_context(p, batch=batch)\n"
+        "    xb = np.stack([x + 0.01 * i for i in range(batch)]) if batch > 1 else x\n"
+        "    f, g = ctx.sweep(xb)\n"
+        "    out['%%d %%s' %% (d, method)] = {'f': [float(v) for v in np.atleast_1d(f)], 'g': np.asarray(g).ravel().tolist()}\n"
+        "    ctx.close()\n"
+        "print(json.dumps(out))\n" % os.path.dirname(__file__))
+    outs = {}
+    for name, env_set in (("helpers", {"VGPA_SYM_HELPERS": "1"}), ("plain", {"VGPA_SYM_HELPERS": "0"}),
+                          ("op", {"VGPA_SYM_HELPERS": "0", "VGPA_SYM_COVER": "op"})):
+        env = dict(os.environ)
+        for k in ("VGPA_SYM_HELPERS", "VGPA_SYM_COVER", "VGPA_SYM_WAVES"):
+            env.pop(k, None)
+        env.update(env_set)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key, ref in outs["plain"].items():
+        assert outs["helpers"][key] == ref, key                      # bit for bit
+        g_ref, g_op = np.asarray(ref["g"]), np.asarray(outs["op"][key]["g"])
+        assert rel_err(g_op, g_ref) < 1e-12 and np.allclose(outs["op"][key]["f"], ref["f"], rtol=1e-13, atol=0.0), key
+
+
 @pytest.mark.parametrize("model,method,n,nb", [("L63", "rk4", 37, 520), ("L63", "rk4", 6, 576), ("L63", "heun", 22, 513), ("L63", "rk2", 9, 640),
                                                ("L63", "euler", 3, 512), ("OU", "euler", 41, 70), ("OU", "rk4", 18, 1), ("DW", "rk4", 33, 130),
                                                ("DW", "heun", 17, 64), ("OU", "rk2", 3, 3)])
