@@ -39,6 +39,7 @@ struct vgpa_ctx {
   double *d_dEs_c = nullptr, *d_psi_c = nullptr;
   bool psi_is_q = false;       // d_psi holds Q''_t = A_t / sigma^2 - 2 Psi_t (fused batched sweeps, OdeArgs::q_on)
   bool des_upper = false;      // d_dEs holds the upper triangles only (EnergyArgs::ds_upper)
+  void* h_fs = nullptr;        // pinned host block [B doubles | B status words]: F and the status words come back in one round trip (vgpa_fetch_f)
   bool des_packed = false;     // d_dEs holds packed lower triangles (EnergyArgs::ds_packed); d_jscp = the constant matrix jump in the same layout
   double* d_jscp = nullptr;
   bool isg_iso = false;        // Sigma = sigma^2 I
@@ -690,6 +691,7 @@ void vgpa_destroy(vgpa_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (void* p : c->user_allocs) (void)hipFree(p);
   if (c->h_coef) (void)hipHostFree(c->h_coef);
+  if (c->h_fs) (void)hipHostFree(c->h_fs);
   for (auto& e : c->ev_coef) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -736,7 +738,9 @@ int vgpa_create(vgpa_ctx** out, const vgpa_config* cfg) {
   HTRY(hipSetDevice(cfg->device));
   HTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   pick_kernel_family(c);
-  for (auto& e : c->ev) HTRY(hipEventCreate(&e));
+  // (phase events: no system-scope fence behind them -- nothing on the host reads device memory at a phase boundary; with the default
+  //  flags five events cost a batched Ornstein-Uhlenbeck step 0.4 of its 1.4 ms)
+  for (auto& e : c->ev) HTRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
 
   // ---- host-side constants -------------------------------------------------------------------
   std::vector<double> sigma(cfg->sigma, cfg->sigma + DD), isig(DD, 0.0), isg(D, 0.0);
@@ -1083,9 +1087,27 @@ int vgpa_free_energy_dev(vgpa_ctx* c, const double* x_dev, double* f_host) {
 int vgpa_fetch_f(vgpa_ctx* c, double* f_host) {
   if (!c || !f_host) return fail(c, VGPA_ERR_ARG, "null argument");
   HIP_TRY(c, hipSetDevice(c->cfg.device));
-  int rc;
-  if ((rc = download(c, f_host, c->d_f, (size_t)c->B))) return rc;
-  return check_status(c);
+  // F and the status words through one pinned block, one synchronisation (a pageable destination makes the copy synchronous by itself,
+  // and check_status is a second round trip: ~0.3 ms per call of a batched context, 15 % of an Ornstein-Uhlenbeck step)
+  const size_t B = (size_t)c->B;
+  if (!c->h_fs && hipHostMalloc(&c->h_fs, B * (sizeof(double) + sizeof(int32_t))) != hipSuccess) {
+    c->h_fs = nullptr;
+    (void)hipGetLastError();
+    int rc;
+    if ((rc = download(c, f_host, c->d_f, B))) return rc;
+    return check_status(c);
+  }
+  double* hf = static_cast<double*>(c->h_fs);
+  int32_t* hs = reinterpret_cast<int32_t*>(hf + B);
+  HIP_TRY(c, hipMemcpyAsync(hf, c->d_f, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hs, c->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::memcpy(f_host, hf, B * sizeof(double));
+  for (size_t p = 0; p < B; p++)
+    if (hs[p] & 1)
+      return fail(c, VGPA_ERR_NOT_PD, "problem %d: marginal covariance S_t is not positive definite "
+                  "(reference: LinAlgError from chol_inv, variational.py:380)", (int)p);
+  return VGPA_OK;
 }
 
 static int finish_gradient(vgpa_ctx* c, double* g_dev);
