@@ -153,6 +153,37 @@ def test_q_stream_of_the_batched_sweeps(d, method):
     ctx_q.close(); ctx_k.close()
 
 
+@pytest.mark.parametrize("d,n_pts,obs", [(40, 2, [1]), (40, 3, [0]), (40, 4, [1, 2]), (40, 5, [3]), (40, 24, None), (33, 3, [1]), (33, 11, None),
+                                         (36, 4, [2]), (37, 9, None), (39, 2, [0])])
+def test_gradient_waves_of_the_backward_kernel(d, n_pts, obs):
+    """Batches of >= 64 Lorenz-96 problems with 33 <= D <= 40 under RK4: the backward kernel assembles the gradient on a third set
+    of waves (k_ode_sym, GF; grad_waves) -- a two-step pipeline per grid point with its own first / second / last steps, so every
+    short grid is a case of its own, and every D < 40 exercises the padding.  Every problem against the same sweep with
+    VGPA_FLAG_KEEP_PSI (backward kernel + separate assembly), some against the oracle; lam_t / Psi_t, which the fused kernel keeps to
+    itself, as vgpa_fetch materialises them; free_energy (no backward recursion at all) followed by gradient(None)."""
+    batch = 67
+    p, x = make_problem("L96", d, n_pts, method="rk4", obs_at=obs)
+    rng = np.random.default_rng(23)
+    xb = x[None, :] + 0.02 * rng.standard_normal((batch, x.size))
+    ctx, ctx_k = gpu_context(p, batch=batch), gpu_context(p, batch=batch, flags=FLAG_KEEP_PSI)
+    fb, gb = ctx.sweep(xb)
+    fk, gk = ctx_k.sweep(xb)
+    assert np.array_equal(fb, fk)
+    assert max(rel_err(gb[i], gk[i]) for i in range(batch)) < 1e-12
+    for i in (0, 31, batch - 1):
+        f_ref, g_ref, st = vo.sweep(p, xb[i], faithful=False)
+        assert abs(fb[i] - f_ref) <= TOL * abs(f_ref) and rel_err(gb[i], g_ref) < TOL
+        if i == 0:
+            lam, psi = ctx.fetch("lamt"), ctx.fetch("psit")
+            assert rel_err(lam[0].reshape(np.shape(st["lamt"])), st["lamt"]) < TOL
+            assert rel_err(psi[0].reshape(np.shape(st["psit"])), st["psit"]) < TOL
+    assert np.array_equal(ctx.gradient(None), gb)            # (after the fetch: the fused kernel again, same bits)
+    f2 = ctx.free_energy(xb[::-1].copy())
+    g2 = ctx.gradient(None)
+    assert np.array_equal(f2, fb[::-1]) and np.array_equal(g2, gb[::-1])
+    ctx.close(); ctx_k.close()
+
+
 @pytest.mark.parametrize("method", ["rk4", "heun"])
 def test_more_problems_than_compute_units(method):
     """bench.py's regime: a batch larger than twice the CU count, so that the default dispatch picks the symmetric-unit steppers and

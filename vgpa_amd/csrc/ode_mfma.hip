@@ -17,6 +17,7 @@ bool ode_mfma_supported(int method, bool, int D) {
 }
 
 bool sym_stores_q(int method, int D) { return sym::stores_q(method, D); }
+bool sym_fuses_grad(int method, int D) { return sym::fuses_grad(method, D); }
 
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st) {
   switch (method) {

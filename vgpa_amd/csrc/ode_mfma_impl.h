@@ -44,6 +44,13 @@ inline bool runs_only_env() {
 inline bool stores_q(int method, int D) {
   return (method == VGPA_ODE_RK2 || method == VGPA_ODE_RK4) && D >= 33 && D <= 40 && !runs_only_env();
 }
+// the backward kernel that assembles the gradient on its helper waves (OdeArgs::grad_on; k_ode_sym, GF): the fragment-cover kernels
+// of RK4 (VGPA_SYM_COVER=op, the outer-product experiment, has no helper waves)
+inline bool fuses_grad(int method, int D) {
+  static const bool op = [] { const char* e = getenv("VGPA_SYM_COVER"); return e && e[0] == 'o' && e[1] == 'p' && !e[2]; }();
+  static const bool off = [] { const char* e = getenv("VGPA_FUSED_GRAD"); return e && e[0] == '0'; }();
+  return method == VGPA_ODE_RK4 && stores_q(method, D) && !op && !off;
+}
 }  // namespace sym
 }  // namespace vgpa
 
@@ -69,6 +76,9 @@ __device__ __forceinline__ void stg(double* base, unsigned off8, double v) {
 
 // Diagnostic build only (tools/ubench/ode_pe_stamp.hip): per-segment cycle sums of one P wave and one E wave of workgroup 0.
 // Never defined in the product build, so no stamp executes there.
+#ifdef VGPA_STAMPS_ROLE
+__device__ long long g_stamp_role[4][16];
+#endif
 #ifdef VGPA_STAMPS
 __device__ long long g_stamp[4][8];
 #define VGPA_STAMP(role, i)                                                                   \

@@ -436,8 +436,385 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // its stage and nothing it reads is written (see tailC), so no new synchronisation.  512 threads, 256 registers each: ONE workgroup
 // per CU -- the shape for up to one problem per CU (the reference's own use case is one optimisation); larger batches keep two
 // four-wave workgroups per CU.
-template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4, bool HLP = false>   // WPE: waves per SIMD the register budget allows for
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 1), 64 * NW * (HLP ? 2 : 1)), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
+// GF (round 5; backward RK4 helper-wave kernels with Q'' on): THE GRADIENT ASSEMBLY INSIDE THE BACKWARD KERNEL, on a THIRD set of four waves
+// (768 threads: product, helper and gradient wave of every SIMD; <= 168 registers each).  gLa_t = dt ((Sigma^-1 (<df/dx> + A_t) -
+// 2 Psi_t) S_t - u m_t^T), u = Sigma^-1 (-<f> - A_t m_t + b_t) + lam_t, gLb_t = dt u (variational.py:263-288, 302-337) is a closed form on
+// what the recursion holds in LDS when step k starts (Psi_t in the stage buffer, A_t in the start-point operand, lam_t from the helpers)
+// plus S_t (packed), m_t, <f>_t, A_t m_t, b_t from HBM.  One grid point per step, one phase per barrier interval of the step:
+//   stage 0: out-buffer of the previous point -> HBM (whole lines); Q''^T = (A_t / sigma^2 - 2 Psi_t)^T from the row-pair units of the
+//            two buffers (both are stable during stage 0) and S_t (both triangles from the packed stream) into two more operand
+//            buffers of the steppers' layout; m_t; the helpers leave lam_t
+//   stage 1: the four-entry band of Sigma^-1 <df/dx> (lorenz_96.py:35-83) is added to Q^T by the rows' lanes; u, gLb -> HBM; the next
+//            grid point's HBM loads
+//   stage 2, 3: Q S on the matrix cores -- 25 units of four 4 x 4 blocks over the four gradient waves (see kGradA) -- then
+//            dt (Q S - u m^T) into the out-buffer
+// Q''_t never goes to HBM (-25.6 KB per grid point), the separate assembly kernel and its launch are gone.  Why a third wave and not
+// the helpers: a helper's stage is a chain of dependent LDS round trips as long as the product waves' stage (measured: the product
+// waves WAIT for the helpers in stages 0 and 1, tools/ubench/ode_gf_loop.hip), so everything added to it lengthened the step by what it
+// took (first version of this round: +1.7 ms per 256-problem launch); the SIMD's third wave runs its own chain beside the two.
+constexpr int kGradA[3][4] = {{0, 1, 3, 2}, {4, 5, 7, 6}, {8, 9, 8, 9}};      // row-side maps (block rows of Q); column-side map s: (s, s, s+1, s+1) mod 10
+__host__ __device__ constexpr int grad_bmap(int s, int q) { return (s + (q >> 1)) % 10; }
+// gradient wave w < 3: maps a0, a1 x column maps 3w, 3w+1, 3w+2 (six units); wave 3: (a0, a1) x 9 and a2 x {9, 1, 3, 5, 7} (seven units):
+// every ordered block pair (I, J) of the 10 x 10 result exactly once (static_assert below), 23 fragment reads per k-pair and workgroup
+__host__ __device__ constexpr int grad_bsel(int w, int i) { return w < 3 ? 3 * w + i : (i == 0 ? 9 : 2 * i - 1); }
+__host__ __device__ constexpr bool grad_cover_exact() {
+  int cnt[10][10] = {};
+  for (int w = 0; w < 4; w++)
+    for (int q = 0; q < 4; q++) {
+      if (w < 3) {
+        for (int ai = 0; ai < 2; ai++)
+          for (int bi = 0; bi < 3; bi++) cnt[kGradA[ai][q]][grad_bmap(grad_bsel(w, bi), q)]++;
+      } else {
+        for (int ai = 0; ai < 3; ai++) cnt[kGradA[ai][q]][grad_bmap(grad_bsel(3, 0), q)]++;
+        for (int bi = 1; bi < 5; bi++) cnt[kGradA[2][q]][grad_bmap(grad_bsel(3, bi), q)]++;
+      }
+    }
+  for (int i = 0; i < 10; i++)
+    for (int j = 0; j < 10; j++)
+      if (cnt[i][j] != 1) return false;
+  return true;
+}
+static_assert(grad_cover_exact(), "the gradient product's units must cover every block of the 10 x 10 result exactly once");
+
+// LDS of the gradient waves, behind the steppers' (offsets in doubles from smem + SGeo::LDS_DOUBLES): two sets of operand buffers
+// (Q^T and S_t of the grid point under construction / of the one being multiplied), the out-buffer, dt u and m_t per set, lam_t
+template <int NB>
+struct GradLds {
+  using g = SGeo<NB, 4>;
+  static constexpr int QT = 0, S = 2 * g::XS, O = 4 * g::XS, U = O + g::PP * g::PP, M = U + 2 * g::PP, LAM = M + 2 * g::PP;
+  static constexpr int DOUBLES = LAM + g::PP;
+};
+
+// The gradient waves of k_ode_sym<..., GF> (threads 512 .. 767).  Pipeline over the backward steps (step k starts with Psi_t, t = Np-1-k,
+// in stage buffer 0 and A_t in the start-point operand R; both are stable during stage 0):
+//   stage 0 of step k: out-buffer (point k-2) -> HBM | build Q^T, S_t, m_t of point k into operand set k & 1 | k-pair 0 of point k-1
+//   stage 1:           band of Sigma^-1 <df/dx> into Q^T of point k, u (lam_t from the helpers), gLb -> HBM; HBM loads of point k+1 | k-pair 1 of point k-1
+//   stage 2:           k-pairs 2, 3 of point k-1
+//   stage 3:           k-pair 4 of point k-1, the result -> out-buffer
+// so that the matrix-core work is spread over the whole step.  Barriers: the same count as the other roles (two in the prologue, four
+// per step, four behind the loop).
+// What this role costs the step is its VECTOR-ALU INSTRUCTION COUNT: while the SIMD's product wave streams fp64 products, another wave's
+// vector-ALU instruction issues once per product slot (22 instead of 5 cycles: tools/ubench/mfma_valu_crosswave.hip; LDS and memory
+// instructions are not affected).  So: every LDS / HBM address is a precomputed per-lane byte offset (tables below; the operand set is a
+// compile-time immediate: the step exists twice), no predicates and no selects -- out-of-range lanes are clamped to a valid duplicate
+// that carries the same value -- and the operand is stored as Q^T / -2 = (Psi_t - (A_t + <df/dx>) / (2 sigma^2))^T: one fused
+// multiply-add per element to build, the factor -2 dt in the epilogue's multiply-add.
+template <int NB>
+__device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict__ smem, const int tid) {
+#pragma clang fp contract(fast)
+  using g = SGeo<NB, 4>;
+  using gl = GradLds<NB>;
+  constexpr int NT = 256, LD = g::LD, NKP = g::NKP, PP = g::PP;
+  static_assert(NKP == 5 && g::NSB == 5, "the gradient product's units are laid out for 33 <= D <= 40");
+  constexpr unsigned GB = 8u * (unsigned)g::LDS_DOUBLES;       // byte offset of this role's LDS
+  constexpr unsigned SETB = 8u * (unsigned)g::XS;              // bytes between the two operand sets (Q^T, S)
+  constexpr unsigned SETV = 8u * (unsigned)PP;                 // ... between the two vector sets (dt u, m)
+  constexpr unsigned RB = 8u * 2u * (unsigned)g::XS;           // the start-point operand R (stage buffer 0 is at 0)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r4 = lane >> 4, bq = (lane >> 2) & 3, c4 = lane & 3;
+  const int prob = (int)blockIdx.x, D = a.D, Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1, PK = a.D * (a.D + 1) / 2;
+  const double dt = a.dt, hq = -0.5 * a.q_scale, m2dt = -2.0 * a.dt;
+  char* const lds = reinterpret_cast<char*>(smem);
+  auto rd2 = [&](unsigned off) -> d2_t { return *reinterpret_cast<const d2_t*>(lds + off); };
+  auto rd1 = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(lds + off); };
+  auto wr1 = [&](unsigned off, double v) { *reinterpret_cast<double*>(lds + off) = v; };
+  auto tidx = [&](int i) { return Np - 1 - i; };
+  const bool vl = lane < D;
+  unsigned lane8 = vl ? 8u * (unsigned)lane : 0u;
+  double* const gbase = a.g + (size_t)prob * a.strideA;
+
+  // ---- per-lane byte offsets (LDS: from smem; HBM: from the grid point's array) ----------------------------------------------------
+  constexpr int NIT = g::NIT;
+  constexpr int NPKI = cdiv(PP * (PP + 1) / 2, NT);      // items of the packed S_t per thread
+  constexpr int NOUT = cdiv(PP * PP, NT);                // doubles of the out-buffer per thread
+  unsigned it_rd[NIT], qt_w0[NIT], qt_w1[NIT];           // row-pair unit (p, c) of Psi / A; Q^T entries (c, 2p), (c, 2p + 1) of set 0
+  unsigned s_w0[NPKI], s_w1[NPKI], s_g[NPKI];            // S_t entries (r, c), (c, r) of set 0; the item in the packed stream
+#pragma unroll
+  for (int q = 0; q < NIT; q++) {
+    const int e = tid + NT * q;
+    int p = e / g::P, c = e - p * g::P;
+    if (!(2 * p < D && c < D)) { p = 0; c = 0; }         // (a duplicate of item (0, 0): same values to the same addresses)
+    it_rd[q] = 8u * (unsigned)unit_off<NB>(p, c);
+    qt_w0[q] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(c, 2 * p));
+    qt_w1[q] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(c, 2 * p + 1));      // (row 2p + 1 = D, D odd: a zero of the padding)
+  }
+#pragma unroll
+  for (int q = 0; q < NPKI; q++) {
+    int e = tid + NT * q;
+    if (e >= PK) e = PK - 1;                             // (a duplicate of the last diagonal element)
+    const int r = tri_row(e), c = e - tri_off(r);
+    s_w0[q] = GB + 8u * (unsigned)(gl::S + elem_off<NB>(r, c));
+    s_w1[q] = GB + 8u * (unsigned)(gl::S + elem_off<NB>(c, r));
+    s_g[q] = 8u * (unsigned)e;
+  }
+  unsigned m_w = GB + 8u * (unsigned)(gl::M + (vl ? lane : 0));      // (every wave writes m_t: the same values)
+  // band of <df/dx> (the lanes i < D of wave 0): Q^T entries (i, i), (i+1, i), (i-2, i), (i-1, i); m_{i-1}, m_{i+1}, m_{i-2}; lam_i; u_i
+  unsigned bq_o[4], bm_o[3], blam, bu;
+  {
+    const int i = vl ? lane : 0, ip1 = i + 1 < D ? i + 1 : 0, im1 = i >= 1 ? i - 1 : D - 1, im2 = i >= 2 ? i - 2 : i - 2 + D;
+    bq_o[0] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(i, i));
+    bq_o[1] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(ip1, i));
+    bq_o[2] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(im2, i));
+    bq_o[3] = GB + 8u * (unsigned)(gl::QT + elem_off<NB>(im1, i));
+    bm_o[0] = GB + 8u * (unsigned)(gl::M + im1);
+    bm_o[1] = GB + 8u * (unsigned)(gl::M + ip1);
+    bm_o[2] = GB + 8u * (unsigned)(gl::M + im2);
+    blam = GB + 8u * (unsigned)(gl::LAM + i);
+    bu = GB + 8u * (unsigned)(gl::U + i);
+  }
+  // fragments of this wave's maps (row side: Q^T, column side: S), the rows' dt u and the columns' m, the out-buffer slot of every
+  // result element (wave < 3: units (a, b) = a in {0, 1} x b in {0, 1, 2}; wave 3: (a0, b0), (a1, b0), (a2, b0), (a2, b1..b4))
+  unsigned fa_o[3], fb_o[5], eu_o[3], em_o[5], eo_o[7];
+  {
+    int rowA[3], colJ[5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int Ia = kGradA[i][bq];
+      fa_o[i] = GB + 8u * (unsigned)(gl::QT + r4 * LD + 2 * ((4 * Ia + c4) ^ r4));
+      rowA[i] = 4 * Ia + r4;
+      eu_o[i] = GB + 8u * (unsigned)(gl::U + rowA[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int sel = wave < 3 ? 3 * wave + (i < 3 ? i : 0) : (i == 0 ? 9 : 2 * i - 1);      // grad_bsel
+      const int Jb = (sel + (bq >> 1)) % 10;
+      fb_o[i] = GB + 8u * (unsigned)(gl::S + r4 * LD + 2 * ((4 * Jb + c4) ^ r4));
+      colJ[i] = 4 * Jb + c4;
+      em_o[i] = GB + 8u * (unsigned)(gl::M + colJ[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+      const int ai = wave < 3 ? (u < 6 ? u / 3 : 0) : (u < 3 ? u : 2), bi = wave < 3 ? (u < 6 ? u % 3 : 0) : (u < 3 ? 0 : u - 2);
+      const int row = rowA[ai], col = colJ[bi];
+      // (results of the padding, D < 4 NB, go to the last slot of the buffer, which D x D elements do not reach)
+      eo_o[u] = GB + 8u * (unsigned)(gl::O + ((row < D && col < D) ? row * D + col : PP * PP - 1));
+    }
+  }
+  unsigned oo[NOUT];                                     // the out-buffer's element tid + 256 q: the same offset in LDS and in gLa_t
+#pragma unroll
+  for (int q = 0; q < NOUT; q++) { const int e = tid + NT * q; oo[q] = 8u * (unsigned)(e < DD ? e : DD - 1); }      // (beyond the matrix: a duplicate of its last element)
+
+  // The tables are all this role keeps across a step.  Left alone, the compiler hoists every address it can derive from them out of
+  // the time loop and spills at the 168 registers of three waves per SIMD (and turns wave-uniform base + 32-bit offset into 64-bit
+  // per-lane address pairs); made opaque once per step, nothing derived from them lives longer than the step.
+  auto opaque_tables = [&]() {
+    auto op = [](unsigned& v) { asm volatile("" : "+v"(v)); };
+#pragma unroll
+    for (int q = 0; q < NIT; q++) { op(it_rd[q]); op(qt_w0[q]); op(qt_w1[q]); }
+#pragma unroll
+    for (int q = 0; q < NPKI; q++) { op(s_w0[q]); op(s_w1[q]); op(s_g[q]); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) op(bq_o[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { op(bm_o[i]); op(fa_o[i]); op(eu_o[i]); }
+#pragma unroll
+    for (int i = 0; i < 5; i++) { op(fb_o[i]); op(em_o[i]); }
+#pragma unroll
+    for (int u = 0; u < 7; u++) op(eo_o[u]);
+#pragma unroll
+    for (int q = 0; q < NOUT; q++) op(oo[q]);
+    op(m_w); op(blam); op(bu); op(lane8);
+  };
+
+  // ---- phases (SET: compile-time operand set) -------------------------------------------------------------------------------------
+  double gsv[NPKI], gvm = 0.0, gvef = 0.0, gvam = 0.0, gvb = 0.0, gacc[7];
+  // S_t (packed) and the vector entries of grid point tg, one step ahead of their use
+  auto prefetch = [&](int tg) {
+    const size_t o = (size_t)prob * Np + tg;
+    const double* Sp = a.S + o * PK;
+#pragma unroll
+    for (int q = 0; q < NPKI; q++) gsv[q] = ldg(Sp, s_g[q]);
+    gvm = ldg(a.m + o * D, lane8);
+    gvef = ldg(a.Ef + o * D, lane8);
+    gvam = ldg(a.Am + o * D, lane8);
+    gvb = ldg(a.b + (size_t)prob * a.strideB + (size_t)tg * D, lane8);
+  };
+  auto settle_loads = [&]() {
+#pragma unroll
+    for (int q = 0; q < NPKI; q++) settle(gsv[q]);
+    settle(gvm); settle(gvef); settle(gvam); settle(gvb);
+  };
+  // the operands of the grid point whose Psi_t is in stage buffer 0 and whose A_t is in R, and m_t
+  auto build = [&](auto set_) {
+    constexpr unsigned SB = decltype(set_)::value * SETB, SV = decltype(set_)::value * SETV;
+    d2_t ps[NIT], a0[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) { ps[q] = rd2(it_rd[q]); a0[q] = rd2(it_rd[q] + RB); }
+#pragma unroll
+    for (int q = 0; q < NPKI; q++) { wr1(s_w0[q] + SB, gsv[q]); wr1(s_w1[q] + SB, gsv[q]); }
+    wr1(m_w + SV, gvm);
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+      wr1(qt_w0[q] + SB, __builtin_fma(hq, a0[q][0], ps[q][0]));      // Q / -2 = Psi - A / (2 sigma^2)
+      wr1(qt_w1[q] + SB, __builtin_fma(hq, a0[q][1], ps[q][1]));
+    }
+  };
+  // row i of <df/dx> / (-2 sigma^2) (lorenz_96.py:35-83; D >= 5: four distinct entries) is added to column i of the operand; dt u, gLb
+  auto band_u = [&](auto set_, int tg) {
+    constexpr unsigned SB = decltype(set_)::value * SETB, SV = decltype(set_)::value * SETV;
+    if (wave == 0 && vl) {
+      const double mm1 = rd1(bm_o[0] + SV), mp1 = rd1(bm_o[1] + SV), mm2 = rd1(bm_o[2] + SV), lam = rd1(blam);
+      const double v0 = rd1(bq_o[0] + SB), v1 = rd1(bq_o[1] + SB), v2 = rd1(bq_o[2] + SB), v3 = rd1(bq_o[3] + SB);      // (all reads first: one LDS round trip)
+      wr1(bq_o[0] + SB, v0 - hq);                              // <df/dx>_ii = -1
+      wr1(bq_o[1] + SB, __builtin_fma(hq, mm1, v1));           // <df/dx>_i,i+1 = m_{i-1}
+      wr1(bq_o[2] + SB, __builtin_fma(-hq, mm1, v2));          // <df/dx>_i,i-2 = -m_{i-1}
+      wr1(bq_o[3] + SB, __builtin_fma(hq, mp1 - mm2, v3));     // <df/dx>_i,i-1 = m_{i+1} - m_{i-2}
+      const double r = -gvef - gvam + gvb;                     // -<f> - A m + b        (variational.py:325-337)
+      const double udt = dt * __builtin_fma(-2.0 * hq, r, lam);      // dt (dEsde_db + lam)
+      wr1(bu + SV, udt);
+      stg(gbase + (size_t)Np * DD + (size_t)tg * D, lane8, udt);
+    }
+  };
+  // k-pairs [KP0, KP1) of the product from operand set SET; unit = (row-side map, column-side map), accumulators carried across the barriers
+  auto prod = [&](auto set_, auto kp0_, auto kp1_) {
+    constexpr unsigned SB = decltype(set_)::value * SETB;
+    constexpr int KP0 = decltype(kp0_)::value, KP1 = decltype(kp1_)::value;
+    if (KP0 == 0) {
+#pragma unroll
+      for (int u = 0; u < 7; u++) gacc[u] = 0.0;
+    }
+    if (wave < 3) {
+#pragma unroll
+      for (int kp = KP0; kp < KP1; kp++) {
+        constexpr unsigned dummy = 0; (void)dummy;
+        const unsigned ko = SB + 8u * (unsigned)(kp * 4 * LD);
+        d2_t fa[2], fb[3];
+#pragma unroll
+        for (int i = 0; i < 2; i++) fa[i] = rd2(fa_o[i] + ko);
+#pragma unroll
+        for (int i = 0; i < 3; i++) fb[i] = rd2(fb_o[i] + ko);
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+          for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+            for (int bi = 0; bi < 3; bi++) gacc[3 * ai + bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[ai][hh], fb[bi][hh], gacc[3 * ai + bi], 0, 0, 0);
+        if (kp + 1 < KP1) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kp = KP0; kp < KP1; kp++) {
+        const unsigned ko = SB + 8u * (unsigned)(kp * 4 * LD);
+        d2_t fa[3], fb[5];
+#pragma unroll
+        for (int i = 0; i < 3; i++) fa[i] = rd2(fa_o[i] + ko);
+#pragma unroll
+        for (int i = 0; i < 5; i++) fb[i] = rd2(fb_o[i] + ko);
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+          for (int ai = 0; ai < 3; ai++) gacc[ai] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[ai][hh], fb[0][hh], gacc[ai], 0, 0, 0);
+#pragma unroll
+          for (int bi = 1; bi < 5; bi++) gacc[2 + bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[2][hh], fb[bi][hh], gacc[2 + bi], 0, 0, 0);
+        }
+        if (kp + 1 < KP1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // gLa = dt (Q S - u m^T) = -2 dt acc - (dt u) m^T of the point in set SET into the out-buffer
+  auto epilogue = [&](auto set_) {
+    constexpr unsigned SV = decltype(set_)::value * SETV;
+    double uu[3], mm[5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) uu[i] = rd1(eu_o[i] + SV);
+#pragma unroll
+    for (int i = 0; i < 5; i++) mm[i] = rd1(em_o[i] + SV);
+    if (wave < 3) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) wr1(eo_o[u], __builtin_fma(m2dt, gacc[u], -(uu[u / 3] * mm[u % 3])));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 7; u++) wr1(eo_o[u], __builtin_fma(m2dt, gacc[u], -(uu[u < 3 ? u : 2] * mm[u < 3 ? 0 : u - 2])));
+    }
+  };
+  // the out-buffer -> gLa of grid point tg, whole lines
+  auto out = [&](int tg) {
+    double* gA = gbase + (size_t)tg * DD;
+    double v[NOUT];
+#pragma unroll
+    for (int q = 0; q < NOUT; q++) v[q] = rd1(oo[q] + GB + 8u * (unsigned)gl::O);
+#pragma unroll
+    for (int q = 0; q < NOUT; q++) stg(gA, oo[q], v[q]);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+
+#ifndef VGPA_GF_ABL
+#define VGPA_GF_ABL 0                    // DIAGNOSTIC (wrong results; tools/ubench/ode_gf_loop.hip only): bit 0 no product, 1 no band, 2 no build, 3 no out
+#endif
+#ifdef VGPA_STAMPS_ROLE
+  long long ts_prev_ = clock64();
+#define VGPA_GF_BARRIER(j)                                                                                               \
+  { const long long tsb_ = clock64(); lds_barrier(); const long long tsa_ = clock64();                                   \
+    if (lane == 0 && wave == 0 && blockIdx.x == 0) { mfma::g_stamp_role[2][2 * (j)] += tsb_ - ts_prev_; mfma::g_stamp_role[2][2 * (j) + 1] += tsa_ - tsb_; } \
+    ts_prev_ = tsa_; }
+#else
+#define VGPA_GF_BARRIER(j) lds_barrier()
+#endif
+#ifndef VGPA_GF_PRIO_G
+#define VGPA_GF_PRIO_G 3                 // (this role's few instructions first: 4.87 -> 4.60 ms per sweep direction of one problem)
+#endif
+  // one backward step: HP / HP2 = a previous / a second-previous grid point exists (compile time: the first two steps are peeled)
+  auto step = [&](int k, auto set_, auto hp_, auto hp2_) {
+    constexpr int SET = decltype(set_)::value;
+    constexpr bool HP = decltype(hp_)::value, HP2 = decltype(hp2_)::value;
+    using CUR = std::integral_constant<int, SET>; using PRV = std::integral_constant<int, SET ^ 1>;
+    opaque_tables();
+    if (HP) settle_loads();              // (the one place that waits for this role's HBM loads)
+    // (scheduling barriers between the phases: interleaved, their operands do not fit the 168 registers of three waves per SIMD)
+    if (HP2 && !(VGPA_GF_ABL & 8)) out(tidx(k - 2));
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(VGPA_GF_ABL & 4)) build(CUR{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I0{}, I1{});
+    VGPA_GF_BARRIER(0);
+    if (!(VGPA_GF_ABL & 2)) band_u(CUR{}, tidx(k));
+    prefetch(tidx(k + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I1{}, I2{});
+    VGPA_GF_BARRIER(1);
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I2{}, I4{});
+    VGPA_GF_BARRIER(2);
+    if (HP) { if (!(VGPA_GF_ABL & 1)) prod(PRV{}, I4{}, I5{}); __builtin_amdgcn_sched_barrier(0); epilogue(PRV{}); }
+    VGPA_GF_BARRIER(3);
+  };
+  // behind the loop: the last grid point (Psi in stage buffer 0, the end point's operand in R, lam from the helpers' last vector update)
+  auto drain = [&](auto set_) {
+    constexpr int SET = decltype(set_)::value;
+    using CUR = std::integral_constant<int, SET>; using PRV = std::integral_constant<int, SET ^ 1>;
+    if (n_steps > 0) settle_loads();
+    if (n_steps > 1) out(tidx(n_steps - 2));
+    build(CUR{});
+    if (n_steps > 0) prod(PRV{}, I0{}, I5{});
+    lds_barrier();
+    if (n_steps > 0) epilogue(PRV{});    // (every thread has read the out-buffer)
+    band_u(CUR{}, tidx(n_steps));
+    lds_barrier();
+    if (n_steps > 0) out(tidx(n_steps - 1));
+    prod(CUR{}, I0{}, I5{});
+    lds_barrier();
+    epilogue(CUR{});
+    lds_barrier();
+    out(tidx(n_steps));
+  };
+
+  __builtin_amdgcn_s_setprio(VGPA_GF_PRIO_G);
+  __syncthreads();                       // LDS zero-filled (by the other roles)
+  prefetch(tidx(0));
+  settle_loads();
+  __syncthreads();                       // prologue published
+  using F = std::false_type; using T = std::true_type;
+  int k = 0;
+  if (n_steps > 0) { step(0, I0{}, F{}, F{}); k = 1; }
+  if (n_steps > 1) { step(1, I1{}, T{}, F{}); k = 2; }
+  for (; k + 1 < n_steps; k += 2) { step(k, I0{}, T{}, T{}); step(k + 1, I1{}, T{}, T{}); }
+  if (k < n_steps) step(k, I0{}, T{}, T{});
+  if (n_steps & 1) drain(I1{});
+  else drain(I0{});
+}
+
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4, bool HLP = false, bool GF = false>   // WPE: waves per SIMD the register budget allows for
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (HLP ? 2 : 1)), 64 * NW * (GF ? 3 : (HLP ? 2 : 1))), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = SGeo<NB, NW>;
@@ -452,11 +829,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   static_assert(!COVER || (g::NSB == 5 && g::MAXS == 4), "the fragment cover is built for 33 <= D <= 40");
   static_assert(!W8 || COVER, "eight waves per problem: fragment-cover kernels only");
   static_assert(!HLP || (COVER && NW == 4), "helper waves: fragment-cover kernels on four product waves");
+  static_assert(!GF || (HLP && QOUT && !FWD && !DENSEJ && METHOD == VGPA_ODE_RK4), "fused gradient assembly: backward RK4 helper-wave kernels with Q'' on");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
   constexpr double sixth = 1.0 / 6.0;
-  const bool helper = HLP && (int)threadIdx.x >= 64 * NW;     // (wave-uniform) this wave does the chores of product wave `wave`
-  const int tid = helper ? (int)threadIdx.x - 64 * NW : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int role = HLP ? (int)threadIdx.x / (64 * NW) : 0;     // (wave-uniform) 0: products; 1: helper -- the chores of product wave `wave`; 2 (GF): gradient assembly
+  const bool helper = role == 1;
+  const int tid = (int)threadIdx.x - role * 64 * NW, lane = tid & 63, wave = tid >> 6;
   const int wq = wave & 3, half = W8 ? (wave >> 2) : 0;      // cover wave whose units this wave multiplies; which half of them (W8)
   const int prob = (int)blockIdx.x;
   const int D = a.D, Np = a.Np, DD = a.D * a.D, n_steps = a.Np - 1;
@@ -468,7 +847,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   double* const xvw = Mb + g::XS + wave * g::XV;           // this wave's copy of the stage vector
   double* const pvb = Mb + g::XS + NW * g::XV;             // [2][NPART][PP] partial inner products
   double* const trash = pvb + 2 * g::PV + 2 * tid;         // one 16-byte unit per thread
-  for (int i = tid; i < (int)g::LDS_DOUBLES; i += NT) smem[i] = 0.0;
+  // GF: the gradient waves (third set of four; grad_waves below) share nothing with this code but the barriers, the buffers they read
+  // and lam_t, which the helpers leave for them
+  using gl = GradLds<NB>;
+  constexpr int GLDS = GF ? gl::DOUBLES : 0;
+  if constexpr (GF) {
+    if (role == 2) { grad_waves<NB>(a, smem, (int)threadIdx.x - 2 * 64 * NW); return; }
+  }
+  double* const gLam = smem + g::LDS_DOUBLES + gl::LAM;
+  for (int i = tid; i < (int)g::LDS_DOUBLES + GLDS; i += NT) smem[i] = 0.0;
   // QOUT (backward, mid-point methods, Sigma = sigma^2 I): the state store writes Q''_t = A_t / sigma^2 - 2 Psi_t in place of Psi_t --
   // the only combination of A_t and Psi_t the gradient assembly reads (assemble.hip), which then streams one matrix less.  (A
   // general diagonal would need its entries per row pair here: with them the kernel no longer fits its 256 registers.)
@@ -728,7 +1115,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
 #pragma unroll
         for (int q = 0; q < NITS; q++) tc_mid[q] = *unit_ptr(Rb, q);
       }
-      load_items(Xc, tc_items);
+      if constexpr (!GF) load_items(Xc, tc_items);      // (GF: nothing of the state leaves through the helpers)
     }
   };
   // QOUT: items of Psi_t -> items of Q''_t, with the start-point operand A_t in the same row-pair items
@@ -745,7 +1132,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   auto tailC_finish = [&](int j, int step) {
     if (j == 0) {
       double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
-      if constexpr (QOUT) to_q(tc_items, tc_mid);
+      if constexpr (QOUT && !GF) to_q(tc_items, tc_mid);
       if (MIDP) {
 #pragma unroll
         for (int q = 0; q < NITS; q++) { tc_mid[q][0] = 0.5 * (tc_mid[q][0] + an[q][0]); tc_mid[q][1] = 0.5 * (tc_mid[q][1] + an[q][1]); }
@@ -753,7 +1140,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
       } else {
         store_a(dst, an);
       }
-      store_items(tc_items, tidx(step));
+      if constexpr (GF) {                 // (Psi_t / Q''_t stay in the kernel; lam_t also goes to the gradient waves)
+        if (wave == 0 && vl) { stg(vout + vec(tidx(step)), lane8, vk); gLam[lane] = vk; }
+      } else store_items(tc_items, tidx(step));
     }
     if (j == JSEC && NS > 1) store_a(Rb, an);
     if (j == JSEC) prefetch(step, std::true_type{});       // (overwrites an[]: behind its last use of the step; with helper waves: their part)
@@ -1176,7 +1565,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
     const int op = stage_op<METHOD, FWD>(j, matrix, k);
     return op == OP_X ? xcur(k, j) : (op == OP_M ? Mb : Rb);
   };
-  if (!(HLP && helper)) product_begin(aop(0, 0, true), xcur(0, 0));
+  if (role == 0) product_begin(aop(0, 0, true), xcur(0, 0));
   VGPA_STAMP_DECL;
   // Chores between the products (round 3).  Nothing of a stage but the stepper depends on the stage's product, so everything
   // else is issued INSIDE the product pipeline, where its LDS and HBM latencies run under matrix-core work instead of behind it
@@ -1223,6 +1612,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
   // (helper waves: the loop exists twice, once per role, so that each role's loop carries only its own state -- one loop with a role
   //  branch inside keeps the union of both alive across the back-edge, and the backward instantiations spill)
   auto time_loop = [&](auto helper_role) {
+#ifdef VGPA_STAMPS_ROLE
+  long long ts_prev_ = clock64();
+#endif
   constexpr bool HR = HLP && decltype(helper_role)::value;      // this copy is the helper waves'
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
@@ -1284,26 +1676,45 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (HLP ? 2 : 
         if (t == SC_F) tailC_finish(j, k);
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
       });
+#ifdef VGPA_STAMPS_ROLE      // diagnostic build (tools/ubench/ode_gf_loop.hip): first wave of each role of workgroup 0, per stage: [busy | wait at the barrier]
+      const long long tsb_ = clock64();
+#endif
       VGPA_STAMP(0, 0);
       __builtin_amdgcn_s_setprio(VGPA_SYM_TAILPRIO);
       lds_barrier();
+#ifdef VGPA_STAMPS_ROLE
+      { const long long tsa_ = clock64();
+        if (lane == 0 && wave == 0 && blockIdx.x == 0) { mfma::g_stamp_role[HR ? 1 : 0][2 * j] += tsb_ - ts_prev_; mfma::g_stamp_role[HR ? 1 : 0][2 * j + 1] += tsa_ - tsb_; }
+        ts_prev_ = tsa_; }
+#endif
       VGPA_STAMP(0, 2);
       // the next stage's first fragments (Xn is complete now; past the last stage of the sweep they are read and dropped)
       const int kn = j + 1 < NS ? k : k + 1, jn = j + 1 < NS ? j + 1 : 0;
       if (!HR) product_begin(aop(kn, jn, true), Xn);
-      __builtin_amdgcn_s_setprio(0);
+#ifndef VGPA_HLP_PRIO
+#define VGPA_HLP_PRIO 0
+#endif
+      __builtin_amdgcn_s_setprio(HR ? VGPA_HLP_PRIO : 0);
       VGPA_STAMP(0, 3);
     }
   }
   };
   if (HLP && helper) time_loop(std::true_type{});
   else time_loop(std::false_type{});
+  if constexpr (GF) {
+    // the last grid point's gradient: three more barrier intervals.  The helpers finish the vector and leave lam; the gradient
+    // waves build (Psi in the stage buffer, the end point's operand in R), then band / u, product, out; the product waves only count.
+    if (role == 0) { lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier(); return; }
+  }
   if (HLP && !helper) return;             // (the last state and the last vector leave through the helper waves)
   if (n_steps > 0) {                     // the last stage's vector update
     vecA_read(pvb + (xcur(n_steps, 0) == Xb0 ? g::PV : 0));
     vecA_finish(NS - 1);
   }
-  {
+  if constexpr (GF) {
+    if (wave == 0 && vl) { stg(vout + vec(tidx(n_steps)), lane8, vk); gLam[lane] = vk; }
+    lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+  } else {
     d2_t items[g::NIT];
     load_items(xcur(n_steps, 0), items);
     if constexpr (QOUT) {                // the end point's operand is in R (staged at stage JSEC of the last step, or by the prologue)
@@ -1338,6 +1749,18 @@ hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
   constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
   constexpr int WPE_C = (HLP || 2 * lds_c <= 160 * 1024) ? 2 : 1;
   constexpr int threads = HLP ? 512 : 256;
+  if constexpr (!FWD && METHOD == VGPA_ODE_RK4 && HLP && GRC == 0) {
+    if (a.grad_on) {                                   // the gradient assembly on the helper waves (k_ode_sym, GF)
+      if (dense || !a.q_on || !a.s_packed || !a.g || !a.S || !a.m || !a.Ef || !a.Am || !a.b) return hipErrorInvalidValue;
+      constexpr size_t lds_g = lds_c + GradLds<NB>::DOUBLES * sizeof(double);
+      static_assert(lds_g <= 160 * 1024, "LDS budget");
+      auto kg = k_ode_sym<METHOD, FWD, NB, false, GRC, 3, true, 4, true, true>;      // 768 threads: three waves per SIMD, 168 registers each
+      (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
+      hipLaunchKernelGGL(kg, dim3(a.batch), dim3(768), lds_g, st, a);
+      return hipGetLastError();
+    }
+  }
+  if (a.grad_on) return hipErrorInvalidValue;          // (only the kernel above assembles the gradient)
   if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
     if (a.q_on) {
       if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)
@@ -1380,7 +1803,7 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
   if constexpr (can_cover) {
-    if (!runs_only && !dense && eight_waves(a.batch)) {
+    if (!runs_only && !dense && eight_waves(a.batch) && !a.grad_on) {
       // up to one problem per CU: eight waves per problem (k_ode_sym, NW = 8), two per SIMD, all 256 registers each
       constexpr size_t lds_8 = SGeo<NB, 8>::LDS_DOUBLES * sizeof(double);
       static_assert(lds_8 <= 160 * 1024, "LDS budget");
@@ -1397,9 +1820,10 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(k8, dim3(a.batch), dim3(512), lds_8, st, a);
       return hipGetLastError();
     }
-    if (!runs_only && old_cover() && helper_waves(a.batch)) return launch_cover<METHOD, FWD, NB, 0, true>(a, st, dense);
+    if (!runs_only && old_cover() && (helper_waves(a.batch) || (!FWD && a.grad_on))) return launch_cover<METHOD, FWD, NB, 0, true>(a, st, dense);
     if (!runs_only) return old_cover() ? launch_cover<METHOD, FWD, NB, 0>(a, st, dense) : launch_cover<METHOD, FWD, NB, -1>(a, st, dense);
   }
+  if (a.grad_on) return hipErrorInvalidValue;
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers
   auto kern = dense ? k_ode_sym<METHOD, FWD, NB, true, GR, WPE> : k_ode_sym<METHOD, FWD, NB, false, GR, WPE>;
   if (lds > 48 * 1024)

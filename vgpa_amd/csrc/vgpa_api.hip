@@ -65,6 +65,8 @@ struct vgpa_ctx {
   int32_t *d_obs_idx = nullptr, *d_status = nullptr;
   double obs_const = 0.0, sigma1 = 1.0;
   bool have_state = false;
+  bool bwd_stored = true;        // d_lam / d_psi hold the backward recursion of the cached state (false: F-only evaluation of a context whose backward
+                                 // kernel assembles the gradient -- grad_fused_ok -- or that kernel, which keeps Psi_t to itself; vgpa_fetch materialises)
   bool derived_valid = true;     // dEsde_dm / dEsde_dS / <f> / E_sde(t) / lam / Psi belong to the cached (m, S): false behind a fused lane pass
   double* d_msT = nullptr;       // fused lane pass: the moments time-major, problem fastest (OdeArgs::msT), [Np][D(D+1)/2 + D][bpad]: packed lower triangle of S_t, then m_t
   double* d_jmT = nullptr;       // ... and its sparse vector jumps, [M][D][bpad]
@@ -280,9 +282,12 @@ static int run_fwd(vgpa_ctx* c, const double* m0, const double* S0, const double
   return VGPA_OK;
 }
 
-static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
+static bool grad_fused_ok(vgpa_ctx* c);
+// g_fused: the backward kernel assembles the gradient into it (grad_fused_ok contexts; Psi_t is then not stored)
+static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym, double* g_fused = nullptr) {
   ld::use_library_gemm = (c->cfg.flags & VGPA_FLAG_LIBRARY_GEMM) != 0;
   int rc;
+  if (g_fused && (dense_jumps || !grad_fused_ok(c) || !c->s_packed)) return fail(c, VGPA_ERR_STATE, "fused gradient assembly asked of a context without it");
   if ((rc = ensure(c, &c->d_psi, (size_t)c->B * c->Np * c->DD))) return rc;
   if ((rc = ensure(c, &c->d_dEs, (size_t)c->B * c->Np * c->DD))) return rc;
   c->psi_is_q = false;
@@ -313,6 +318,13 @@ static int run_bwd(vgpa_ctx* c, bool dense_jumps, bool sym) {
                 c->cfg.model == VGPA_MODEL_L96 && !(c->cfg.flags & VGPA_FLAG_KEEP_PSI) && sym_stores_q(c->cfg.method, c->D);
   a.q_on = c->psi_is_q ? 1 : 0;
   a.q_scale = c->isg0;
+  if (g_fused) {                           // the gradient assembly on the kernel's helper waves (k_ode_sym, GF)
+    if (!c->psi_is_q) return fail(c, VGPA_ERR_STATE, "fused gradient assembly: the backward kernel is not the Q'' one");
+    a.grad_on = 1; a.g = g_fused; a.s_packed = 1;
+    a.S = c->d_S; a.m = c->d_m; a.b = ctx_b(c); a.Ef = c->d_Ef; a.Am = c->d_Am;
+    c->psi_is_q = false;                   // (nothing is stored in d_psi)
+  }
+  c->bwd_stored = !g_fused;
   hipError_t e = use_lane(c) ? launch_ode_small(c->cfg.method, false, a, c->stream)
                  : use_wave(c) ? launch_ode_wave(c->cfg.method, false, a, c->stream)
                  : use_mfma(c, false, sym) ? launch_ode_mfma(c->cfg.method, false, a, c->stream)
@@ -610,6 +622,20 @@ static bool s_packed_ok(vgpa_ctx* c) {
          sym_stores_q(c->cfg.method, c->D) && !c->hyp_on && c->D <= kMaxSmallD;
 }
 
+// the backward kernel assembles the gradient itself (OdeArgs::grad_on): wherever S_t is packed and the stepper's kernel can.  F-only
+// evaluations of such a context skip the backward recursion altogether (F does not depend on it); gradient(x, eval_fun=False) runs it.
+static bool grad_fused_ok(vgpa_ctx* c) {
+  return s_packed_ok(c) && sym_fuses_grad(c->cfg.method, c->D) && c->d_Am != nullptr;
+}
+// ... from kFusedGradMinBatch problems on (VGPA_FUSED_GRAD=1 in the environment: always).  The third wave set costs the recursion
+// ~0.4-0.5 ms per launch round (its matrix-core and vector-ALU instructions share the SIMDs' issue port with the product waves), the
+// separate assembly ~7 us per problem: below ~70 problems the backward kernel followed by k_grad_mfma_q is the shorter way.
+constexpr int kFusedGradMinBatch = 64;
+static bool grad_fused_now(vgpa_ctx* c) {
+  static const bool always = [] { const char* e = getenv("VGPA_FUSED_GRAD"); return e && e[0] == '1'; }();
+  return grad_fused_ok(c) && c->s_packed && (always || c->B >= kFusedGradMinBatch);
+}
+
 // dEsde_dS between the energy kernel and the backward cover kernel as packed lower triangles: wherever S_t is packed (the same two
 // kernels sit on either side); VGPA_DS_PACKED=0 in the environment keeps the upper triangles in whole matrices (comparison runs)
 static bool ds_packed_ok(vgpa_ctx* c) {
@@ -651,6 +677,14 @@ static int enqueue_free_energy(vgpa_ctx* c) {
   for (int r = diag_repeat("energy"); r > 0; r--)
     if ((rc = run_energy(c, nullptr, sym_bwd, ds_packed_ok(c)))) return rc;
   prof_mark(c, 2);
+  if (grad_fused_ok(c)) {                  // F needs no backward recursion; the gradient's comes with its assembly (finish_gradient)
+    if ((rc = run_reduce(c))) return rc;
+    c->bwd_stored = false;
+    c->psi_is_q = false;
+    c->have_state = true;
+    c->derived_valid = true;
+    return VGPA_OK;
+  }
   for (int r = diag_repeat("bwd"); r > 0; r--)
     if ((rc = run_bwd(c, false, c->sym_inputs))) return rc;
   prof_mark(c, 3);
@@ -1132,6 +1166,16 @@ static int finish_gradient(vgpa_ctx* c, double* g_dev) {
     return rc;
   }
   int rc = VGPA_OK;
+  if (grad_fused_now(c)) {                 // backward recursion + gradient assembly in one kernel (phase "bwd"; "grad" is empty)
+    for (int r = diag_repeat("bwd"); r > 0 && rc == VGPA_OK; r--) rc = run_bwd(c, false, c->sym_inputs, g_dev);
+    prof_mark(c, 3);
+    if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
+    return rc;
+  }
+  if (!c->bwd_stored) {                    // (F-only evaluation before: the recursion now, with Q''_t for the assembly kernel)
+    for (int r = diag_repeat("bwd"); r > 0 && rc == VGPA_OK; r--) rc = run_bwd(c, false, c->sym_inputs);
+    prof_mark(c, 3);
+  }
   for (int r = diag_repeat("grad"); r > 0 && rc == VGPA_OK; r--) rc = run_grad(c, g_dev);
   if (rc == VGPA_OK && c->prof) { prof_mark(c, 4); c->prof_pending = true; }
   return rc;
@@ -1198,6 +1242,7 @@ int vgpa_fetch(vgpa_ctx* c, int which, double* out) {
   int rc = VGPA_OK;
   if ((rc = materialize_moments(c))) return rc;
   if (which != VGPA_FETCH_MT && which != VGPA_FETCH_ST && which != VGPA_FETCH_EDF && (rc = materialize_derived(c))) return rc;
+  if ((which == VGPA_FETCH_LAMT || which == VGPA_FETCH_PSIT) && !c->bwd_stored && !c->stream_ld && (rc = run_bwd(c, false, c->sym_inputs))) return rc;
   switch (which) {
     case VGPA_FETCH_MT: rc = download(c, out, c->d_m, BN * c->D); break;
     case VGPA_FETCH_ST: {

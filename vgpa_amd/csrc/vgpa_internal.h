@@ -81,6 +81,13 @@ struct OdeArgs {
   int s_packed;
   int ds_packed;            // dEs holds packed lower triangles (EnergyArgs::ds_packed): symmetric-unit cover kernels, backward
   const double* jmT;     // sparse vector jumps in the same spirit: entry i of observation n of problem p at jmT[(n * D + i) * bpad + p]
+  // backward kernel with the gradient assembly on its helper waves (sym::fuses_grad: fragment-cover kernels, RK4, Sigma = sigma^2 I,
+  // Lorenz-96, packed S_t): grad_on = 1, q_on = 1; the kernel reads S (packed), m, b, Ef, Am of every grid point beside its own
+  // streams and writes g = dt [gLa | gLb] (variational.py:263-288) -- Psi_t / Q''_t are NOT stored, lam_t is
+  int grad_on;
+  const double* Ef;      // [B][Np][D] <f>_t            (energy kernel)
+  const double* Am;      // [B][Np][D] A_t m_t          (energy kernel)
+  double* g;             // [B][strideA]: problem p's [Np][D][D] gLa, then [Np][D] gLb (the caller's x layout)
 };
 
 // Fused lane-per-problem pass of the models with closed-form moments (OU, double well, Lorenz-63; ode_small.hip::k_sweep_lane):
@@ -183,6 +190,7 @@ hipError_t launch_ode_wave(int method, bool fwd, const OdeArgs& a, hipStream_t s
 bool ode_mfma_supported(int method, bool fwd, int D);
 hipError_t launch_ode_mfma(int method, bool fwd, const OdeArgs& a, hipStream_t st);
 bool sym_stores_q(int method, int D);      // the backward kernel launch_ode_mfma picks for sym_units honours OdeArgs::q_on
+bool sym_fuses_grad(int method, int D);    // ... and OdeArgs::grad_on (the gradient assembly on its helper waves)
 // Psi_t = (diag(isg) A_t - Q''_t) / 2 in place (A: problem stride strideA, grid-point stride D*D)
 // the strict lower triangle of [batch * Np] D x D matrices from their upper one, in place
 hipError_t launch_mirror_upper(size_t n_mat, int D, double* m, hipStream_t st);
