@@ -572,8 +572,13 @@ def main():
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
 
+    traffic_missing = []
+
     def traffic_of(name):
-        return tj.get(f"{name}_B{B}_D{d}_Np{n_pts}")
+        key = f"{name}_B{B}_D{d}_Np{n_pts}"
+        if key not in tj:
+            traffic_missing.append(key)              # (reported in the line: a null `traffic` is never silent)
+        return tj.get(key)
 
     # NOT measured in this run: PMC counters need rocprofv3 passes of their own (tools/profile_bench.sh); the numbers are the
     # committed result of the last such run of this workload
@@ -592,18 +597,30 @@ def main():
     tri = d * (d + 1) / 2.0 if sym_path else float(d * d)
     # ... and (round 4) S_t travels between the kernels as its packed lower triangle (OdeArgs::s_packed; VGPA_S_PACKED=0 keeps whole matrices)
     s_tri = d * (d + 1) / 2.0 if (q_mode and os.environ.get("VGPA_S_PACKED") != "0") else float(d * d)
+    # ... and (round 5) from 64 problems on the backward RK4 kernel assembles the gradient itself on a third set of waves
+    # (vgpa_api.hip::grad_fused_now): no Q'' stream, no assembly kernel -- three kernels per sweep
+    fused = q_mode and args.method.upper() == "RK4" and s_tri < d * d and B >= 64 and os.environ.get("VGPA_FUSED_GRAD") != "0" \
+        and os.environ.get("VGPA_SYM_COVER") != "op"
+    grad_flop = B * n_pts * 2.0 * d ** 3                     # Q S per grid point
     kernels = {
         # stepping kernels: fp64 matrix pipe (AI = 8 D^3 / (16 D^2 ..) ~ D/2 flop/B > ridge ~10)
         "solve_fwd": dict(bound="mfma", seconds=fwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
                           alg_bytes=B * 8.0 * n_pts * (d * d + s_tri + 2 * d)),   # read A,b ; write S (packed lower triangle), m
         "solve_bwd": dict(bound="mfma", seconds=bwd_s, alg=alg_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
                           alg_bytes=B * 8.0 * n_pts * (2 * d * d + tri + 2 * d)),  # read A, dEsde/dS (upper), dEsde/dm ; write Psi | Q'', lam
+        # the fused kernel: recursion + assembly; read A, dEsde/dS, dEsde/dm, S (packed), m, <f>, A m, b ; write gLa, gLb, lam
+        "solve_bwd_grad": dict(bound="mfma", seconds=bwd_s, alg=alg_flop + grad_flop, peak=FP64_PEAK_TFLOPS, scale=1e12, unit="TFLOP/s",
+                               alg_bytes=B * 8.0 * n_pts * (2 * d * d + tri + s_tri + 7 * d)),
         # per-grid-point kernels: HBM (energy: AI = 4 D^3 / (24 D^2) = D/6 flop/B; gradient: 2 D^3 / (32 D^2) = D/16)
         "energy_l96": dict(bound="hbm", seconds=en_s, alg=B * 8.0 * n_pts * (d * d + s_tri + tri + 6 * d), peak=HBM_PEAK_GBS, scale=1e9,
                            unit="GB/s"),                                          # read S, A, m, b ; write dEsde/dS (upper), dEsde/dm, <f>, A m, e_t
         "grad": dict(bound="hbm", seconds=gr_s, alg=B * 8.0 * n_pts * ((2 if q_mode else 3) * d * d + s_tri + 7 * d), peak=HBM_PEAK_GBS, scale=1e9,
                      unit="GB/s"),                                                # read Q'' (or A and Psi), S + vectors ; write gLa, gLb
     }
+    if fused:
+        del kernels["solve_bwd"], kernels["grad"]
+    else:
+        del kernels["solve_bwd_grad"]
     nb_blocks = (d + 3) // 4
     method_id = {"EULER": 0, "HEUN": 1, "RK2": 2, "RK4": 3}.get(args.method.upper(), 3)
     # device symbols as they appear in a rocprofv3 kernel trace (MFMA path, 5 <= D <= 64): symmetric-unit kernels from two
@@ -615,9 +632,11 @@ def main():
     cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
     # (last parameter: the backward cover kernels of RK2 / RK4 store Q''_t = Sigma^-1 A_t - 2 Psi_t for the gradient assembly)
     q_out = lambda fwd: "true" if (fwd == "false" and cover == 0 and method_id in (2, 3) and not args.keep_psi) else "false"
-    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4>") if sym_units else \
+    hlp = "true" if (cover == 0 and B <= n_cu and os.environ.get("VGPA_SYM_HELPERS") != "0") or os.environ.get("VGPA_SYM_HELPERS") == "1" else "false"
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4, {hlp}, false>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
+               "solve_bwd_grad": f"vgpa::sym::k_ode_sym<{method_id}, false, {nb_blocks}, false, 0, 3, true, 4, true, true> (768 threads: product, helper and gradient waves)",
                "energy_l96": f"vgpa::(anonymous namespace)::k_energy_l96_r<{nb_blocks}, 1> (+ k_obs)", "grad": f"vgpa::k_grad_mfma{'_q' if (sym_units and q_out('false') == 'true') else ''}<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():
@@ -628,7 +647,7 @@ def main():
                       ("alg_flop_per_launch" if k["bound"] == "mfma" else "alg_bytes_per_launch"): k["alg"]}
     dom = max(kernels, key=lambda n: kernels[n]["seconds"])
     dom_s = kernels[dom]["seconds"]
-    step_dom = "solve_bwd" if bwd_s >= fwd_s else "solve_fwd"
+    step_dom = ("solve_bwd_grad" if fused else "solve_bwd") if bwd_s >= fwd_s else "solve_fwd"
     alg_bytes = kernels[step_dom]["alg_bytes"]
     gbs = alg_bytes / kernels[step_dom]["seconds"] / 1e9
     sweep_bytes = 8.0 * n_pts * (5 * d * d + 6 * d)         # SURVEY.md s.8d algorithmic bytes of one fused sweep
@@ -648,7 +667,7 @@ def main():
         # matrix pipe, not by HBM (19.6 us of fp64 work vs 8.2 us of HBM traffic per sweep), so THIS is the whole-sweep roofline
         "whole_sweep_frac_of_fp64": 24.0 * d ** 3 * n_pts * value / world / 1e12 / FP64_PEAK_TFLOPS,
         "roofline": dict(roof[dom], traffic_source=traffic_source, note=f"kernel with the longest launch of the sweep (batched, B={B}); energy+obs phase = "
-                                         f"k_energy_l96_r + k_obs (0.1 ms); all four kernels under roofline_kernels; whole "
+                                         f"k_energy_l96_r + k_obs (0.1 ms); all {len(kernels)} kernels under roofline_kernels; whole "
                                          f"sweep = {sweep_bytes * value / world / 1e9 / HBM_PEAK_GBS:.3f} of HBM on SURVEY 8d's "
                                          f"algorithmic bytes; single problem = "
                                          f"{(single or {}).get('sweeps_per_s', float('nan')):.1f} sweeps/s"),
@@ -656,6 +675,7 @@ def main():
         # into profiles/peak_context.json; not used for `frac`, not measured in this run)
         "peak_context": peak_context(),
         "roofline_kernels": roof,
+        "traffic_missing": traffic_missing or None,      # keys profiles/pmc_traffic.json does not hold (tools/profile_bench.sh writes them)
         "roofline_hbm": {"bound": "hbm", "kernel": step_dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
                          "whole_sweep_GBs": sweep_bytes * value / world / 1e9,

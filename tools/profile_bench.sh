@@ -1,4 +1,5 @@
 set -e
+export VGPA_HEAD=${VGPA_HEAD:-$(cat vgpa_amd/_tree.txt 2>/dev/null)}      # the commit of the measured tree (tools/stamp_tree.sh), into every summary header
 TAG=${1:-r03}          # usage: bash tools/profile_bench.sh [tag]: writes gpurun_out/<tag>_* (copy what is to be judged into profiles/)
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write

@@ -1,4 +1,5 @@
 set -e
+export VGPA_HEAD=${VGPA_HEAD:-$(cat vgpa_amd/_tree.txt 2>/dev/null)}      # the commit of the measured tree (tools/stamp_tree.sh), into every summary header
 # usage: bash tools/profile_large_d.sh [tag]: rocprofv3 kernel stats + matrix-pipe counters of (a) the resident fused sweep at D = 1024, Np = 41
 # (tools/bench_large_d_sweep.py) and (b) the one-rank D = 4096 fused sweep through the row-sharded driver (tools/bench_config5.py --sweep).
 # Counters in their own passes (no trace domains beside --pmc).  Writes gpurun_out/<tag>_large_d_*.

@@ -1,4 +1,5 @@
 # rocprofv3 kernel stats of ONE problem's sweeps (the helper-wave steppers): tools/profile_single.sh [tag]
+export VGPA_HEAD=${VGPA_HEAD:-$(cat vgpa_amd/_tree.txt 2>/dev/null)}      # the commit of the measured tree (tools/stamp_tree.sh), into every summary header
 set -e
 TAG=${1:-r04z}
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 set -e
+export VGPA_HEAD=${VGPA_HEAD:-$(cat vgpa_amd/_tree.txt 2>/dev/null)}      # the commit of the measured tree (tools/stamp_tree.sh), into every summary header
 TAG=${1:-r04}; MODEL=${2:-L63}; BATCH=${3:-65536}   # usage: bash tools/profile_small.sh [tag] [model] [batch]: writes gpurun_out/<tag>_*
 export TMPDIR=/tmp
 rm -rf gpurun_out/ps_stats gpurun_out/ps_fetch gpurun_out/ps_write

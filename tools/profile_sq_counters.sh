@@ -1,5 +1,7 @@
 export TMPDIR=/tmp
+export VGPA_HEAD=${VGPA_HEAD:-$(cat vgpa_amd/_tree.txt 2>/dev/null)}      # the commit of the measured tree (tools/stamp_tree.sh), into every summary header
 BATCH=${1:-512}      # usage: bash tools/profile_sq_counters.sh [batch]
+echo "# tree $VGPA_HEAD, bench.py --batch $BATCH"
 rocprofv3 --list-avail 2>/dev/null | grep -o -E "SQ_(LDS|VALU_MFMA|INSTS_VALU_MFMA|WAIT|ACTIVE_INST|WAVE_CYCLES|BUSY_CY|INST_CYCLES)[A-Z0-9_]*" | sort -u > gpurun_out/pmc_avail.txt
 cat gpurun_out/pmc_avail.txt | tr '\n' ' '
 for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do

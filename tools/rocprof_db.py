@@ -15,8 +15,16 @@ import re
 import sqlite3
 import sys
 
-KEYS = [(r"k_ode_(pe|sym)<\d+, true", "solve_fwd"), (r"k_ode_(pe|sym)<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"),
-        (r"k_grad", "grad")]
+# (first match wins: the backward kernel that assembles the gradient -- last template argument GF = true -- before the plain one)
+KEYS = [(r"k_ode_(pe|sym)<\d+, true", "solve_fwd"), (r"k_ode_sym<\d+, false, .*, true>", "solve_bwd_grad"),
+        (r"k_ode_(pe|sym)<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"), (r"k_grad", "grad")]
+
+
+def head_note():
+    """The commit the measured tree was built from (tools/profile_*.sh export VGPA_HEAD: the GPU box has no .git)."""
+    import os
+    h = os.environ.get("VGPA_HEAD", "")
+    return f"; tree {h}" if h else ""
 
 
 def stats(db_path, out_csv):
@@ -25,7 +33,7 @@ def stats(db_path, out_csv):
                        "group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1.0
     with open(out_csv, "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --stats (durations in us)\n")
+        fh.write("# rocprofv3 --kernel-trace --stats (durations in us)" + head_note() + "\n")
         fh.write("Name,Calls,TotalDurationUs,AverageUs,Percentage,MinUs,MaxUs\n")
         for name, calls, tot, avg, mn, mx in rows:
             fh.write('"%s",%d,%.3f,%.3f,%.4f,%.3f,%.3f\n' % (name, calls, tot / 1e3, avg / 1e3, 100.0 * tot / total, mn / 1e3, mx / 1e3))
@@ -61,7 +69,7 @@ def traffic(fetch_db, write_db, B, D, Np, out_csv, out_json):
         res[f"{short}_B{B}_D{D}_Np{Np}"] = hbm
     with open(out_csv, "w") as fh:
         fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 "
-                 f"--batch {B} --no-cpu-baseline --no-single-problem\n"
+                 f"--batch {B} --no-cpu-baseline --no-single-problem" + head_note() + "\n"
                  "# KB per dispatch (max over dispatches); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
         exp = B * Np * (D * D + D) * 8.0
         cal = [r for r in rows if re.search(KEYS[0][0], r[0])]
@@ -84,7 +92,7 @@ def traffic_all(fetch_db, write_db, out_csv, note="", out_json=None, key=None, p
     pattern: the sum over the kernels whose name matches `pattern` is stored under `key` (bench.py reads it as `traffic`)."""
     f, w = per_dispatch(fetch_db, "FETCH_SIZE"), per_dispatch(write_db, "WRITE_SIZE")
     with open(out_csv, "w") as fh:
-        fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)" + (": " + note if note else "") + "\n"
+        fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)" + (": " + note if note else "") + head_note() + "\n"
                  "# KB per dispatch (max over dispatches); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B "
                  "requests at 64 B, MI355X_MICROARCH.md HBM section)\n")
         fh.write("kernel,grid_size,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected\n")
@@ -122,7 +130,7 @@ def counters(db_path, out_csv, note=""):
         disp[kname].add(did)
     names = sorted({c for k in acc for c in acc[k]})
     with open(out_csv, "w") as fh:
-        fh.write("# rocprofv3 --pmc " + " ".join(names) + (": " + note if note else "") + "\n")
+        fh.write("# rocprofv3 --pmc " + " ".join(names) + (": " + note if note else "") + head_note() + "\n")
         fh.write("# per kernel: counter sums over all instances, averaged over the kernel's dispatches\n")
         fh.write("kernel,dispatches," + ",".join(names) + ",mfma_busy_share_of_simd_cycles\n")
         for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0.0)):

@@ -12,7 +12,8 @@ from ctypes import c_int, c_int32, c_int64, c_uint64, c_double, c_void_p, c_char
 import numpy as np
 
 ABI_VERSION = 2
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvgpa_hip.so")
+# VGPA_LIB: another build of the same library (same-box A/B of build variants: tools/build_variant.sh); never set by the package
+LIB_PATH = os.environ.get("VGPA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvgpa_hip.so")
 
 MODEL_IDS = {"NONE": -1, "OU": 0, "DW": 1, "L63": 2, "L96": 3}
 METHOD_IDS = {"euler": 0, "heun": 1, "rk2": 2, "rk4": 3}

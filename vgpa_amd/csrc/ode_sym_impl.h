@@ -759,20 +759,29 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
     constexpr int SET = decltype(set_)::value;
     constexpr bool HP = decltype(hp_)::value, HP2 = decltype(hp2_)::value;
     using CUR = std::integral_constant<int, SET>; using PRV = std::integral_constant<int, SET ^ 1>;
+#ifndef VGPA_GF_OUT_TICK
+#define VGPA_GF_OUT_TICK 0
+#endif
+#ifndef VGPA_GF_PRIO_LOW
+#define VGPA_GF_PRIO_LOW VGPA_GF_PRIO_G
+#endif
     opaque_tables();
+    if (VGPA_GF_PRIO_LOW != VGPA_GF_PRIO_G) __builtin_amdgcn_s_setprio(VGPA_GF_PRIO_G);
     if (HP) settle_loads();              // (the one place that waits for this role's HBM loads)
     // (scheduling barriers between the phases: interleaved, their operands do not fit the 168 registers of three waves per SIMD)
-    if (HP2 && !(VGPA_GF_ABL & 8)) out(tidx(k - 2));
+    if (VGPA_GF_OUT_TICK == 0 && HP2 && !(VGPA_GF_ABL & 8)) out(tidx(k - 2));
     __builtin_amdgcn_sched_barrier(0);
     if (!(VGPA_GF_ABL & 4)) build(CUR{});
     __builtin_amdgcn_sched_barrier(0);
     if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I0{}, I1{});
     VGPA_GF_BARRIER(0);
+    if (VGPA_GF_PRIO_LOW != VGPA_GF_PRIO_G) __builtin_amdgcn_s_setprio(VGPA_GF_PRIO_LOW);
     if (!(VGPA_GF_ABL & 2)) band_u(CUR{}, tidx(k));
     prefetch(tidx(k + 1));
     __builtin_amdgcn_sched_barrier(0);
     if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I1{}, I2{});
     VGPA_GF_BARRIER(1);
+    if (VGPA_GF_OUT_TICK == 2 && HP2 && !(VGPA_GF_ABL & 8)) { out(tidx(k - 2)); __builtin_amdgcn_sched_barrier(0); }
     if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I2{}, I4{});
     VGPA_GF_BARRIER(2);
     if (HP) { if (!(VGPA_GF_ABL & 1)) prod(PRV{}, I4{}, I5{}); __builtin_amdgcn_sched_barrier(0); epilogue(PRV{}); }
@@ -832,6 +841,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
   static_assert(!GF || (HLP && QOUT && !FWD && !DENSEJ && METHOD == VGPA_ODE_RK4), "fused gradient assembly: backward RK4 helper-wave kernels with Q'' on");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
+  // the stage whose chores end with the requests for A_{t+2}, c_{t+2} (consumed at the top of the next step).  Helper-wave RK4 kernels:
+  // the last stage -- same box, one problem: 7.82 -> 7.39 ms per sweep (forward 3.74 -> 3.43, backward 3.99 -> 3.87), the fused
+  // backward kernel 9.77 -> 9.6 ms per 512 problems; the four-wave kernels (two workgroups per CU) measured no difference and keep JSEC
+#ifndef VGPA_SYM_LOADA_STAGE
+#define VGPA_SYM_LOADA_STAGE 3
+#endif
+  constexpr int LSTG = (NS == 4 && HLP) ? VGPA_SYM_LOADA_STAGE : JSEC;
   constexpr double sixth = 1.0 / 6.0;
   const int role = HLP ? (int)threadIdx.x / (64 * NW) : 0;     // (wave-uniform) 0: products; 1: helper -- the chores of product wave `wave`; 2 (GF): gradient assembly
   const bool helper = role == 1;
@@ -932,11 +948,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
   // ---- operand staging --------------------------------------------------------------------------------------------------
   const double* A = a.A + (size_t)prob * a.strideA;
   d2_t an[NITS];
+#ifndef VGPA_SYM_LOADA_NT
+#define VGPA_SYM_LOADA_NT 0
+#endif
   auto load_a = [&](const double* At) {
 #pragma unroll
     for (int q = 0; q < NITS; q++) {
+      if (VGPA_SYM_LOADA_NT) {
+        an[q][0] = __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(At) + (FWD ? TT.g0[q] : IT.g0[q])));
+        an[q][1] = __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(At) + (FWD ? TT.g1[q] : IT.g1[q])));
+      } else {
       an[q][0] = ldg(At, FWD ? TT.g0[q] : IT.g0[q]);
       an[q][1] = ldg(At, FWD ? TT.g1[q] : IT.g1[q]);
+      }
     }
   };
   auto unit_ptr = [&](double* buf, int q) -> d2_t* {
@@ -1021,19 +1045,23 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
 
   // every HBM load of a step, issued together (see "Memory waits"): what the step after the next one needs
   auto prefetch = [&](int step, auto helper_role) {
+#ifndef VGPA_ABL_NOLOAD
+#define VGPA_ABL_NOLOAD 0                // DIAGNOSTIC (wrong results; ubench only): behind the second step no loads of 1: A_t, c_t  2: G_t  4: jumps  8: obs index
+#endif
+    const bool late = step > 1;
     constexpr bool HR = decltype(helper_role)::value;
     constexpr bool chores = !HLP || HR, units = !HLP || !HR;         // (helper waves: the operand and the vector; product waves: G_t)
-    if (chores) {
+    if (chores && !((VGPA_ABL_NOLOAD & 1) && late) && LSTG == JSEC) {
       load_a(A + (size_t)tclamp(step + 2) * DD);
       c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
     }
     if (!FWD) {
-      if (units) {
+      if (units && !((VGPA_ABL_NOLOAD & 2) && late)) {
 #pragma unroll
         for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * GS, gofs[s]);
       }
-      if (chores) jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
-      n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
+      if (chores && !((VGPA_ABL_NOLOAD & 4) && late)) jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
+      if (!((VGPA_ABL_NOLOAD & 8) && late)) n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
     }
   };
 
@@ -1146,6 +1174,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
     }
     if (j == JSEC && NS > 1) store_a(Rb, an);
     if (j == JSEC) prefetch(step, std::true_type{});       // (overwrites an[]: behind its last use of the step; with helper waves: their part)
+    if (LSTG != JSEC && j == LSTG) {     // (helper-wave RK4 kernels: the next operand's loads behind the LAST stage's chores)
+      load_a(A + (size_t)tclamp(step + 2) * DD);
+      c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+    }
   };
 
   // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
