@@ -43,6 +43,32 @@ extern "C" {
 #endif
 
 #define VGPA_ABI_VERSION 2
+/* vgpa_abi_version() of a library built with -DVGPA_EXPERIMENTS (diagnostic switches and rejected experiments compiled in; never the
+   product build) carries this bit beside the version */
+#define VGPA_ABI_DIAGNOSTIC_BUILD 0x10000
+
+/* ---- environment switches -------------------------------------------------------------------------------------------------------
+   Every getenv() of the library, read ONCE per process (the first time the code path is reached).  None of them changes a result
+   beyond rounding; all exist for same-box comparison runs and tests.  Nothing in vgpa_amd/ sets any of them.
+
+   VGPA_ODE_KERNEL=pe|sym     33 <= D <= 44 / D <= 44: keep the role-specialised steppers (pe) / take the symmetric-unit ones (sym)
+   VGPA_SYM_RUNS=1            33 <= D <= 40: the run layout of the symmetric-unit steppers instead of the fragment cover (then no
+                              Q'' stream, no packed S_t, no fused gradient)
+   VGPA_SYM_HELPERS=0|1       fragment-cover steppers: helper waves off / on at every batch size (default: up to one problem per CU)
+   VGPA_FUSED_GRAD=0|1        backward RK4 fragment-cover kernel: never / always assemble the gradient on its third wave set
+                              (default: from 64 problems per context on)
+   VGPA_S_PACKED=0            fused batched sweeps: S_t as whole matrices between the kernels (default: packed lower triangles)
+   VGPA_DS_PACKED=0           ... dEsde_dS as upper triangles of whole matrices (default: packed lower triangles)
+   VGPA_SHARD_CHUNKS=<n>      row-sharded recursion: sub-blocks of the pipelined gather (default 4; 0 = the serial schedule);
+                              per shard: vgpa_shard_set_option
+   VGPA_STAGE_FULL=1          D > 64: the stage kernel over whole tiles instead of symmetric tile pairs
+   VGPA_GEMM_SCALAR_LOADS=1   D > 64: the 8-byte-load GEMM kernels also for full tiles
+   VGPA_DIAG_REPEAT=<phase>:<n>  launch one phase (fwd|energy|bwd|grad) of the fused sweep n times (clock / power samples under one
+                              kernel, tools/power_per_kernel.sh); every phase is a pure function of its inputs
+   Only in builds with -DVGPA_EXPERIMENTS (vgpa_abi_version() carries VGPA_ABI_DIAGNOSTIC_BUILD; never the product build):
+   VGPA_SYM_WAVES=8, VGPA_SYM_COVER=op (measured-and-rejected stepper variants); -DVGPA_LANE_T_EXPERIMENTS adds VGPA_LANE_T_FWD /
+   VGPA_LANE_T_BWD (chunk lengths of the lane kernels, tools/lane_t_scan.sh).
+   Host side: VGPA_LIB (vgpa_amd/_lib.py: path of another build of this library), VGPA_ALLOW_DIAGNOSTIC=1 (load a diagnostic build).  */
 
 typedef enum {
   VGPA_OK = 0,

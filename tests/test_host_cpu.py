@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/vgpa_hip.h but not exported"
     from vgpa_amd._lib import SYMBOLS
     assert set(SYMBOLS) == declared
-    assert lib.vgpa_abi_version() == 2
+    assert lib.vgpa_abi_version() == 2          # version 2, and NOT a diagnostic build (bit 16, vgpa_hip.h VGPA_ABI_DIAGNOSTIC_BUILD)
 
 
 def test_python_constants_agree_with_the_header():

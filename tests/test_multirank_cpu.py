@@ -69,6 +69,46 @@ def test_two_rank_gloo_gather_and_timing(tmp_path):
         assert float(np.load(tmp_path / f"t_{rank}.npy")[0]) == 2.0   # MAX over ranks of (1 + rank)
 
 
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vgpa_amd import parallel as par
+    from vgpa_amd.numerics import OdeSolver
+    par.init_from_env("gloo")
+    n_pts, d = 7, 3                                    # slices of unequal length: 4 + 3 grid points
+
+    class _Arr:                                        # what NativeShardedRecursion hands back: something with .numpy()
+        def __init__(self, a):
+            self.a = a
+
+        def numpy(self):
+            return self.a
+
+    class _Rec:
+        D, world = d, 2
+        time_slice = (0, 4) if rank == 0 else (4, 7)
+
+    lo, hi = _Rec.time_slice
+    full_v = np.arange(n_pts * d, dtype=float).reshape(n_pts, d)
+    full_m = np.arange(n_pts * d * d, dtype=float).reshape(n_pts, d, d) * 0.5
+    v, m = OdeSolver._gather_time(_Rec, _Arr(full_v[lo:hi].copy()), _Arr(full_m[lo:hi].copy()), n_pts)
+    assert np.array_equal(v, full_v) and np.array_equal(m, full_m)
+    # D not a multiple of the world size: no sharded recursion (every rank steps by itself on its own GPU)
+    assert OdeSolver.__new__(OdeSolver)._large(65, 4) is None
+    par.barrier()
+    open(os.path.join(out_dir, f"ok_{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_time_sharded_results_are_gathered_without_pickling(tmp_path):
+    """OdeSolver under a process group (D > 64): the native driver's time-sharded (vector, matrix) slices come back as the whole grid
+    on every rank through two tensor all-gathers (slices of unequal length padded); gloo, world size 2, a stand-in for the driver."""
+    import torch.multiprocessing as mp
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
 def _bench(args, env_extra, timeout=300):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}

@@ -7,7 +7,7 @@ out=gpurun_out/${TAG}_stepper_power_ablations.txt
 : > $out
 # usage: tools/power_ablations.sh [tag] ["name:flags" ...]   (default: the shipped build and the four ablations)
 shift
-if [ $# -eq 0 ]; then set -- "shipped:" "nofrag:-DVGPA_ABL_NOFRAG=1" "nostore:-DVGPA_ABL_NOSTORE=1" "novec:-DVGPA_ABL_NOVEC=1" "loop0:-DVGPA_SYM_LOOP1=0"; fi
+if [ $# -eq 0 ]; then set -- "shipped:" "nofrag:-DVGPA_EXPERIMENTS -DVGPA_ABL_NOFRAG=1" "nostore:-DVGPA_EXPERIMENTS -DVGPA_ABL_NOSTORE=1" "novec:-DVGPA_EXPERIMENTS -DVGPA_ABL_NOVEC=1" "loop0:-DVGPA_SYM_LOOP1=0"; fi
 names=""
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; names="$names $name"

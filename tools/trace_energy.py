@@ -1,6 +1,6 @@
 """Cycles per phase of the D <= 64 L96 energy kernel (k_energy_l96_r), summed over all waves of bench.py's workload.
 
-Diagnostic build only:   VGPA_EXTRA_CFLAGS=-DVGPA_ENERGY_TRACE python -m vgpa_amd.build && python tools/trace_energy.py
+Diagnostic build only:   VGPA_EXTRA_CFLAGS="-DVGPA_EXPERIMENTS -DVGPA_ENERGY_TRACE" python -m vgpa_amd.build && VGPA_ALLOW_DIAGNOSTIC=1 python tools/trace_energy.py
 (the stamps are s_memtime reads at the phase boundaries; a build without the macro has none of them).
 """
 import ctypes

@@ -1,7 +1,7 @@
 // The backward RK4 fragment-cover kernel with helper waves, with (grad 1) and without (grad 0) the gradient assembly on them, launched
 // back to back for <seconds>.  Inputs are arbitrary finite numbers (the timing does not depend on them); ablation macros of
 // ode_sym_impl.h (-DVGPA_GF_ABL=<bits>, wrong results) show what each phase of the assembly costs.
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../vgpa_amd/csrc -I../../include ode_gf_loop.hip -o ode_gf_loop
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_EXPERIMENTS -DVGPA_STAMPS_ROLE | -DVGPA_EXPERIMENTS -DVGPA_GF_ABL=<bits>] -I../../vgpa_amd/csrc -I../../include ode_gf_loop.hip -o ode_gf_loop
 // usage: ode_gf_loop <batch> <grad 1|0> <seconds>
 #include "ode_sym_impl.h"
 #include <cstdio>

@@ -1,5 +1,5 @@
 // Diagnostic build of the role-specialised stepping kernel with in-kernel cycle stamps (share of each segment of a phase).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_pe_stamp.hip -o ode_pe_stamp
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_EXPERIMENTS -DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_pe_stamp.hip -o ode_pe_stamp
 // usage: ode_pe_stamp <batch> <pair_mode 0|1|2>
 #include "ode_mfma_impl.h"
 #include <cstdio>

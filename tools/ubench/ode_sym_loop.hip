@@ -1,6 +1,6 @@
 // The symmetric-unit stepping kernel alone, launched back to back for <seconds> (clock / power samples beside it: tools/power_ablations.sh;
 // ablation macros of ode_sym_impl.h -- VGPA_ABL_NOFRAG / NOSTORE / NOVEC -- are passed with -D).  Derived from ode_sym_stamp.hip.
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_sym_stamp.hip -o ode_sym_stamp
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_EXPERIMENTS -DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_sym_stamp.hip -o ode_sym_stamp
 // usage: ode_sym_loop <batch> <fwd 1|0> <seconds>
 #include "ode_sym_impl.h"
 #include <cstdio>

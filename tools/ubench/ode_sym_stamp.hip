@@ -1,5 +1,5 @@
 // Diagnostic build of the symmetric-unit stepping kernel with in-kernel cycle stamps (share of each segment of a stage).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_sym_stamp.hip -o ode_sym_stamp
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_EXPERIMENTS -DVGPA_STAMPS] -I../../vgpa_amd/csrc -I../../include ode_sym_stamp.hip -o ode_sym_stamp
 // usage: ode_sym_stamp <batch> <fwd 1|0>
 #include "ode_sym_impl.h"
 #include <cstdio>

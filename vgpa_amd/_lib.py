@@ -12,6 +12,7 @@ from ctypes import c_int, c_int32, c_int64, c_uint64, c_double, c_void_p, c_char
 import numpy as np
 
 ABI_VERSION = 2
+ABI_DIAGNOSTIC_BUILD = 0x10000     # vgpa_hip.h: bit of vgpa_abi_version() set by a -DVGPA_EXPERIMENTS build
 # VGPA_LIB: another build of the same library (same-box A/B of build variants: tools/build_variant.sh); never set by the package
 LIB_PATH = os.environ.get("VGPA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvgpa_hip.so")
 
@@ -167,8 +168,12 @@ def load():
     lib.vgpa_set_prior_energy.argtypes = [c_void_p, c_double]
     lib.vgpa_profile_begin.argtypes = [c_void_p]
     lib.vgpa_profile_end.argtypes = [c_void_p, P_DOUBLE, P_DOUBLE, P_DOUBLE, P_DOUBLE, POINTER(c_int64)]
-    if lib.vgpa_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libvgpa_hip ABI {lib.vgpa_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    abi = lib.vgpa_abi_version()
+    if (abi & 0xFFFF) != ABI_VERSION:
+        raise RuntimeError(f"libvgpa_hip ABI {abi & 0xFFFF} != binding ABI {ABI_VERSION}: rebuild")
+    if (abi & ABI_DIAGNOSTIC_BUILD) and os.environ.get("VGPA_ALLOW_DIAGNOSTIC") != "1":
+        raise RuntimeError(f"{LIB_PATH} is a DIAGNOSTIC build (-DVGPA_EXPERIMENTS: wrong-result ablation switches and rejected "
+                           "experiments compiled in); set VGPA_ALLOW_DIAGNOSTIC=1 to load it anyway, or rebuild with `python -m vgpa_amd.build`")
     _lib = lib
     return lib
 

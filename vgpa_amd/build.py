@@ -37,8 +37,8 @@ def _newer(src, dst, extra=()):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "vgpa_internal.h"), os.path.join(CSRC, "ode_mfma_impl.h"), os.path.join(CSRC, "ode_sym_impl.h"),
-               os.path.join(HERE, "..", "include", "vgpa_hip.h")]
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -1147,20 +1147,26 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
     size_t lds = (one_matrix ? l96r_lds_doubles(a.D) : l96_lds_doubles(a.D)) * sizeof(double);
     const long long nwaves = (long long)a.Np * a.batch;
     if (nwaves > 0x7fffffffLL) return hipErrorInvalidValue;
-#define VGPA_L96_CASE(NBV)                                                                                          \
-  case NBV:                                                                                                         \
-    if (lds > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute(one_matrix ? (const void*)k_energy_l96_r<NBV> : (const void*)k_energy_l96<NBV>,       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    if constexpr (NBV == 9 || NBV == 10) {       /* packed S_t (the batched fused sweeps): persistent waves, see k_energy_l96_r */ \
-      if (one_matrix && a.s_packed && kEnergyTPW > 1) {                                                              \
-        constexpr int TPW = kEnergyTPW > 1 ? kEnergyTPW : 2;                                                         \
+#if defined(VGPA_EXPERIMENTS) && VGPA_ENERGY_TPW > 1     /* EXPERIMENT: packed S_t, persistent waves, see k_energy_l96_r */
+#define VGPA_L96_TPW(NBV)                                                                                           \
+    if constexpr (NBV == 9 || NBV == 10) {                                                                          \
+      if (one_matrix && a.s_packed) {                                                                               \
+        constexpr int TPW = kEnergyTPW;                                                                             \
         (void)hipFuncSetAttribute((const void*)k_energy_l96_r<NBV, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         const long long nw = (long long)((a.Np + TPW - 1) / TPW) * a.batch;                                          \
         hipLaunchKernelGGL((k_energy_l96_r<NBV, TPW>), dim3((unsigned)nw), dim3(64), lds, st, a);                    \
         break;                                                                                                      \
       }                                                                                                             \
-    }                                                                                                               \
+    }
+#else
+#define VGPA_L96_TPW(NBV)
+#endif
+#define VGPA_L96_CASE(NBV)                                                                                          \
+  case NBV:                                                                                                         \
+    if (lds > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute(one_matrix ? (const void*)k_energy_l96_r<NBV> : (const void*)k_energy_l96<NBV>,       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    VGPA_L96_TPW(NBV)                                                                                               \
     if (one_matrix) hipLaunchKernelGGL(k_energy_l96_r<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);          \
     else hipLaunchKernelGGL(k_energy_l96<NBV>, dim3((unsigned)nwaves), dim3(64), lds, st, a);                        \
     break;
@@ -1171,6 +1177,7 @@ hipError_t launch_energy(const EnergyArgs& a, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
 #undef VGPA_L96_CASE
+#undef VGPA_L96_TPW
   } else {
     return hipErrorInvalidValue;
   }

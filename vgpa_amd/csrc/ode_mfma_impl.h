@@ -47,7 +47,11 @@ inline bool stores_q(int method, int D) {
 // the backward kernel that assembles the gradient on its helper waves (OdeArgs::grad_on; k_ode_sym, GF): the fragment-cover kernels
 // of RK4 (VGPA_SYM_COVER=op, the outer-product experiment, has no helper waves)
 inline bool fuses_grad(int method, int D) {
+#ifdef VGPA_EXPERIMENTS
   static const bool op = [] { const char* e = getenv("VGPA_SYM_COVER"); return e && e[0] == 'o' && e[1] == 'p' && !e[2]; }();
+#else
+  const bool op = false;
+#endif
   static const bool off = [] { const char* e = getenv("VGPA_FUSED_GRAD"); return e && e[0] == '0'; }();
   return method == VGPA_ODE_RK4 && stores_q(method, D) && !op && !off;
 }

@@ -815,7 +815,7 @@ namespace {
 // (on demand only: vgpa_fetch and the separate kernels of the four-kernel path)
 __global__ void __launch_bounds__(NTS) k_ms_untranspose(int D, int Np, int batch, int bpad, const double* __restrict__ msT,
                                                         double* __restrict__ m, double* __restrict__ S) {
-  const int prob = blockIdx.x * NTS + threadIdx.x, t = blockIdx.y;
+  const int prob = blockIdx.y * NTS + threadIdx.x, t = blockIdx.x;      // (t in grid.x: Np may exceed the 65 535 of grid.y)
   if (prob >= batch) return;
   const int DD = D * D, TRI = D * (D + 1) / 2, W = TRI + D;
   const double* src = msT + (size_t)t * W * bpad + prob;
@@ -883,7 +883,8 @@ __global__ void __launch_bounds__(NTS) k_obs_lane(ObsArgs a, const double* __res
 }  // namespace
 
 hipError_t launch_ms_untranspose(int D, int Np, int batch, int bpad, const double* msT, double* m, double* S, hipStream_t st) {
-  hipLaunchKernelGGL(k_ms_untranspose, dim3((batch + NTS - 1) / NTS, Np), dim3(NTS), 0, st, D, Np, batch, bpad, msT, m, S);
+  if ((batch + NTS - 1) / NTS > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_ms_untranspose, dim3(Np, (batch + NTS - 1) / NTS), dim3(NTS), 0, st, D, Np, batch, bpad, msT, m, S);
   return hipGetLastError();
 }
 

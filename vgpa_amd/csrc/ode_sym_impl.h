@@ -1764,17 +1764,25 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
 // (tools/ab_waves.sh, tests).  They measured slower than four waves at every batch size -- the product phase is bound by the LDS
 // fragment traffic as much as by the matrix pipe, and the split raises the fragment reads per product from 0.5 to 0.75.
 inline bool eight_waves(int batch) {
-  static const int forced = [] { const char* e = getenv("VGPA_SYM_WAVES"); return e ? atoi(e) : 0; }();
   (void)batch;
+#ifdef VGPA_EXPERIMENTS
+  static const int forced = [] { const char* e = getenv("VGPA_SYM_WAVES"); return e ? atoi(e) : 0; }();
   return forced == 8;      // measured slower at every batch size (EXPERIMENTS.md s.9): opt-in only
+#else
+  return false;            // (not compiled into the product build)
+#endif
 }
 
 // The outer-product cover (kOpMaps: two maps per wave, rotated row sides by DPP) is an EXPERIMENT kept reachable: VGPA_SYM_COVER=op.
 // It measured slower than the round-3 fragment cover (EXPERIMENTS.md s.12): a rotated operand costs two v_mov_dpp, which do not
 // issue under a running fp64 product, where the fragment read it replaces costs LDS cycles beside the matrix pipe.
 inline bool old_cover() {
+#ifdef VGPA_EXPERIMENTS
   static const bool op = [] { const char* e = getenv("VGPA_SYM_COVER"); return e && !strcmp(e, "op"); }();
   return !op;
+#else
+  return true;             // (not compiled into the product build)
+#endif
 }
 template <int METHOD, bool FWD, int NB, int GRC, bool HLP = false>
 hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
@@ -1835,6 +1843,7 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
   constexpr int GR = 1;
   const bool dense = !FWD && a.js_dense;
   if constexpr (can_cover) {
+#ifdef VGPA_EXPERIMENTS
     if (!runs_only && !dense && eight_waves(a.batch) && !a.grad_on) {
       // up to one problem per CU: eight waves per problem (k_ode_sym, NW = 8), two per SIMD, all 256 registers each
       constexpr size_t lds_8 = SGeo<NB, 8>::LDS_DOUBLES * sizeof(double);
@@ -1852,8 +1861,12 @@ hipError_t launch_sym(const OdeArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(k8, dim3(a.batch), dim3(512), lds_8, st, a);
       return hipGetLastError();
     }
+#endif
     if (!runs_only && old_cover() && (helper_waves(a.batch) || (!FWD && a.grad_on))) return launch_cover<METHOD, FWD, NB, 0, true>(a, st, dense);
-    if (!runs_only) return old_cover() ? launch_cover<METHOD, FWD, NB, 0>(a, st, dense) : launch_cover<METHOD, FWD, NB, -1>(a, st, dense);
+#ifdef VGPA_EXPERIMENTS
+    if (!runs_only && !old_cover()) return launch_cover<METHOD, FWD, NB, -1>(a, st, dense);
+#endif
+    if (!runs_only) return launch_cover<METHOD, FWD, NB, 0>(a, st, dense);
   }
   if (a.grad_on) return hipErrorInvalidValue;
   constexpr int WPE = 2 * lds <= 160 * 1024 ? 2 : 1;     // two workgroups per CU when their LDS fits, else all 512 registers

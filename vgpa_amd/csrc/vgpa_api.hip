@@ -194,7 +194,9 @@ static bool use_lane(vgpa_ctx* c) {
 // the fused lane pass (ode_small.hip::k_sweep_lane): forward kernel -> observations -> ONE kernel for the E_sde terms, the backward
 // recursion, the gradient and F
 static bool lane_fused(vgpa_ctx* c) {
-  return use_lane(c) && c->full && sweep_lane_supported(c->cfg.model, c->D) && !(c->cfg.flags & VGPA_FLAG_MATERIALIZE);
+  // (msT carries S_t as its lower triangle: a non-symmetric s0 / Sigma keeps the four-kernel path, which handles both halves literally)
+  return use_lane(c) && c->full && sweep_lane_supported(c->cfg.model, c->D) && !(c->cfg.flags & VGPA_FLAG_MATERIALIZE) &&
+         (c->D == 1 || c->sym_inputs);
 }
 // D = 2..4 below that: 16 lanes per problem, operands exchanged by ds_bpermute (ode_wave.hip)
 static bool use_wave(vgpa_ctx* c) {
@@ -429,7 +431,7 @@ static int run_grad(vgpa_ctx* c, double* g_dev) {
   a.Ef = c->d_Ef; a.Edf = nullptr; a.g = g_dev;
   a.psi_is_q = c->psi_is_q ? 1 : 0;
   a.s_packed = (c->s_packed && c->psi_is_q) ? 1 : 0;
-  if (c->s_packed && !c->psi_is_q) {      // (an assembly kernel that wants S_t whole: cannot happen while s_packed_ok mirrors run_bwd's choice)
+  if (c->s_packed && !c->psi_is_q) {      // (an assembly kernel that wants S_t whole: behind VGPA_FETCH_PSIT, which recovers Psi_t in place and clears psi_is_q)
     const double* full = nullptr;
     int rc = unpack_S(c, &full);
     if (rc) return rc;
@@ -708,7 +710,11 @@ static int check_status(vgpa_ctx* c) {
 // =====================================================================================================
 extern "C" {
 
+#ifdef VGPA_EXPERIMENTS
+int vgpa_abi_version(void) { return VGPA_ABI_VERSION | VGPA_ABI_DIAGNOSTIC_BUILD; }
+#else
 int vgpa_abi_version(void) { return VGPA_ABI_VERSION; }
+#endif
 
 int vgpa_device_count(void) {
   int n = 0;
@@ -1448,6 +1454,8 @@ int vgpa_device_memcpy(int device, void* dst, const void* src, uint64_t bytes, i
   if (!sc.ok) return VGPA_ERR_DEVICE;
   const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
   if (bytes == 0) return VGPA_OK;
+  // (every stream of the library is non-blocking: the null-stream copy below does not wait for them by itself)
+  if (kind != 1 && hipDeviceSynchronize() != hipSuccess) return VGPA_ERR_DEVICE;
   if (hipMemcpy(dst, src, bytes, k) != hipSuccess) return VGPA_ERR_DEVICE;
   return hipDeviceSynchronize() == hipSuccess ? VGPA_OK : VGPA_ERR_DEVICE;
 }

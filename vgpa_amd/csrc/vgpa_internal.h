@@ -7,6 +7,18 @@
 
 #include "../../include/vgpa_hip.h"
 
+// ONE switch for every diagnostic or rejected-experiment code path of the library: -DVGPA_EXPERIMENTS.  vgpa_amd/build.py never sets it;
+// a library built with it says so (bit 16 of vgpa_abi_version(), vgpa_amd/_lib.py refuses to load it unless VGPA_ALLOW_DIAGNOSTIC=1).
+// Without it the wrong-result ablation macros and the cycle stamps of the micro-benchmarks (tools/ubench/) are compile errors, and the
+// measured-slower kernel variants (eight product waves per problem, the outer-product cover, persistent energy waves) are not
+// compiled at all -- their environment switches are then ignored.
+#ifndef VGPA_EXPERIMENTS
+#if defined(VGPA_ABL_NOFRAG) || defined(VGPA_ABL_NOSTORE) || defined(VGPA_ABL_NOVEC) || defined(VGPA_ABL_NOLOAD) || defined(VGPA_GF_ABL) || \
+    defined(VGPA_STAMPS) || defined(VGPA_STAMPS_ROLE) || defined(VGPA_ENERGY_TPW) || defined(VGPA_ENERGY_TRACE)
+#error "diagnostic / wrong-result switches need -DVGPA_EXPERIMENTS (the library then reports a diagnostic build)"
+#endif
+#endif
+
 namespace vgpa {
 
 #ifdef __HIPCC__

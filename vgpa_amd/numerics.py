@@ -40,34 +40,61 @@ class OdeSolver(object):
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    def _drop_contexts(self):
+        """One live workspace per stepper object.  A row-sharded recursion owns an RCCL communicator: it is closed HERE, in program
+        order (the same on every rank), not whenever the garbage collector gets to it."""
+        for obj in self._ctx.values():
+            close = getattr(obj, "close", None)
+            if close is not None:
+                close()
+        self._ctx.clear()
+
     def _large(self, dim_d, n_pts):
-        """D > 64 under a live process group: the row-sharded native driver (vgpa_amd/large_d.py) on the default group."""
+        """D > 64 under a live process group: the row-sharded native driver (vgpa_amd/large_d.py) on the default group.  The driver
+        shards rows evenly: D must be a multiple of the number of ranks -- otherwise None, and every rank runs the recursion by
+        itself on its own GPU (same results, no speed-up)."""
+        import torch.distributed as dist
+        if dim_d % dist.get_world_size():
+            return None
         from .large_d import NativeShardedRecursion
         key = ("large", dim_d, n_pts)
         rec = self._ctx.get(key)
         if rec is None:
-            self._ctx.clear()
+            self._drop_contexts()
             rec = NativeShardedRecursion(self.method, self.dt, dim_d, n_pts)
             self._ctx[key] = rec
         return rec
 
     @staticmethod
     def _gather_time(rec, v_own, m_own, n_pts):
-        """The driver's results are time-sharded; the reference's contract is the whole grid on the caller: gather the slices."""
+        """The driver's results are time-sharded; the reference's contract is the whole grid on the caller: one all-gather of the
+        vector slices and one of the matrix slices into preallocated tensors (slices padded to the longest; nothing is pickled)."""
+        import torch
         import torch.distributed as dist
-        parts = [None] * rec.world
-        dist.all_gather_object(parts, (rec.time_slice, v_own.numpy(), m_own.numpy()))
-        d = rec.D
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        d, world = rec.D, rec.world
+        lo, hi = rec.time_slice
+        mine = torch.tensor([lo, hi], dtype=torch.int64, device=dev)
+        slices = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(slices, mine)
+        slices = [tuple(int(x) for x in s.cpu()) for s in slices]
+        n_max = max(h - l for l, h in slices)
+        pv, pm = torch.zeros((n_max, d), dtype=torch.float64, device=dev), torch.zeros((n_max, d, d), dtype=torch.float64, device=dev)
+        pv[:hi - lo] = torch.from_numpy(np.ascontiguousarray(v_own.numpy()).reshape(hi - lo, d)).to(dev)
+        pm[:hi - lo] = torch.from_numpy(np.ascontiguousarray(m_own.numpy()).reshape(hi - lo, d, d)).to(dev)
+        gv, gm = [torch.empty_like(pv) for _ in range(world)], [torch.empty_like(pm) for _ in range(world)]
+        dist.all_gather(gv, pv)
+        dist.all_gather(gm, pm)
         v, m = np.empty((n_pts, d)), np.empty((n_pts, d, d))
-        for (lo, hi), pv, pm in parts:
-            v[lo:hi], m[lo:hi] = pv, pm
+        for (l, h), tv, tm in zip(slices, gv, gm):
+            v[l:h], m[l:h] = tv[:h - l].cpu().numpy(), tm[:h - l].cpu().numpy()
         return v, m
 
     def _context(self, dim_d, n_pts):
         key = (dim_d, n_pts, self.device, self.flags)
         ctx = self._ctx.get(key)
         if ctx is None:
-            self._ctx.clear()          # one live workspace per stepper object
+            self._drop_contexts()      # one live workspace per stepper object
             ctx = Context("NONE", self.method, dim_d, n_pts, self.dt, sigma=np.eye(dim_d), device=self.device,
                           flags=self.flags)
             self._ctx[key] = ctx
@@ -84,8 +111,8 @@ class OdeSolver(object):
                                    np.array([sigma], dtype=float))
             return mt.reshape(n), st.reshape(n)
         n, d = off_b.shape
-        if d > SMALL_D_MAX and self._sharded():
-            rec = self._large(d, n)
+        rec = self._large(d, n) if (d > SMALL_D_MAX and self._sharded()) else None
+        if rec is not None:
             return self._gather_time(rec, *rec.solve_fwd(lin_a, off_b, m0, s0, sigma), n)
         ctx = self._context(d, n)
         return ctx.solve_fwd(lin_a, off_b, m0, s0, sigma)
@@ -101,8 +128,8 @@ class OdeSolver(object):
             lam, psi = ctx.solve_bwd(r3(lin_a), r2(dEsde_dm), r3(dEsde_ds), r2(dEobs_dm), r3(dEobs_ds))
             return lam.reshape(n), psi.reshape(n)
         n, d = dEsde_dm.shape
-        if d > SMALL_D_MAX and self._sharded():
-            rec = self._large(d, n)
+        rec = self._large(d, n) if (d > SMALL_D_MAX and self._sharded()) else None
+        if rec is not None:
             return self._gather_time(rec, *rec.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds), n)
         ctx = self._context(d, n)
         return ctx.solve_bwd(lin_a, dEsde_dm, dEsde_ds, dEobs_dm, dEobs_ds)
