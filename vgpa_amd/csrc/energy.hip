@@ -555,9 +555,29 @@ __global__ void __launch_bounds__(64) k_energy_l96(EnergyArgs a) {
 //    * L^-1 overwrites L in place (block-row I of L is dead once block-row I of the inverse is known).
 //  LDS per grid point at D = 40: 17.9 KB instead of 30.5 KB -> 9 waves per CU instead of 5 (168 VGPRs: three per SIMD).
 // ------------------------------------------------------------------------------------------------
+// NB = 10 (37 <= D <= 40, the headline's size; round 5): the COMPACT layout -- L + FIVE vectors (m, b, A m, delta, q), 14.4 KB: ELEVEN
+// waves per CU instead of nine.  Everything else lives where the matrix has room that nobody reads at that time:
+//   * row D-1 of the parked G in the padding column of L (column Dp of the odd leading dimension),
+//   * the partial sums of the residuals (one row of Dp for the plus, one for the minus points: the four block slots are summed by
+//     row rotations in registers first) in rows 4 .. 7, columns 20 .. 39 -- strictly-upper blocks (1, 5 .. 9) that are exact zeros,
+//     which only the residual loop (before) and nobody after it reads,
+//   * the inverses of the ten diagonal blocks (phase 4) in the blocks (0, 4 .. 9) and (1, 5 .. 8): phase 4 reads blocks (K, J) with
+//     J - K <= 3 only, the SYRK skips every block above the diagonal at compile time, dE/dm masks rows 0 .. 7,
+//   * 1 / L_ii stays in the lanes' registers (four cross-lane reads build a diagonal block's inverse).
+__host__ __device__ inline bool l96r_compact(int D) { return (D + 3) / 4 == 10; }
 __host__ __device__ inline size_t l96r_lds_doubles(int D) {
   const size_t dp = l96_dp(D);
+  if (l96r_compact(D)) return dp * l96_ld(D) + 5 * dp;
   return dp * l96_ld(D) + 6 * dp + 9 * dp;       // L + 6 vectors + scratch (4 + 4 partial rows, 1 row of G; later xdiag)
+}
+// one double rotated by R block slots inside every 16-lane row (v_mov_b32 row_ror:4R: lane l reads lane (l - 4R) mod 16 of its row)
+template <int R>
+__device__ __forceinline__ double row_ror_blocks(double v) {
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  i2_t x = __builtin_bit_cast(i2_t, v), y;
+  y[0] = __builtin_amdgcn_mov_dpp(x[0], 0x120 + 4 * R, 0xf, 0xf, false);
+  y[1] = __builtin_amdgcn_mov_dpp(x[1], 0x120 + 4 * R, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, y);
 }
 
 // row of flat index e of a packed lower triangle (D <= 64: e < 2080), as a table: the staging of a packed S_t looks its (row, column)
@@ -609,12 +629,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   L96Lds S;
   // (Sigma^-1's diagonal is kept in registers, not in LDS; rows 0 and 1 of the parked G share the space of dl and qq,
   //  which are written after the boundary pass: 17.9 KB per grid point at D = 40, nine waves per CU)
+  constexpr bool CMP = (NB == 10);   // the compact LDS layout (l96r_lds_doubles)
   S.Lm = smem; S.Gm = nullptr; S.mv = S.Lm + Dp * LD; S.bv = S.mv + Dp; S.am = S.bv + Dp; S.sg = nullptr;
-  S.dl = S.am + Dp; S.qq = S.dl + Dp; S.rd = S.qq + Dp; S.vv = S.rd + Dp;
+  S.dl = S.am + Dp; S.qq = S.dl + Dp; S.rd = CMP ? nullptr : S.qq + Dp; S.vv = CMP ? nullptr : S.rd + Dp;
   double* pv = S.vv;                 // [4][Dp] partial sums (over the rows of block-slot b) of the plus points
-  double* pw = pv + 4 * Dp;          // [4][Dp] ... of the minus points
-  double* gb2 = pw + 4 * Dp;         // [Dp] row D-1 of G (rows 0 and 1: S.dl, S.qq)
+  double* pw = CMP ? nullptr : pv + 4 * Dp;          // [4][Dp] ... of the minus points
+  double* gb2 = CMP ? nullptr : pw + 4 * Dp;         // [Dp] row D-1 of G (rows 0 and 1: S.dl, S.qq)
   double* xdiag = pv;                // phase 4 (the partial sums are dead by then)
+  // compact layout: element j of the parked row D-1 of G; of the plus / minus partial-sum rows; element (r, c) of diagonal-block inverse I
+  auto cg2 = [&](int j) -> double* { return S.Lm + j * LD + Dp; };
+  auto cps = [&](int minus, int j) -> double* { return S.Lm + (4 + 2 * minus + (j >= 20 ? 1 : 0)) * LD + (j >= 20 ? j : 20 + j); };
+  auto cxd = [&](int I, int r, int c) -> double* { return S.Lm + ((I < 6 ? 0 : 4) + r) * LD + 4 * (I < 6 ? I + 4 : I - 1) + c; };
   const double* At = a.A + (size_t)prob * a.strideA + (size_t)t * D * D;       // (advanced per grid point)
   const bool spk = a.s_packed != 0;                // S_t as its packed lower triangle (OdeArgs::s_packed): all the factorisation reads
   const int PK = tri_off(D);
@@ -787,7 +812,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     chol_panel_pivots<LD>(S.Lm, myrd, j0, l, li, pad);       // 1/sqrt and sqrt to ~1 ulp, no fp64 divide
     wave_sync();
   }
-  if (pad) S.rd[l] = myrd;
+  if (!CMP && pad) S.rd[l] = myrd;
   wave_sync();
   bad = __any(!(myrd > 0.0 && myrd < __builtin_inf()));
   if (bad) {
@@ -838,7 +863,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   for (int u = 0; u < NUU; u++) {
     if (u == 0 || (16 * u <= Dp - 1 && 16 * u + 15 >= Dp - 4)) {
       const int i = 16 * u + 4 * b + r4;
-      double* gdst = (i == 0) ? S.dl : ((i == 1) ? S.qq : ((i == D - 1) ? gb2 : nullptr));
+      if constexpr (CMP) {
+        if (i == D - 1) {
+#pragma unroll
+          for (int J = 0; J < NB; J++) *cg2(4 * J + c4) = gacc[u][J];
+        }
+      }
+      double* gdst = (i == 0) ? S.dl : ((i == 1) ? S.qq : ((i == D - 1 && !CMP) ? gb2 : nullptr));
       if (gdst) {
 #pragma unroll
         for (int J = 0; J < NB; J++) gdst[4 * J + c4] = gacc[u][J];
@@ -890,6 +921,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
       rp[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, vp[J], 0.0, 0, 0, 0);
       rm[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, vm[J], 0.0, 0, 0, 0);
     }
+    if constexpr (CMP) {
+      // the four block slots of a row of 16 lanes are summed by rotations (every lane ends with the total of its column), the lanes
+      // of block slot 0 of the first row write the two rows of totals -- behind a synchronisation: the residual loop of some lanes
+      // may still be reading the zeros the totals replace
+#pragma unroll
+      for (int J = 0; J < NB; J++) {       // (two rotations: slot b + slot b-1, then that pair + the pair two slots away)
+        const double p1 = rp[J] + row_ror_blocks<1>(rp[J]), m1 = rm[J] + row_ror_blocks<1>(rm[J]);
+        rp[J] = p1 + row_ror_blocks<2>(p1);
+        rm[J] = m1 + row_ror_blocks<2>(m1);
+      }
+      wave_sync();
+      if (r4 == 0 && b == 0) {
+#pragma unroll
+        for (int J = 0; J < NB; J++) {
+          *cps(0, 4 * J + c4) = rp[J];
+          *cps(1, 4 * J + c4) = rm[J];
+        }
+      }
+    } else
     if (r4 == 0) {
 #pragma unroll
       for (int J = 0; J < NB; J++) {
@@ -908,8 +958,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     auto chi = [&](int q, int i) { return S.mv[i] + sgn_of(q) * S.Lm[i * LD + col_of(q)]; };
     const int jc = act ? l : 0;
     {
-      const double s1 = (pv[jc] + pv[Dp + jc]) + (pv[2 * Dp + jc] + pv[3 * Dp + jc]);
-      const double s2 = (pw[jc] + pw[Dp + jc]) + (pw[2 * Dp + jc] + pw[3 * Dp + jc]);
+      double s1, s2;
+      if constexpr (CMP) { s1 = *cps(0, jc); s2 = *cps(1, jc); }
+      else {
+        s1 = (pv[jc] + pv[Dp + jc]) + (pv[2 * Dp + jc] + pv[3 * Dp + jc]);
+        s2 = (pw[jc] + pw[Dp + jc]) + (pw[2 * Dp + jc] + pw[3 * Dp + jc]);
+      }
       vplus = s1 + 2.0 * s2;                       // sum s_i r_+^2 over the interior rows
       vminus = s1 - 2.0 * s2;
     }
@@ -923,7 +977,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
       const double N0 = chi(pMm, D - 2), N1 = chi(pMm, D - 1), N2 = chi(pM, 0), N3 = chi(pM, 1), N4 = chi(pM, 2);
       const double Q0 = chi(pP, D - 3), Q1 = chi(pP, D - 2), Q2 = chi(pP, D - 1), Q3 = chi(pPp, 0);
       const double R0 = chi(pM, D - 3), R1 = chi(pM, D - 2), R2 = chi(pM, D - 1), R3 = chi(pMp, 0);
-      const double g0 = S.dl[jc], g1 = S.qq[jc], g2 = gb2[jc];
+      const double g0 = S.dl[jc], g1 = S.qq[jc], g2 = CMP ? *cg2(jc) : gb2[jc];
       {
         const double ami = S.am[0], bvi = S.bv[0], sgi = lane_value(v_sg, 0);
         const double ra = ((P3 - P0) * P1 - P2 + theta) + (ami + g0) - bvi;
@@ -967,9 +1021,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   }
   if (l == 0) a.e_t[o] = e_t;
   // inverses of the 4x4 diagonal blocks of L (lane I < NB)
+  const int l4 = l < NB ? 4 * l : 0;
+  const double rd0 = CMP ? __shfl(myrd, l4, 64) : 0.0, rd1 = CMP ? __shfl(myrd, l4 + 1, 64) : 0.0;
+  const double rd2 = CMP ? __shfl(myrd, l4 + 2, 64) : 0.0, rd3 = CMP ? __shfl(myrd, l4 + 3, 64) : 0.0;
   if (l < NB) {
     const double* tb = S.Lm + (4 * l) * LD + 4 * l;
-    const double x00 = S.rd[4 * l], x11 = S.rd[4 * l + 1], x22 = S.rd[4 * l + 2], x33 = S.rd[4 * l + 3];
+    const double x00 = CMP ? rd0 : S.rd[4 * l], x11 = CMP ? rd1 : S.rd[4 * l + 1], x22 = CMP ? rd2 : S.rd[4 * l + 2], x33 = CMP ? rd3 : S.rd[4 * l + 3];
     const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
     const double x10 = -(t10 * x00) * x11;
     const double x21 = -(t21 * x11) * x22;
@@ -977,11 +1034,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     const double x20 = -(t20 * x00 + t21 * x10) * x22;
     const double x31 = -(t31 * x11 + t32 * x21) * x33;
     const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
+    if constexpr (CMP) {
+      double* x0 = cxd(l, 0, 0);
+      x0[0] = x00; x0[1] = 0.0; x0[2] = 0.0; x0[3] = 0.0;
+      x0[LD] = x10; x0[LD + 1] = x11; x0[LD + 2] = 0.0; x0[LD + 3] = 0.0;
+      x0[2 * LD] = x20; x0[2 * LD + 1] = x21; x0[2 * LD + 2] = x22; x0[2 * LD + 3] = 0.0;
+      x0[3 * LD] = x30; x0[3 * LD + 1] = x31; x0[3 * LD + 2] = x32; x0[3 * LD + 3] = x33;
+    } else {
     double* xo = xdiag + 16 * l;
     xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
     xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
     xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
     xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
+    }
   }
   wave_sync();
 
@@ -998,8 +1063,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
 #pragma unroll
   for (int I = 0; I < NB; I++) {
     const double* arow = l4_a + 4 * I * LD;
-    const double xd = xd_a[16 * I];
-    const double xdd = xd_d[16 * I];
+    const double xd = CMP ? *cxd(I, c4, r4) : xd_a[16 * I];
+    const double xdd = CMP ? *cxd(I, r4, c4) : xd_d[16 * I];
     double xo[NUU];
     // all products of the block-row first (they read L[I][:]), then the stores (they overwrite it)
 #pragma unroll
@@ -1020,7 +1085,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
     for (int u = 0; u < NUU; u++) {
       const int Jb = 4 * u + b;
       const bool colok = (4 * u + 3 < NB) || (Jb < NB);
-      if (colok) S.Lm[(4 * I + r4) * LD + 4 * Jb + c4] = xo[u];
+      // (compact layout: the blocks right of the diagonal are exact zeros already -- and the far ones hold the diagonal blocks' inverses)
+      if (colok && (!CMP || Jb <= I)) S.Lm[(4 * I + r4) * LD + 4 * Jb + c4] = xo[u];
     }
     wave_sync();
   }
@@ -1030,6 +1096,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NB <= 1
   // ---- 5. dE/dm = (c/2) X^T delta ; dE/dS = (c/2) X^T diag(q) X
   {
     double s = 0.0;
+    if constexpr (CMP) {               // (rows 0 .. 7 of the columns >= 16 hold the diagonal blocks' inverses, not the zeros of X: masked)
+      const bool z0 = li < 4, z1 = li < 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s = __builtin_fma((k < 4 ? z0 : z1) ? S.Lm[k * LD + li] : 0.0, S.dl[k], s);
+      for (int k = 8; k < Dp; k++) s = __builtin_fma(S.Lm[k * LD + li], S.dl[k], s);
+    } else
     for (int k = 0; k < Dp; k++) s = __builtin_fma(S.Lm[k * LD + li], S.dl[k], s);
     if (act) a.dEm[o * D + l] = 0.5 * c * s;
   }
