@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--keep-psi", action="store_true", help="comparison runs: VGPA_FLAG_KEEP_PSI (the backward kernel stores Psi_t, "
                     "the gradient assembly re-reads A_t) instead of the default Q''_t stream")
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary D = 4096 row-sharded block")
-    ap.add_argument("--config5-np", type=int, default=16, help="grid points of the D = 4096 block: a multiple of 8, so that the "
-                    "time-parallel energy / gradient phases are balanced at N = 1, 2, 4, 8 (vgpa_shard_time_slice)")
+    ap.add_argument("--config5-np", type=int, default=64, help="grid points of the D = 4096 block: a multiple of 8, so that the "
+                    "time-parallel energy / gradient phases are balanced at N = 1, 2, 4, 8 (vgpa_shard_time_slice); 64 = eight per rank "
+                    "at N = 8, so that the 64-step chain of the blocked Cholesky's diagonal kernel is amortised over a batch")
     ap.add_argument("--config5-dim", type=int, default=4096)
     ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
@@ -305,12 +306,13 @@ def config5_block(args, rank, world, local_rank, rehearse):
             stage_with, stage_without = float(st_t[0]), float(st_t[1])
         chunks = rec.gather_chunks
         rccl_ranks = rec.rccl_ranks                           # ncclCommCount of the communicator the sweep ran on
+        rccl_comms = rec.rccl_communicators                   # 2: compute-stream collectives and the gather's point-to-point groups apart
         rec.close()
         flop = 24.0 * d ** 3 * n                             # nominal flop of one fused sweep
         return {"workload": f"Lorenz96 D={d}, RK4, Np={n}: ONE problem, fused sweep (free energy + gradient), S_t / Psi_t row-sharded, "
                             f"energy / gradient time-parallel, x and gradient memory-sharded (BASELINE configs[4] matrix size; its "
                             f"full grid fits no node)",
-                "n_gpus": world, "rccl_ranks": rccl_ranks, "rccl_ranks_how": "ncclCommCount of the shard's communicator (0: one rank or host-staged rehearsal)",
+                "n_gpus": world, "rccl_ranks": rccl_ranks, "rccl_communicators": rccl_comms, "rccl_ranks_how": "ncclCommCount of the shard's communicator (0: one rank or host-staged rehearsal)",
                 "grid_points_per_rank": [int(v) for v in npts.tolist()],
                 "transport": "host-staged gloo (REHEARSAL: not a measurement)" if comm is not None else ("RCCL" if world > 1 else "none"),
                 "scaling": "strong", "s_per_sweep": secs,
@@ -320,6 +322,9 @@ def config5_block(args, rank, world, local_rank, rehearse):
                             ("serial (one grouped all-gather per stage)" if world > 1 else "one rank: no collective"),
                 "phase_ms_max_over_ranks": {k: float(v) for k, v in zip(names, pht.tolist())},
                 "phase_ms_rank0": ph,
+                # the time-parallel phases per grid point of the busiest rank: energy_obs does not shrink below the 64-step diagonal-block
+                # chain of the blocked Cholesky / inverse (69 us x 64 per batch at D = 4096) however few grid points a rank owns
+                "ms_per_own_grid_point": {k: float(v) / max(float(npts.max()), 1.0) for k, v in zip(names, pht.tolist()) if k in ("energy_obs", "gradient")},
                 "phase_how": "vgpa_shard_phase_ms: HIP events on the shard's stream around the phases of the last timed sweep; the recursions "
                              "(row-sharded, one collective pair per RK stage) scale with the stage time, energy_obs and gradient (time-parallel) with "
                              "grid_points_per_rank",

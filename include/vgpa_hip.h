@@ -385,6 +385,9 @@ int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_128_bytes, int rank, in
 void vgpa_rccl_comm_destroy(vgpa_comm* comm);
 /* ranks of the communicator as librccl counts them (ncclCommCount); VGPA_ERR_ARG for a table RCCL did not fill */
 int vgpa_rccl_comm_count(const vgpa_comm* comm, int* count);
+/* communicators behind the table: 2 -- the collectives of the compute stream and the point-to-point groups of the communication stream
+ * (the pipelined gather) each have their own (ncclCommSplit of the first) -- or 1 when the library cannot split */
+int vgpa_rccl_comm_streams(const vgpa_comm* comm, int* count);
 
 /* Device memory without a context -- what the callers of the row-sharded driver keep their operands and results in (the host
  * mirror vgpa_amd/large_d.py needs no tensor library for it).  kind: 1 = host -> device, 2 = device -> host, 3 = device -> device;

@@ -387,8 +387,8 @@ def test_diagnostic_phase_repeat_leaves_the_results_alone():
 
 
 def test_stepper_variants_of_the_fragment_cover_agree():
-    """33 <= D <= 40 on the fragment-cover steppers: with four helper waves beside the four product waves of a workgroup (the default up
-    to one problem per CU: the chores of a stage off the product waves' issue slots) and without them the same operations run in the same
+    """33 <= D <= 40 on the fragment-cover steppers: with four or eight helper waves beside the four product waves of a workgroup (the
+    default up to one problem per CU: the chores of a stage off the product waves' issue slots) and without them the same operations run in the same
     order -- F and the gradient must not differ in any bit.  (The outer-product cover and the eight-product-wave split, measured and
     rejected, are no longer part of the product build: -DVGPA_EXPERIMENTS.)  The switch is read once per process: child processes;
     RK4 and Heun, an unpadded and a padded dimension, one problem and a small batch."""
@@ -410,7 +410,7 @@ def test_stepper_variants_of_the_fragment_cover_agree():
         "    ctx.close()\n"
         "print(json.dumps(out))\n" % os.path.dirname(__file__))
     outs = {}
-    for name, env_set in (("helpers", {"VGPA_SYM_HELPERS": "1"}), ("plain", {"VGPA_SYM_HELPERS": "0"})):
+    for name, env_set in (("helpers", {"VGPA_SYM_HELPERS": "1"}), ("two", {"VGPA_SYM_HELPERS": "2"}), ("plain", {"VGPA_SYM_HELPERS": "0"})):
         env = dict(os.environ)
         for k in ("VGPA_SYM_HELPERS", "VGPA_SYM_COVER", "VGPA_SYM_WAVES"):
             env.pop(k, None)
@@ -420,6 +420,7 @@ def test_stepper_variants_of_the_fragment_cover_agree():
         outs[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     for key, ref in outs["plain"].items():
         assert outs["helpers"][key] == ref, key                      # bit for bit
+        assert outs["two"][key] == ref, key                          # (two helper roles: vector recursion and staging on waves of their own)
 
 
 @pytest.mark.parametrize("model,method,n,nb", [("L63", "rk4", 37, 520), ("L63", "rk4", 6, 576), ("L63", "heun", 22, 513), ("L63", "rk2", 9, 640),

@@ -1074,6 +1074,19 @@ def test_rccl_table_single_rank():
     n = ctypes.c_int(-1)
     assert lib.vgpa_rccl_comm_count(ctypes.byref(comm), ctypes.byref(n)) == 0 and n.value == 1     # ncclCommCount: bench.py's rccl_ranks
     assert lib.vgpa_rccl_comm_count(ctypes.byref(VgpaComm()), ctypes.byref(n)) == -1               # not an RCCL table
+    # the table holds TWO communicators (ncclCommSplit): the point-to-point groups of the pipelined gather (communication stream) do
+    # not share one with the compute stream's collectives -- exercised here through send / recv to the rank itself inside a group
+    assert lib.vgpa_rccl_comm_streams(ctypes.byref(comm), ctypes.byref(n)) == 0 and n.value == 2
+    z = torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    s2 = ctypes.c_void_p(side.cuda_stream)
+    assert comm.group_begin(comm.user) == 0
+    assert comm.send(comm.user, ctypes.c_void_p(x.data_ptr()), 1000, 0, s2) == 0
+    assert comm.recv(comm.user, ctypes.c_void_p(z.data_ptr()), 1000, 0, s2) == 0
+    assert comm.group_end(comm.user) == 0
+    assert comm.all_to_all(comm.user, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), 1000, stream) == 0      # (the other communicator, concurrently)
+    torch.cuda.synchronize()
+    assert torch.equal(z, x) and torch.equal(y, x)
     lib.vgpa_rccl_comm_destroy(ctypes.byref(comm))
 
 

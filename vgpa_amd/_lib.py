@@ -38,7 +38,7 @@ SYMBOLS = ["vgpa_create", "vgpa_destroy", "vgpa_last_error", "vgpa_abi_version",
            "vgpa_shard_create", "vgpa_shard_destroy", "vgpa_shard_time_slice", "vgpa_shard_stream", "vgpa_shard_synchronize",
            "vgpa_shard_solve_fwd", "vgpa_shard_solve_bwd", "vgpa_shard_sweep", "vgpa_shard_sweep_sharded", "vgpa_shard_set_option",
            "vgpa_shard_get_option", "vgpa_shard_time_collectives", "vgpa_ld_gemm_chunk", "vgpa_rccl_unique_id", "vgpa_rccl_comm_create",
-           "vgpa_rccl_comm_destroy", "vgpa_rccl_comm_count", "vgpa_shard_time_stage", "vgpa_shard_phase_ms", "vgpa_time_slice",
+           "vgpa_rccl_comm_destroy", "vgpa_rccl_comm_count", "vgpa_rccl_comm_streams", "vgpa_shard_time_stage", "vgpa_shard_phase_ms", "vgpa_time_slice",
            "vgpa_device_alloc", "vgpa_device_free", "vgpa_device_memcpy"]
 
 P_DOUBLE = POINTER(c_double)
@@ -153,6 +153,7 @@ def load():
     lib.vgpa_rccl_comm_destroy.argtypes = [POINTER(VgpaComm)]
     lib.vgpa_rccl_comm_destroy.restype = None
     lib.vgpa_rccl_comm_count.argtypes = [POINTER(VgpaComm), POINTER(c_int)]
+    lib.vgpa_rccl_comm_streams.argtypes = [POINTER(VgpaComm), POINTER(c_int)]
     lib.vgpa_shard_time_stage.argtypes = [c_void_p, c_int, c_int, P_DOUBLE]
     lib.vgpa_shard_phase_ms.argtypes = [c_void_p, P_DOUBLE]
     lib.vgpa_time_slice.argtypes = [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]

@@ -822,8 +822,13 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
   else drain(I0{});
 }
 
-template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4, bool HLP = false, bool GF = false>   // WPE: waves per SIMD the register budget allows for
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (HLP ? 2 : 1)), 64 * NW * (GF ? 3 : (HLP ? 2 : 1))), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
+// H2 (round 5; helper-wave kernels without GF): TWO helper roles -- 768 threads, three waves per SIMD.  A helper's stage is a chain of
+// dependent LDS round trips (partial sums -> stage vector -> partial products; start-point operand -> mid-point; stage state -> HBM)
+// about as long as the product waves' stage, and the product waves wait for it in stages 0 and 1 (tools/ubench/ode_gf_loop.hip).  The
+// vector recursion (role 1) and the operand staging / state stores / operand loads (role 2) share nothing but the barriers: side by
+// side each chain is shorter than the products.
+template <int METHOD, bool FWD, int NB, bool DENSEJ, int GR, int WPE, bool QOUT = false, int NW = 4, bool HLP = false, bool GF = false, bool H2 = false>   // WPE: waves per SIMD the register budget allows for
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * ((GF || H2) ? 3 : (HLP ? 2 : 1)), 64 * NW * ((GF || H2) ? 3 : (HLP ? 2 : 1))), amdgpu_waves_per_eu(WPE, WPE))) k_ode_sym(OdeArgs a) {
 #pragma clang fp contract(fast)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using g = SGeo<NB, NW>;
@@ -839,6 +844,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
   static_assert(!W8 || COVER, "eight waves per problem: fragment-cover kernels only");
   static_assert(!HLP || (COVER && NW == 4), "helper waves: fragment-cover kernels on four product waves");
   static_assert(!GF || (HLP && QOUT && !FWD && !DENSEJ && METHOD == VGPA_ODE_RK4), "fused gradient assembly: backward RK4 helper-wave kernels with Q'' on");
+  static_assert(!H2 || (HLP && !GF), "two helper roles: helper-wave kernels without the gradient waves");
   constexpr int NITS = FWD ? g::NITF : g::NIT;     // staging items per thread
   constexpr int JSEC = NS > 1 ? 1 : 0;
   // the stage whose chores end with the requests for A_{t+2}, c_{t+2} (consumed at the top of the next step).  Helper-wave RK4 kernels:
@@ -849,8 +855,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
 #endif
   constexpr int LSTG = (NS == 4 && HLP) ? VGPA_SYM_LOADA_STAGE : JSEC;
   constexpr double sixth = 1.0 / 6.0;
-  const int role = HLP ? (int)threadIdx.x / (64 * NW) : 0;     // (wave-uniform) 0: products; 1: helper -- the chores of product wave `wave`; 2 (GF): gradient assembly
-  const bool helper = role == 1;
+  const int role = HLP ? (int)threadIdx.x / (64 * NW) : 0;     // (wave-uniform) 0: products; 1: helper -- the chores of product wave `wave` (H2: its vector recursion); 2: gradient assembly (GF) / operand staging and state stores (H2)
+  const bool helper = role >= 1;
   const int tid = (int)threadIdx.x - role * 64 * NW, lane = tid & 63, wave = tid >> 6;
   const int wq = wave & 3, half = W8 ? (wave >> 2) : 0;      // cover wave whose units this wave multiplies; which half of them (W8)
   const int prob = (int)blockIdx.x;
@@ -1028,7 +1034,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
   __syncthreads();                       // prologue published
 
   // S_k / Psi_t and m_k / lam_t of grid point t to HBM: the matrix from the stage buffer that holds it
-  auto store_items = [&](const d2_t (&v)[g::NIT], int t) {
+  auto store_vector = [&](int t) {
+    if (VGPA_ABL_NOSTORE && t > 1) return;
+    if (wave == 0 && vl) stg(vout + vec(t), lane8, vk);
+  };
+  auto store_items = [&](const d2_t (&v)[g::NIT], int t, bool with_vector = true) {
     if (VGPA_ABL_NOSTORE && t > 1) return;
     double* so = mout + (size_t)t * MS;
 #pragma unroll
@@ -1036,7 +1046,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
       if (IT.st0[q]) stg(so, IT.g0[q], v[q][0]);
       if (IT.st1[q]) stg(so, IT.g1[q], v[q][1]);
     }
-    if (wave == 0 && vl) stg(vout + vec(t), lane8, vk);
+    if (with_vector) store_vector(t);
   };
   auto load_items = [&](const double* Xc, d2_t (&v)[g::NIT]) {
 #pragma unroll
@@ -1049,18 +1059,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
 #define VGPA_ABL_NOLOAD 0                // DIAGNOSTIC (wrong results; ubench only): behind the second step no loads of 1: A_t, c_t  2: G_t  4: jumps  8: obs index
 #endif
     const bool late = step > 1;
-    constexpr bool HR = decltype(helper_role)::value;
-    constexpr bool chores = !HLP || HR, units = !HLP || !HR;         // (helper waves: the operand and the vector; product waves: G_t)
-    if (chores && !((VGPA_ABL_NOLOAD & 1) && late) && LSTG == JSEC) {
-      load_a(A + (size_t)tclamp(step + 2) * DD);
-      c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+    // role kind: 0 = product waves beside helpers (G_t), 1 = every chore (the one helper role; without helpers: everything),
+    //            2 = the vector recursion's helper (H2), 3 = the staging helper (H2)
+    constexpr int HK = decltype(helper_role)::value;
+    constexpr bool ch_a = !HLP || HK == 1 || HK == 3, ch_v = !HLP || HK == 1 || HK == 2, units = !HLP || HK == 0;
+    if (!((VGPA_ABL_NOLOAD & 1) && late) && LSTG == JSEC) {
+      if (ch_a) load_a(A + (size_t)tclamp(step + 2) * DD);
+      if (ch_v) c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
     }
     if (!FWD) {
       if (units && !((VGPA_ABL_NOLOAD & 2) && late)) {
 #pragma unroll
         for (int s = 0; s < MAXS; s++) fnn[s] = ldg(G + (size_t)tclamp(step + 2) * GS, gofs[s]);
       }
-      if (chores && !((VGPA_ABL_NOLOAD & 4) && late)) jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
+      if (ch_v && !((VGPA_ABL_NOLOAD & 4) && late)) jm_next = step + 2 <= n_steps ? jump_vector(tidx(step + 2), n_obs_next) : 0.0;
       if (!((VGPA_ABL_NOLOAD & 8) && late)) n_obs_nn = (sparse_j && step + 3 <= n_steps) ? ldu(a.obs_idx, tidx(step + 3)) : -1;
     }
   };
@@ -1157,7 +1169,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
       }
     }
   };
-  auto tailC_finish = [&](int j, int step) {
+  using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+  // kind_: 1 = all of it (the one helper role / no helpers), 3 = the staging helper of H2 (the vector's store and loads are role 2's)
+  auto tailC_finish = [&](int j, int step, auto kind_) {
+    constexpr int KIND = decltype(kind_)::value;
     if (j == 0) {
       double* dst = (METHOD == VGPA_ODE_EULER && (step & 1)) ? Rb : Mb;
       if constexpr (QOUT && !GF) to_q(tc_items, tc_mid);
@@ -1170,14 +1185,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
       }
       if constexpr (GF) {                 // (Psi_t / Q''_t stay in the kernel; lam_t also goes to the gradient waves)
         if (wave == 0 && vl) { stg(vout + vec(tidx(step)), lane8, vk); gLam[lane] = vk; }
-      } else store_items(tc_items, tidx(step));
+      } else store_items(tc_items, tidx(step), KIND == 1);
     }
     if (j == JSEC && NS > 1) store_a(Rb, an);
-    if (j == JSEC) prefetch(step, std::true_type{});       // (overwrites an[]: behind its last use of the step; with helper waves: their part)
+    if (j == JSEC) prefetch(step, kind_);                  // (overwrites an[]: behind its last use of the step; with helper waves: their part)
     if (LSTG != JSEC && j == LSTG) {     // (helper-wave RK4 kernels: the next operand's loads behind the LAST stage's chores)
       load_a(A + (size_t)tclamp(step + 2) * DD);
-      c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
+      if (KIND == 1) c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
     }
+  };
+  // H2, role 1: what tailC does for the vector -- its way to HBM (stage 0) and its HBM loads
+  auto vec_chores = [&](int j, int step) {
+    if (j == 0) store_vector(tidx(step));
+    if (j == JSEC) prefetch(step, K2{});
+    if (LSTG != JSEC && j == LSTG) c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
   };
 
   // behind the barrier of stage j: every wave sums the partial products and advances its copy of the vector
@@ -1647,10 +1668,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
 #ifdef VGPA_STAMPS_ROLE
   long long ts_prev_ = clock64();
 #endif
-  constexpr bool HR = HLP && decltype(helper_role)::value;      // this copy is the helper waves'
+  constexpr int HK = HLP ? decltype(helper_role)::value : 0;    // 0: product waves (or no helpers); 1: the helper role; 2 / 3 (H2): vector / staging helper
+  constexpr bool HR = HK != 0;                                  // this copy is a helper role's
   for (int k = 0; k < n_steps; k++) {
     if (k > 0) {                         // what the last step's prefetch brought (the ONE place that waits for HBM)
-      if (!HLP || HR) {
+      if (!HLP || HK == 1 || HK == 3) {
 #pragma unroll
         for (int q = 0; q < NITS; q++) settle(an[q]);
       }
@@ -1673,17 +1695,21 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
         // every chore of the stage, requests first: the partial sums of the previous stage and (stage 0) the start-point operand and
         // the stage state; then the vector update, its partial products (they read the vector just written, same wave, in order),
         // the staging, the HBM stores and loads
-        if (j > 0 || k > 0) vecA_read(pv_prev);
-        tailC_read(j, Xc);
-        if (j > 0) vecA_finish(j - 1);
-        else if (k > 0) {
-          vecA_finish(NS - 1);
-          c0 = c1; c1 = c2;
-          if (!FWD) jm = jm_next;
+        if (HK != 3 && (j > 0 || k > 0)) vecA_read(pv_prev);
+        if (HK != 2) tailC_read(j, Xc);
+        if (HK != 3) {
+          if (j > 0) vecA_finish(j - 1);
+          else if (k > 0) {
+            vecA_finish(NS - 1);
+            c0 = c1; c1 = c2;
+            if (!FWD) jm = jm_next;
+          }
+          tailB_read(Aopv);
+          tailB_finish(pv);
         }
-        tailB_read(Aopv);
-        tailB_finish(pv);
-        tailC_finish(j, k);
+        if (HK == 1) tailC_finish(j, k, K1{});
+        if (HK == 2) vec_chores(j, k);
+        if (HK == 3) tailC_finish(j, k, K3{});
       } else
       product_stage(j, k, aop(k, j, true), Xc, Xn, [&](int t) {
         if (HLP) {                       // (product waves beside helpers: only their own HBM loads -- G_t of the step after the next)
@@ -1705,7 +1731,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
         if (t == SB_F) tailB_finish(pv);
         }
         if (t == SC_R) tailC_read(j, Xc);
-        if (t == SC_F) tailC_finish(j, k);
+        if (t == SC_F) tailC_finish(j, k, K1{});
         if (SPLIT) __builtin_amdgcn_sched_barrier(0);
       });
 #ifdef VGPA_STAMPS_ROLE      // diagnostic build (tools/ubench/ode_gf_loop.hip): first wave of each role of workgroup 0, per stage: [busy | wait at the barrier]
@@ -1716,7 +1742,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
       lds_barrier();
 #ifdef VGPA_STAMPS_ROLE
       { const long long tsa_ = clock64();
-        if (lane == 0 && wave == 0 && blockIdx.x == 0) { mfma::g_stamp_role[HR ? 1 : 0][2 * j] += tsb_ - ts_prev_; mfma::g_stamp_role[HR ? 1 : 0][2 * j + 1] += tsa_ - tsb_; }
+        if (lane == 0 && wave == 0 && blockIdx.x == 0) { mfma::g_stamp_role[HK == 3 ? 2 : (HR ? 1 : 0)][2 * j] += tsb_ - ts_prev_; mfma::g_stamp_role[HK == 3 ? 2 : (HR ? 1 : 0)][2 * j + 1] += tsa_ - tsb_; }
         ts_prev_ = tsa_; }
 #endif
       VGPA_STAMP(0, 2);
@@ -1731,18 +1757,21 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
     }
   }
   };
-  if (HLP && helper) time_loop(std::true_type{});
-  else time_loop(std::false_type{});
+  if (H2 && role == 1) time_loop(K2{});
+  else if (H2 && role == 2) time_loop(K3{});
+  else if (HLP && helper) time_loop(K1{});
+  else time_loop(std::integral_constant<int, 0>{});
   if constexpr (GF) {
     // the last grid point's gradient: three more barrier intervals.  The helpers finish the vector and leave lam; the gradient
     // waves build (Psi in the stage buffer, the end point's operand in R), then band / u, product, out; the product waves only count.
     if (role == 0) { lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier(); return; }
   }
   if (HLP && !helper) return;             // (the last state and the last vector leave through the helper waves)
-  if (n_steps > 0) {                     // the last stage's vector update
+  if (!(H2 && role == 2) && n_steps > 0) {      // the last stage's vector update
     vecA_read(pvb + (xcur(n_steps, 0) == Xb0 ? g::PV : 0));
     vecA_finish(NS - 1);
   }
+  if (H2 && role == 1) { store_vector(tidx(n_steps)); return; }
   if constexpr (GF) {
     if (wave == 0 && vl) { stg(vout + vec(tidx(n_steps)), lane8, vk); gLam[lane] = vk; }
     lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
@@ -1755,7 +1784,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * (GF ? 3 : (
       for (int q = 0; q < NITS; q++) a0[q] = *unit_ptr(Rb, q);
       to_q(items, a0);
     }
-    store_items(items, tidx(n_steps));
+    store_items(items, tidx(n_steps), !H2);
   }
 }
 
@@ -1784,6 +1813,14 @@ inline bool old_cover() {
   return true;             // (not compiled into the product build)
 #endif
 }
+// Helper-wave kernels: one helper role (512 threads) or two (768; VGPA_SYM_HELPERS=2 in the environment forces two, =1 one)
+inline bool two_helper_roles() {
+  static const int forced = [] { const char* e = getenv("VGPA_SYM_HELPERS"); return e ? atoi(e) : -1; }();
+#ifndef VGPA_SYM_TWO_HELPERS
+#define VGPA_SYM_TWO_HELPERS 1
+#endif
+  return forced >= 0 ? forced == 2 : VGPA_SYM_TWO_HELPERS != 0;
+}
 template <int METHOD, bool FWD, int NB, int GRC, bool HLP = false>
 hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
   constexpr size_t lds_c = SGeo<NB>::LDS_DOUBLES * sizeof(double);
@@ -1801,6 +1838,23 @@ hipError_t launch_cover(const OdeArgs& a, hipStream_t st, bool dense) {
     }
   }
   if (a.grad_on) return hipErrorInvalidValue;          // (only the kernel above assembles the gradient)
+  if constexpr (HLP && GRC == 0) {                     // two helper roles (k_ode_sym, H2): 768 threads, three waves per SIMD
+    if (two_helper_roles()) {
+      if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
+        if (a.q_on) {
+          if (dense) return hipErrorInvalidValue;
+          auto kq2 = k_ode_sym<METHOD, FWD, NB, false, GRC, 3, true, 4, true, false, true>;
+          (void)hipFuncSetAttribute((const void*)kq2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+          hipLaunchKernelGGL(kq2, dim3(a.batch), dim3(768), lds_c, st, a);
+          return hipGetLastError();
+        }
+      }
+      auto kc2 = dense ? k_ode_sym<METHOD, FWD, NB, true, GRC, 3, false, 4, true, false, true> : k_ode_sym<METHOD, FWD, NB, false, GRC, 3, false, 4, true, false, true>;
+      (void)hipFuncSetAttribute((const void*)kc2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+      hipLaunchKernelGGL(kc2, dim3(a.batch), dim3(768), lds_c, st, a);
+      return hipGetLastError();
+    }
+  }
   if constexpr (!FWD && (METHOD == VGPA_ODE_RK2 || METHOD == VGPA_ODE_RK4)) {
     if (a.q_on) {
       if (dense) return hipErrorInvalidValue;          // (the fused sweeps bring sparse jumps)

@@ -20,6 +20,7 @@ typedef int (*send_t)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*recv_t)(void*, size_t, int, int, void*, hipStream_t);
 typedef int (*group_t)();
 typedef int (*comm_count_t)(void*, int*);
+typedef int (*comm_split_t)(void*, int, int, void**, void*);
 constexpr int kNcclFloat64 = 8;          // ncclDataType_t (rccl.h)
 
 struct Api {
@@ -33,6 +34,7 @@ struct Api {
   recv_t recv = nullptr;
   group_t group_start = nullptr, group_end = nullptr;
   comm_count_t comm_count = nullptr;      // optional
+  comm_split_t comm_split = nullptr;      // optional (ncclCommSplit): the second communicator of the table
   bool tried = false, ok = false;
 };
 Api g_api;
@@ -62,14 +64,21 @@ bool load_api() {
   g_api.group_start = (group_t)dlsym(g_api.so, "ncclGroupStart");
   g_api.group_end = (group_t)dlsym(g_api.so, "ncclGroupEnd");
   g_api.comm_count = (comm_count_t)dlsym(g_api.so, "ncclCommCount");
+  g_api.comm_split = (comm_split_t)dlsym(g_api.so, "ncclCommSplit");
   g_api.ok = g_api.get_unique_id && g_api.comm_init_rank && g_api.comm_destroy && g_api.all_gather && g_api.send && g_api.recv &&
              g_api.group_start && g_api.group_end;
   return g_api.ok;
 }
 
+// TWO communicators per table: the stage's all-to-all / all-gathers run on the shard's compute stream, the point-to-point groups of the
+// pipelined gather on its communication stream, concurrently.  RCCL orders the operations of ONE communicator across streams with
+// events of its own; a communicator per stream is the documented pattern (comm2 = ncclCommSplit of comm with one colour: same ranks,
+// no second unique id to distribute).  Without ncclCommSplit in the library both roles share `comm`.
 struct RcclComm {
   void* comm = nullptr;
+  void* comm2 = nullptr;       // point-to-point traffic of the communication stream (nullptr: `comm`)
   int rank = 0, world = 1;
+  void* p2p() const { return comm2 ? comm2 : comm; }
 };
 
 int rccl_all_gather(void* user, const double* send, double* recv, uint64_t count, void* stream) {
@@ -94,11 +103,11 @@ int rccl_all_to_all(void* user, const double* send, double* recv, uint64_t count
 // point-to-point pair of the pipelined gather (always inside rccl_group_begin / rccl_group_end: one launch per sub-block)
 int rccl_send(void* user, const double* buf, uint64_t count, int peer, void* stream) {
   RcclComm* c = static_cast<RcclComm*>(user);
-  return c->comm ? g_api.send(buf, (size_t)count, kNcclFloat64, peer, c->comm, (hipStream_t)stream) : -1;
+  return c->comm ? g_api.send(buf, (size_t)count, kNcclFloat64, peer, c->p2p(), (hipStream_t)stream) : -1;
 }
 int rccl_recv(void* user, double* buf, uint64_t count, int peer, void* stream) {
   RcclComm* c = static_cast<RcclComm*>(user);
-  return c->comm ? g_api.recv(buf, (size_t)count, kNcclFloat64, peer, c->comm, (hipStream_t)stream) : -1;
+  return c->comm ? g_api.recv(buf, (size_t)count, kNcclFloat64, peer, c->p2p(), (hipStream_t)stream) : -1;
 }
 // after a failure: ncclCommAbort frees the communicator and fails the operations this rank still has in flight, so that its
 // streams drain; the peers see their own collectives fail or time out (vgpa_shard's bounded waits) and abort in turn
@@ -106,8 +115,12 @@ int rccl_abort(void* user) {
   RcclComm* c = static_cast<RcclComm*>(user);
   if (!c->comm) return 0;
   void* comm = c->comm;
-  c->comm = nullptr;
-  return g_api.comm_abort ? g_api.comm_abort(comm) : g_api.comm_destroy(comm);
+  void* comm2 = c->comm2;
+  c->comm = nullptr; c->comm2 = nullptr;
+  int rc2 = 0;
+  if (comm2) rc2 = g_api.comm_abort ? g_api.comm_abort(comm2) : g_api.comm_destroy(comm2);
+  const int rc = g_api.comm_abort ? g_api.comm_abort(comm) : g_api.comm_destroy(comm);
+  return rc ? rc : rc2;
 }
 
 int rccl_group_begin(void*) { return g_api.group_start(); }
@@ -135,6 +148,8 @@ int vgpa_rccl_comm_create(vgpa_comm* out, const void* id_bytes, int rank, int wo
   RcclComm* c = new RcclComm();
   c->rank = rank; c->world = world;
   if (g_api.comm_init_rank(&c->comm, world, id, rank) != 0) { delete c; return VGPA_ERR_DEVICE; }
+  // (collective: every rank of the table splits; a failure leaves the one communicator for both streams)
+  if (g_api.comm_split && g_api.comm_split(c->comm, 0, rank, &c->comm2, nullptr) != 0) c->comm2 = nullptr;
   out->user = c;
   out->all_gather = rccl_all_gather;
   out->all_to_all = rccl_all_to_all;
@@ -156,9 +171,20 @@ int vgpa_rccl_comm_count(const vgpa_comm* comm, int* count) {
   return g_api.comm_count(c->comm, count) == 0 ? VGPA_OK : VGPA_ERR_DEVICE;
 }
 
+// communicators behind the table: 2 (one per stream of the shard), or 1 when librccl has no ncclCommSplit
+int vgpa_rccl_comm_streams(const vgpa_comm* comm, int* count) {
+  if (!comm || !comm->user || !count) return VGPA_ERR_ARG;
+  if (comm->all_gather != rccl_all_gather) return VGPA_ERR_ARG;
+  RcclComm* c = static_cast<RcclComm*>(comm->user);
+  if (!c->comm) return VGPA_ERR_COMM;
+  *count = c->comm2 ? 2 : 1;
+  return VGPA_OK;
+}
+
 void vgpa_rccl_comm_destroy(vgpa_comm* comm) {
   if (!comm || !comm->user) return;
   RcclComm* c = static_cast<RcclComm*>(comm->user);
+  if (c->comm2) (void)g_api.comm_destroy(c->comm2);
   if (c->comm) (void)g_api.comm_destroy(c->comm);
   delete c;
   comm->user = nullptr;

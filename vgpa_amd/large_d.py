@@ -308,6 +308,16 @@ class NativeShardedRecursion:
         self._check(self._lib.vgpa_rccl_comm_count(ctypes.byref(self._comm), ctypes.byref(n)), "vgpa_rccl_comm_count")
         return int(n.value)
 
+    @property
+    def rccl_communicators(self):
+        """Communicators behind the RCCL table: 2 (the collectives of the compute stream and the point-to-point groups of the
+        communication stream each have their own), 1 when librccl cannot split, 0 without an RCCL communicator."""
+        if self._comm is None or not self._own_comm:
+            return 0
+        n = ctypes.c_int(0)
+        self._check(self._lib.vgpa_rccl_comm_streams(ctypes.byref(self._comm), ctypes.byref(n)), "vgpa_rccl_comm_streams")
+        return int(n.value)
+
     def _problem(self, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
         from ._lib import VgpaShardProblem
         d = self.D
