@@ -2,7 +2,7 @@
 // back to back for <seconds>.  Inputs are arbitrary finite numbers (the timing does not depend on them); ablation macros of
 // ode_sym_impl.h (-DVGPA_GF_ABL=<bits>, wrong results) show what each phase of the assembly costs.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DVGPA_EXPERIMENTS -DVGPA_STAMPS_ROLE | -DVGPA_EXPERIMENTS -DVGPA_GF_ABL=<bits>] -I../../vgpa_amd/csrc -I../../include ode_gf_loop.hip -o ode_gf_loop
-// usage: ode_gf_loop <batch> <grad 1|0> <seconds>
+// usage: ode_gf_loop <batch> <grad 1|0> <seconds> [fwd 1|0]
 #include "ode_sym_impl.h"
 #include <cstdio>
 #include <vector>
@@ -31,7 +31,9 @@ int main(int argc, char** argv) {
   a.dEm = dv; a.dEs = dG; a.ds_packed = 1; a.lam = dlam; a.psi = dpsi; a.js_const = dSg; a.n_obs = 0;
   a.q_on = 1; a.q_scale = 0.25;
   if (grad) { a.grad_on = 1; a.s_packed = 1; a.S = dS; a.m = dv; a.Ef = dv; a.Am = dv; a.g = dg; }
-  auto go = [&]() { return sym::launch_cover<3, false, 10, 0, true>(a, 0, false); };
+  const int fwd = (argc > 4) ? atoi(argv[4]) : 0;
+  if (fwd) { a.q_on = 0; a.m0 = dv; a.S0 = dSg; a.Sigma = dSg; a.m = dlam; a.S = dpsi; a.s_packed = 0; }
+  auto go = [&]() { return fwd ? sym::launch_cover<3, true, 10, 0, true>(a, 0, false) : sym::launch_cover<3, false, 10, 0, true>(a, 0, false); };
   hipError_t e0_ = go(); hipDeviceSynchronize();
   const double seconds = (argc > 3) ? atof(argv[3]) : 3.0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -46,8 +48,8 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(mfma::g_stamp_role), zero, sizeof(zero));
     go(); hipDeviceSynchronize();
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mfma::g_stamp_role), sizeof(st));
-    for (int r = 0; r < (grad ? 3 : 2); r++) {
-      printf("%s wave 0 of workgroup 0, cycles per stage [busy | barrier wait]:", r == 2 ? "grad   " : r ? "helper " : "product");
+    for (int r = 0; r < 3; r++) {
+      printf("%s wave 0 of workgroup 0, cycles per stage [busy | barrier wait]:", r == 2 ? (grad ? "grad   " : "helper2") : r ? "helper " : "product");
       for (int j = 0; j < 4; j++) printf("  j%d %lld | %lld", j, st[r][2 * j] / (Np - 1), st[r][2 * j + 1] / (Np - 1));
       printf("\n");
     }
@@ -59,7 +61,7 @@ int main(int argc, char** argv) {
     }
   }
 #endif
-  printf("bwd RK4 D=40 Np=%d B=%d grad=%d abl=%d: %.3f ms per launch over %.1f s  err=%s / %s\n", Np, B, grad, VGPA_GF_ABL, total / n, 1e-3 * total,
+  printf("%s RK4 D=40 Np=%d B=%d grad=%d abl=%d: %.3f ms per launch over %.1f s  err=%s / %s\n", fwd ? "fwd" : "bwd", Np, B, grad, VGPA_GF_ABL, total / n, 1e-3 * total,
          hipGetErrorString(e0_), hipGetErrorString(hipGetLastError()));
   return 0;
 }

@@ -1185,8 +1185,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * ((GF || H2)
       }
       if constexpr (GF) {                 // (Psi_t / Q''_t stay in the kernel; lam_t also goes to the gradient waves)
         if (wave == 0 && vl) { stg(vout + vec(tidx(step)), lane8, vk); gLam[lane] = vk; }
-      } else store_items(tc_items, tidx(step), KIND == 1);
+      } else if (!(KIND == 3 && NS > 1)) store_items(tc_items, tidx(step), KIND == 1);
     }
+    // (H2's staging helper is the longest chain of stage 0 -- units in, mid-point, operand out, state out -- and nearly idle in stages 1
+    //  and 2: the state's way to HBM, which only needs the registers read at stage 0, waits for stage 2 (stage 1 has the end-point
+    //  operand's staging).  One problem, stamps: stage 0 2 860 -> 2 370 cycles for this role against 2 320 - 2 420 for the product waves;
+    //  one sweep direction 3.64 -> 3.5 ms backward, 3.39 -> 3.27 forward.)
+    if (KIND == 3 && NS > 1 && j == (NS > 2 ? 2 : 1)) store_items(tc_items, tidx(step), false);
     if (j == JSEC && NS > 1) store_a(Rb, an);
     if (j == JSEC) prefetch(step, kind_);                  // (overwrites an[]: behind its last use of the step; with helper waves: their part)
     if (LSTG != JSEC && j == LSTG) {     // (helper-wave RK4 kernels: the next operand's loads behind the LAST stage's chores)
