@@ -590,23 +590,6 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
       eo_o[u] = GB + 8u * (unsigned)(gl::O + ((row < D && col < D) ? row * D + col : PP * PP - 1));
     }
   }
-#ifndef VGPA_GF_STAGING_IN_G
-#define VGPA_GF_STAGING_IN_G 1           // the operand staging (mid-point, end point, A_t's loads) on these waves instead of the helpers'
-#endif
-  constexpr bool GSTG = VGPA_GF_STAGING_IN_G != 0;
-  constexpr unsigned MBo = 8u * 3u * (unsigned)g::XS;    // the mid-point operand M
-  unsigned a_g[NIT];                                     // byte offset of A[2p][c] in A_t (the item's row pair; row 2p + 1 is D doubles on)
-  unsigned twomask = 0;                                  // bit q: row 2p + 1 of item q exists
-#pragma unroll
-  for (int q = 0; q < NIT; q++) {
-    const int e = tid + NT * q;
-    int p = e / g::P, c = e - p * g::P;
-    if (!(2 * p < D && c < D)) { p = 0; c = 0; }
-    a_g[q] = 8u * (unsigned)(2 * p * D + c);
-    if (2 * p + 1 < D) twomask |= 1u << q;
-  }
-  const unsigned d8 = 8u * (unsigned)D;
-  const bool d_odd = (D & 1) != 0;
   unsigned oo[NOUT];                                     // the out-buffer's element tid + 256 q: the same offset in LDS and in gLa_t
 #pragma unroll
   for (int q = 0; q < NOUT; q++) { const int e = tid + NT * q; oo[q] = 8u * (unsigned)(e < DD ? e : DD - 1); }      // (beyond the matrix: a duplicate of its last element)
@@ -631,26 +614,10 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
 #pragma unroll
     for (int q = 0; q < NOUT; q++) op(oo[q]);
     op(m_w); op(blam); op(bu); op(lane8);
-    if (GSTG) {
-#pragma unroll
-      for (int q = 0; q < NIT; q++) op(a_g[q]);
-      op(twomask);
-    }
   };
 
   // ---- phases (SET: compile-time operand set) -------------------------------------------------------------------------------------
   double gsv[NPKI], gvm = 0.0, gvef = 0.0, gvam = 0.0, gvb = 0.0, gacc[7];
-  d2_t an[NIT];                                          // GSTG: A of the step's end point (then of the next step's), row-pair items
-  auto wr2 = [&](unsigned off, d2_t v) { *reinterpret_cast<d2_t*>(lds + off) = v; };
-  auto load_an = [&](int tg) {
-    const double* At = a.A + (size_t)prob * a.strideA + (size_t)tg * DD;
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-      an[q][0] = ldg(At, a_g[q]);
-      an[q][1] = ldg(At, a_g[q] + (((twomask >> q) & 1u) ? d8 : 0u));      // (no row 2p + 1: a duplicate of row 2p, zeroed where it is used)
-    }
-  };
-  auto tclamp = [&](int i) { return tidx(i <= n_steps ? i : n_steps); };
   // S_t (packed) and the vector entries of grid point tg, one step ahead of their use
   auto prefetch = [&](int tg) {
     const size_t o = (size_t)prob * Np + tg;
@@ -666,19 +633,6 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
 #pragma unroll
     for (int q = 0; q < NPKI; q++) settle(gsv[q]);
     settle(gvm); settle(gvef); settle(gvam); settle(gvb);
-    if (GSTG) {
-#pragma unroll
-      for (int q = 0; q < NIT; q++) settle(an[q]);
-    }
-  };
-  // GSTG, stage 1: the end point's operand A_{t-1} -> R (mfma::stage_op: nobody reads R during stage 1)
-  auto stage_end_point = [&]() {
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-      d2_t o = an[q];
-      if (d_odd && !((twomask >> q) & 1u)) o[1] = 0.0;
-      wr2(it_rd[q] + RB, o);
-    }
   };
   // the operands of the grid point whose Psi_t is in stage buffer 0 and whose A_t is in R, and m_t
   auto build = [&](auto set_) {
@@ -686,15 +640,6 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
     d2_t ps[NIT], a0[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; q++) { ps[q] = rd2(it_rd[q]); a0[q] = rd2(it_rd[q] + RB); }
-    if (GSTG) {                          // the mid-point operand M = (A_t + A_{t-1}) / 2 of stages 1 and 2 (same expression as tailC_finish)
-#pragma unroll
-      for (int q = 0; q < NIT; q++) {
-        d2_t o;
-        o[0] = 0.5 * (a0[q][0] + an[q][0]); o[1] = 0.5 * (a0[q][1] + an[q][1]);
-        if (d_odd && !((twomask >> q) & 1u)) o[1] = 0.0;
-        wr2(it_rd[q] + MBo, o);
-      }
-    }
 #pragma unroll
     for (int q = 0; q < NPKI; q++) { wr1(s_w0[q] + SB, gsv[q]); wr1(s_w1[q] + SB, gsv[q]); }
     wr1(m_w + SV, gvm);
@@ -815,10 +760,7 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
     constexpr bool HP = decltype(hp_)::value, HP2 = decltype(hp2_)::value;
     using CUR = std::integral_constant<int, SET>; using PRV = std::integral_constant<int, SET ^ 1>;
 #ifndef VGPA_GF_OUT_TICK
-#define VGPA_GF_OUT_TICK 2               // (with the operand staging on these waves stage 0 is their longest: out-buffer and first k-pair later)
-#endif
-#ifndef VGPA_GF_KP_SHIFT
-#define VGPA_GF_KP_SHIFT 1               // 1: k-pairs 0 | 1, 2 | 3, 4 in stages 1 | 2 | 3 (0: 0 | 1 | 2, 3 | 4 in stages 0 .. 3)
+#define VGPA_GF_OUT_TICK 0
 #endif
 #ifndef VGPA_GF_PRIO_LOW
 #define VGPA_GF_PRIO_LOW VGPA_GF_PRIO_G
@@ -831,21 +773,18 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
     __builtin_amdgcn_sched_barrier(0);
     if (!(VGPA_GF_ABL & 4)) build(CUR{});
     __builtin_amdgcn_sched_barrier(0);
-    if (!VGPA_GF_KP_SHIFT && HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I0{}, I1{});
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I0{}, I1{});
     VGPA_GF_BARRIER(0);
     if (VGPA_GF_PRIO_LOW != VGPA_GF_PRIO_G) __builtin_amdgcn_s_setprio(VGPA_GF_PRIO_LOW);
-    if (GSTG) stage_end_point();
     if (!(VGPA_GF_ABL & 2)) band_u(CUR{}, tidx(k));
     prefetch(tidx(k + 1));
     __builtin_amdgcn_sched_barrier(0);
-    using I3 = std::integral_constant<int, 3>;
-    if (HP && !(VGPA_GF_ABL & 1)) { if (VGPA_GF_KP_SHIFT) prod(PRV{}, I0{}, I1{}); else prod(PRV{}, I1{}, I2{}); }
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I1{}, I2{});
     VGPA_GF_BARRIER(1);
     if (VGPA_GF_OUT_TICK == 2 && HP2 && !(VGPA_GF_ABL & 8)) { out(tidx(k - 2)); __builtin_amdgcn_sched_barrier(0); }
-    if (HP && !(VGPA_GF_ABL & 1)) { if (VGPA_GF_KP_SHIFT) prod(PRV{}, I1{}, I3{}); else prod(PRV{}, I2{}, I4{}); }
+    if (HP && !(VGPA_GF_ABL & 1)) prod(PRV{}, I2{}, I4{});
     VGPA_GF_BARRIER(2);
-    if (HP) { if (!(VGPA_GF_ABL & 1)) { if (VGPA_GF_KP_SHIFT) prod(PRV{}, I3{}, I5{}); else prod(PRV{}, I4{}, I5{}); } __builtin_amdgcn_sched_barrier(0); epilogue(PRV{}); }
-    if (GSTG) load_an(tclamp(k + 2));    // (behind the last stage's work, like the helpers' LSTG)
+    if (HP) { if (!(VGPA_GF_ABL & 1)) prod(PRV{}, I4{}, I5{}); __builtin_amdgcn_sched_barrier(0); epilogue(PRV{}); }
     VGPA_GF_BARRIER(3);
   };
   // behind the loop: the last grid point (Psi in stage buffer 0, the end point's operand in R, lam from the helpers' last vector update)
@@ -871,7 +810,6 @@ __device__ __forceinline__ void grad_waves(const OdeArgs& a, double* __restrict_
   __builtin_amdgcn_s_setprio(VGPA_GF_PRIO_G);
   __syncthreads();                       // LDS zero-filled (by the other roles)
   prefetch(tidx(0));
-  if (GSTG) load_an(tclamp(1));
   settle_loads();
   __syncthreads();                       // prologue published
   using F = std::false_type; using T = std::true_type;
@@ -1263,10 +1201,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * ((GF || H2)
   };
   // H2, role 1: what tailC does for the vector -- its way to HBM (stage 0) and its HBM loads
   auto vec_chores = [&](int j, int step) {
-    if (j == 0) {
-      store_vector(tidx(step));
-      if constexpr (GF) { if (wave == 0 && vl) gLam[lane] = vk; }      // (lam_t for the gradient waves)
-    }
+    if (j == 0) store_vector(tidx(step));
     if (j == JSEC) prefetch(step, K2{});
     if (LSTG != JSEC && j == LSTG) c2 = ldg(cin + vec(tclamp(step + 2)), lane8);
   };
@@ -1827,7 +1762,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * NW * ((GF || H2)
     }
   }
   };
-  if ((H2 || (GF && VGPA_GF_STAGING_IN_G)) && role == 1) time_loop(K2{});      // (GF: the gradient waves stage the operands)
+  if (H2 && role == 1) time_loop(K2{});
   else if (H2 && role == 2) time_loop(K3{});
   else if (HLP && helper) time_loop(K1{});
   else time_loop(std::integral_constant<int, 0>{});
