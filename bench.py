@@ -590,7 +590,7 @@ def main():
     traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
                       "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-single-problem "
                              "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
-                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r05e_pmc_fetch_write_B512.csv"}
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r05z_pmc_fetch_write_B512.csv"}
 
     # streams of the default batched path (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I, B > #CUs): the backward kernel writes
     # Q''_t = A_t / sigma^2 - 2 Psi_t where Psi_t would be, the gradient assembly reads Q''_t and S_t only, and dEsde_dS exists as its
@@ -633,15 +633,15 @@ def main():
     n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     keep_pe = os.environ.get("VGPA_ODE_KERNEL") == "pe"
     sym_units = d > 44 or (B > n_cu and nb_blocks <= 10) or os.environ.get("VGPA_ODE_KERNEL") == "sym" or (nb_blocks in (9, 10) and not keep_pe)
-    wpe = 2 if nb_blocks <= 10 else 1
+    wpe = 2 if nb_blocks <= 10 else 1        # (helper-wave kernels with two helper roles: 3, see `hlp`)
     cover = 0 if (nb_blocks in (9, 10) and os.environ.get("VGPA_SYM_RUNS") != "1") else 1      # fragment-cover kernels for 33 <= D <= 40
     # (last parameter: the backward cover kernels of RK2 / RK4 store Q''_t = Sigma^-1 A_t - 2 Psi_t for the gradient assembly)
     q_out = lambda fwd: "true" if (fwd == "false" and cover == 0 and method_id in (2, 3) and not args.keep_psi) else "false"
     hlp = "true" if (cover == 0 and B <= n_cu and os.environ.get("VGPA_SYM_HELPERS") != "0") or os.environ.get("VGPA_SYM_HELPERS") == "1" else "false"
-    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4, {hlp}, false>") if sym_units else \
+    step_sym = (lambda fwd: f"vgpa::sym::k_ode_sym<{method_id}, {fwd}, {nb_blocks}, false, {cover}, {wpe}, {q_out(fwd)}, 4, {hlp}, false, {hlp}>") if sym_units else \
                (lambda fwd: f"vgpa::mfma::k_ode_pe<{method_id}, {fwd}, {nb_blocks}, false>")
     symbols = {"solve_fwd": step_sym("true"), "solve_bwd": step_sym("false"),
-               "solve_bwd_grad": f"vgpa::sym::k_ode_sym<{method_id}, false, {nb_blocks}, false, 0, 3, true, 4, true, true> (768 threads: product, helper and gradient waves)",
+               "solve_bwd_grad": f"vgpa::sym::k_ode_sym<{method_id}, false, {nb_blocks}, false, 0, 3, true, 4, true, true, false> (768 threads: product, helper and gradient waves)",
                "energy_l96": f"vgpa::(anonymous namespace)::k_energy_l96_r<{nb_blocks}, 1> (+ k_obs)", "grad": f"vgpa::k_grad_mfma{'_q' if (sym_units and q_out('false') == 'true') else ''}<{nb_blocks}> (+ k_reduce)"}
     roof = {}
     for name, k in kernels.items():

@@ -15,8 +15,8 @@ import re
 import sqlite3
 import sys
 
-# (first match wins: the backward kernel that assembles the gradient -- last template argument GF = true -- before the plain one)
-KEYS = [(r"k_ode_(pe|sym)<\d+, true", "solve_fwd"), (r"k_ode_sym<\d+, false, .*, true>", "solve_bwd_grad"),
+# (first match wins: the backward kernel that assembles the gradient -- tenth template argument GF = true -- before the plain one)
+KEYS = [(r"k_ode_(pe|sym)<\d+, true", "solve_fwd"), (r"k_ode_sym<\d+, false, \d+, \w+, -?\d+, \d+, \w+, \d+, \w+, true", "solve_bwd_grad"),
         (r"k_ode_(pe|sym)<\d+, false", "solve_bwd"), (r"k_energy_l96", "energy_l96"), (r"k_grad", "grad")]
 
 
