@@ -184,6 +184,45 @@ def test_gradient_waves_of_the_backward_kernel(d, n_pts, obs):
     ctx.close(); ctx_k.close()
 
 
+def test_fused_gradient_kernel_below_its_default_batch_size():
+    """Below 64 problems per context the default is the backward kernel followed by the separate assembly; VGPA_FUSED_GRAD=1 forces the
+    kernel with the gradient waves (read once per process: a child process).  One problem, three problems and a padded dimension
+    against the default path of this process and the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    cases = ((40, 9, 1), (40, 14, 3), (35, 6, 2))
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_gpu_edge_cases as t\n"
+        "out = []\n"
+        "for d, n, batch in %r:\n"
+        "    p, x = t.make_problem('L96', d, n, method='rk4')\n"
+        "    ctx = t.gpu_context(p, batch=batch)\n"
+        "    xb = np.stack([x + 0.01 * i for i in range(batch)]) if batch > 1 else x\n"
+        "    f, g = ctx.sweep(xb)\n"
+        "    out.append({'f': [float(v) for v in np.atleast_1d(f)], 'g': np.asarray(g).ravel().tolist()})\n"
+        "    ctx.close()\n"
+        "print(json.dumps(out))\n" % (os.path.dirname(__file__), cases))
+    env = dict(os.environ)
+    env["VGPA_FUSED_GRAD"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fused = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])
+    for (d, n, batch), got in zip(cases, fused):
+        p, x = make_problem("L96", d, n, method="rk4")
+        ctx = gpu_context(p, batch=batch)
+        xb = np.stack([x + 0.01 * i for i in range(batch)]) if batch > 1 else x
+        f, g = ctx.sweep(xb)
+        ctx.close()
+        assert np.array_equal(np.atleast_1d(f), np.asarray(got["f"]))                   # F: the same kernels either way
+        assert rel_err(np.asarray(got["g"]), np.asarray(g).ravel()) < 1e-12              # the gradient: another product order
+        f_ref, g_ref, _ = vo.sweep(p, np.atleast_2d(xb)[0], faithful=False)
+        assert rel_err(np.asarray(got["g"]).reshape(batch, -1)[0], g_ref) < TOL
+
+
 @pytest.mark.parametrize("method", ["rk4", "heun"])
 def test_more_problems_than_compute_units(method):
     """bench.py's regime: a batch larger than twice the CU count, so that the default dispatch picks the symmetric-unit steppers and
