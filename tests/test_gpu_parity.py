@@ -184,6 +184,35 @@ def test_full_size_anchors_on_the_bench_kernels(pert, monkeypatch):
     assert abs(f - f_pe) <= 1e-12 * abs(f_pe) and rel_err(g, g_pe) < 1e-10
 
 
+def test_full_size_anchors_on_the_fused_backward_kernel():
+    """bench.py's backward path since round 5: from 64 problems per context on the backward kernel assembles the gradient on a third
+    set of waves (k_ode_sym, GF) and keeps Psi_t to itself.  A batch of 64 at the FULL grid of BASELINE configs[2]: problem 0 = the
+    reference's x0, problem 1 = its perturbed x, against the reference's anchors (F, the gradient's norm and largest entry); Psi_t as
+    vgpa_fetch materialises it afterwards against the anchored norm; the other 62 problems keep the batch honest (all finite, all
+    different)."""
+    anchors = json.load(open(os.path.join(GOLDEN_DIR, "anchors.json")))
+    a0, a1 = anchors["l96d40_rk4_full"], anchors["l96d40_rk4_full_p"]
+    p = build_problem("L96", "RK4", a0["tf"], a0["dt"], 40)
+    v = p["vgp"]
+    x0 = v.initialization()
+    nb = 64
+    xb = np.stack([x0 + 0.05 * np.random.default_rng(0 if i == 1 else 100 + i).standard_normal(x0.size) for i in range(nb)])
+    xb[0] = x0
+    e0 = float(p["kl0"](p["m0"], p["s0"]))
+    ctx = va.Context("L96", "rk4", 40, v.dim_n, a0["dt"], sigma=p["model"].sigma, theta=[8.0], m0=p["m0"], s0=p["s0"], obs_t=p["obs_t"],
+                     obs_y=p["obs_y"], obs_noise=p["obs_noise"], e0=e0, batch=nb)
+    f, g = ctx.sweep(xb)
+    for i, a in ((0, a0), (1, a1)):
+        assert abs(f[i] - a["F"]) <= TOL * abs(a["F"])
+        assert abs(np.linalg.norm(g[i]) - a["grad_norm"]) <= TOL * a["grad_norm"]
+        assert abs(np.abs(g[i]).max() - a["grad_absmax"]) <= TOL * a["grad_absmax"]
+    assert np.all(np.isfinite(f)) and np.all(np.isfinite(g)) and len(set(np.round(f, 6))) == nb
+    psi = ctx.fetch("psit")
+    for i, a in ((0, a0), (1, a1)):
+        assert abs(np.linalg.norm(psi[i].ravel()) - a["psi_fro"]) <= TOL * a["psi_fro"]
+    ctx.close()
+
+
 def test_properties_at_baseline_size():
     """Lorenz-96 D=40, Np=1001: symmetry of S_t / Psi_t, batch consistency, determinism, op/fused agreement."""
     p = build_problem("L96", "RK4", 10.0, 0.01, 40)
