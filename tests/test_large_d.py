@@ -307,6 +307,39 @@ def test_large_d_fused_sweep(d, n, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,n,method,batch", [(72, 9, "rk4", 1), (128, 7, "heun", 1), (96, 8, "rk2", 1), (80, 11, "euler", 1), (96, 9, "rk4", 3)])
+def test_repeated_sweeps_on_one_context_above_64(d, n, method, batch):
+    """An optimiser's use of a context above D = 64: sweep after sweep on the same device buffers, every one on another
+    parameter vector and compared with the oracle; the stored recursions fetched in between; F-only evaluations followed by
+    the gradient (all four steppers through the one-kernel stages, one batched context)."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    p, x = make_problem("L96", d, n, method=method)
+    ctx = gpu_context(p, batch=batch)
+    rng = np.random.default_rng(11)
+    for it in range(5):
+        xs = np.stack([x + 0.01 * rng.standard_normal(x.size) for _ in range(batch)])
+        f, g = ctx.sweep(xs if batch > 1 else xs[0])
+        f, g = np.atleast_1d(f), np.asarray(g).reshape(batch, -1)
+        for q in range(batch):
+            f_ref, g_ref, st = vo.sweep(p, xs[q], faithful=False)
+            assert abs(f[q] - f_ref) <= TOL * abs(f_ref), (it, q, f[q], f_ref)
+            assert rel_err(g[q], g_ref) < TOL, (it, q)
+        if it in (2, 4):
+            for key in ("mt", "st", "lamt", "psit"):
+                got = np.asarray(ctx.fetch(key))
+                got = got[batch - 1] if batch > 1 else got
+                assert rel_err(got.reshape(np.shape(st[key])), st[key]) < TOL, (it, key)
+    if batch == 1:                                  # F-only evaluations, the gradient asked for afterwards
+        for it in range(3):
+            xs = x + 0.01 * rng.standard_normal(x.size)
+            f = ctx.free_energy(xs)
+            f_ref, g_ref, _ = vo.sweep(p, xs, faithful=False)
+            assert abs(float(np.atleast_1d(f)[0]) - f_ref) <= TOL * abs(f_ref)
+            assert rel_err(ctx.gradient(), g_ref) < TOL
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method", ["euler", "heun", "rk2", "rk4"])
 @pytest.mark.parametrize("d,n,chunk", [(80, 23, 5), (96, 12, 11), (72, 30, 1), (128, 9, 64)])
 def test_time_chunked_sweep_equals_the_resident_one(d, n, chunk, method):

@@ -408,6 +408,10 @@ struct StageArgs {
   const double* jv;     // [Mp] vector jump or nullptr
   const double* vbase;  // [Mp]
   double* k1v; double* k23v; double* vout;   // [Mp]
+  // one-kernel stage (k_stage_prod): the operands of the products instead of W / Wcol
+  const double* M0 = nullptr; const double* M1 = nullptr;   // A of the matrix product (M1: mid-point partner or nullptr), [D][D]
+  const double* Xm = nullptr;                               // stage state S / Psi (symmetric), [D][D]
+  size_t zM = 0, zXm = 0;
 };
 
 constexpr int TS = 32;
@@ -433,6 +437,35 @@ __device__ __forceinline__ void stage_batch_offsets(StageArgs& a) {
   a.e0 += z * a.zEv; if (a.e1) a.e1 += z * a.zEv;
   if (a.jv) a.jv += z * a.zJv;
   a.vbase += z * a.zVb; a.k1v += z * a.zKv; a.k23v += z * a.zKv; a.vout += z * a.zVo;
+  if (a.M0) { a.M0 += z * a.zM; if (a.M1) a.M1 += z * a.zM; a.Xm += z * a.zXm; }
+}
+
+// the vector recursion of a stage (m forward, lam backward): one wave per row of this rank's block, `blk` counts the
+// workgroups behind the matrix tiles
+__device__ __forceinline__ void stage_vector_rows(const StageArgs& a, int blk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blk * (NT / 64) + wave;
+  if (r >= a.Mp) return;
+  const double sgn = a.fwd ? 1.0 : -1.0;
+  const size_t ro = (size_t)(a.row0 + r) * a.lda;
+  double s = 0.0;
+  for (int k = lane; k < a.D; k += 64) {
+    const double av = a.mid_a ? 0.5 * (a.A0[ro + k] + a.A1[ro + k]) : a.A0[ro + k];
+    s = __builtin_fma(av, a.x[k], s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const double e = a.mid_ev ? 0.5 * (a.e1[r] + a.e0[r]) : a.e0[r];
+    const double rv = a.fwd ? (-s + e) : (-e + s);
+    const double k1 = (a.final >= 2) ? a.k1v[r] : 0.0;
+    const double k23 = (a.final == 3) ? a.k23v[r] : 0.0;
+    if (a.kstore == 1) a.k1v[r] = rv;
+    else if (a.kstore == 2) a.k23v[r] = rv;
+    else if (a.kstore == 3) a.k23v[r] = a.k23v[r] + rv;
+    const double jump = (a.final && a.jv) ? a.jv[r] : 0.0;
+    a.vout[r] = stage_combine(rv, a.vbase[r], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+  }
 }
 
 __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
@@ -473,29 +506,7 @@ __global__ void __launch_bounds__(NT) k_stage(StageArgs a) {
     }
     return;
   }
-  // ---- vector recursion: one wave per row
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = ((int)blockIdx.x - nmat) * (NT / 64) + wave;
-  if (r >= a.Mp) return;
-  const size_t ro = (size_t)(a.row0 + r) * a.lda;
-  double s = 0.0;
-  for (int k = lane; k < a.D; k += 64) {
-    const double av = a.mid_a ? 0.5 * (a.A0[ro + k] + a.A1[ro + k]) : a.A0[ro + k];
-    s = __builtin_fma(av, a.x[k], s);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) {
-    const double e = a.mid_ev ? 0.5 * (a.e1[r] + a.e0[r]) : a.e0[r];
-    const double rv = a.fwd ? (-s + e) : (-e + s);
-    const double k1 = (a.final >= 2) ? a.k1v[r] : 0.0;
-    const double k23 = (a.final == 3) ? a.k23v[r] : 0.0;
-    if (a.kstore == 1) a.k1v[r] = rv;
-    else if (a.kstore == 2) a.k23v[r] = rv;
-    else if (a.kstore == 3) a.k23v[r] = a.k23v[r] + rv;
-    const double jump = (a.final && a.jv) ? a.jv[r] : 0.0;
-    a.vout[r] = stage_combine(rv, a.vbase[r], k1, k23, a.final, a.cx, a.cf, sgn, jump);
-  }
+  stage_vector_rows(a, (int)blockIdx.x - nmat);
 }
 
 template <int BM, bool FULL>
@@ -614,30 +625,189 @@ __global__ void __launch_bounds__(NT) k_stage_sym(StageArgs a) {
     }
     return;
   }
-  // ---- vector recursion: one wave per row
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = ((int)blockIdx.x - npair) * (NT / 64) + wave;
-  if (r >= a.Mp) return;
-  const size_t ro = (size_t)(a.row0 + r) * a.lda;
-  double s = 0.0;
-  for (int k = lane; k < a.D; k += 64) {
-    const double av = a.mid_a ? 0.5 * (a.A0[ro + k] + a.A1[ro + k]) : a.A0[ro + k];
-    s = __builtin_fma(av, a.x[k], s);
-  }
+  stage_vector_rows(a, (int)blockIdx.x - npair);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One kernel per stage (64 < D <= kStageProdMaxD, one rank owns every row, symmetric inputs).  A stage of the two-kernel
+// scheme above costs ~6 us between dependent launches whatever their size (measured: 3600 launches of an RK4 recursion over
+// 401 grid points take 24 ms at D = 96 AND at D = 128, 32 ms at D = 256; replaying the loop as a hipGraph changes nothing --
+// the gap is the device's, not the host's -- EXPERIMENTS.md s.13), so below D ~ 512 the recursion is bound by the NUMBER of
+// launches: nine per RK4 step (mid-point operand, four products, four stage kernels).  Here a workgroup owns the pair of
+// 32 x 32 tiles (I, J) / (J, I), I <= J, of the stage slope and forms BOTH products it needs itself,
+//     forward :  w = (A X)[I, J],      wt = (A X)[J, I]^T   = (X A^T)[I, J]      (X = X^T)
+//     backward:  w = (A^T Psi)[I, J],  wt = (A^T Psi)[J, I]^T = (Psi A)[I, J]    (Psi = Psi^T)
+// -- two fp64-MFMA accumulators over the same k loop, the same k order as k_gemm, then the element-wise stage of k_stage_sym
+// on them in the same expression order (results equal the two-kernel scheme's bit for bit), the mirror tile through an LDS
+// transposition.  The mid-point operand 0.5 (A_k + A_{k+1}) is averaged while staging (A is L2-resident at these sizes).
+// Four launches per RK4 step instead of nine; every tile product is still computed exactly once per stage.
+// By symmetry of X every operand tile is a set of ROW segments: forward all four tiles are [32 rows][16 k] (rows I / J of A
+// and of X); backward the A tiles are [16 k][32 columns I / J] and the Psi tiles [32 rows][16 k].
+constexpr int kStageProdMaxD = 512;
+// Operand tiles come through buffer descriptors (raw_buffer_load: a per-thread 32-bit offset fixed for the whole k loop + a
+// scalar offset per k-tile): no per-tile address arithmetic in vector registers -- with 64-bit addresses recomputed per tile
+// the register allocator recycles the destination registers of the loads in flight for them and every prefetch waits for the
+// previous one (seen in the ISA of the first version of this kernel: 17 us per launch at D = 128) -- and the range check of the
+// descriptor returns zero for rows / columns / k beyond the matrix (edge tiles: an offset beyond the D x D doubles), so that
+// no load sits in a branch region either.  Only a row-major tile's k overrun into the NEXT ROW needs a select.
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __builtin_bit_cast(double, v);
+}
+template <bool TRANSA, bool MID>
+__global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
+  stage_batch_offsets(a);
+  const int D = a.D;
+  const int nt = (D + TS - 1) / TS;
+  const int npair = nt * (nt + 1) / 2;
+  if ((int)blockIdx.x >= npair) { stage_vector_rows(a, (int)blockIdx.x - npair); return; }
+  constexpr int LDR = 18;                       // [32 rows][16 k + 2]: conflict-free fragment reads (k_gemm_v, NN)
+  constexpr int LDT = 48;                       // [16 k][32 + 16]: = 16 (mod 32)
+  constexpr int ASZ = TRANSA ? BK * LDT : TS * LDR;
+  __shared__ double sA[2][2][ASZ];              // [buffer][I | J]
+  __shared__ double sX[2][2][TS * LDR];
+  __shared__ double tc[TS][TS + 1];
+  int by = 0, rem = (int)blockIdx.x;
+  while (rem >= nt - by) { rem -= nt - by; by++; }
+  const int bx = by + rem;
+  const bool diag = (by == bx);
+  const int I0 = by * TS, J0 = bx * TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  const unsigned mat_bytes = (unsigned)((size_t)D * D * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.Xm), 0, mat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.M0), 0, mat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(MID ? a.M1 : a.M0), 0, mat_bytes, 0x00020000);
+  // per-thread element of every operand tile: row-major tiles (r = (tid >> 4) + 16 q, k = tid & 15), k-major A tiles of the
+  // backward product (k = (tid >> 5) + 8 q, column i = tid & 31); byte offsets without the k-tile part, beyond the matrix when
+  // the row / column is
+  constexpr int kBeyond = 0x7ff00000;
+  const int kx = tid & 15;
+  int ox[2][2], oa[2][2];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) {
-    const double e = a.mid_ev ? 0.5 * (a.e1[r] + a.e0[r]) : a.e0[r];
-    const double rv = a.fwd ? (-s + e) : (-e + s);
-    const double k1 = (a.final >= 2) ? a.k1v[r] : 0.0;
-    const double k23 = (a.final == 3) ? a.k23v[r] : 0.0;
-    if (a.kstore == 1) a.k1v[r] = rv;
-    else if (a.kstore == 2) a.k23v[r] = rv;
-    else if (a.kstore == 3) a.k23v[r] = a.k23v[r] + rv;
-    const double jump = (a.final && a.jv) ? a.jv[r] : 0.0;
-    a.vout[r] = stage_combine(rv, a.vbase[r], k1, k23, a.final, a.cx, a.cf, sgn, jump);
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int R0 = h ? J0 : I0;
+      const int r = R0 + (tid >> 4) + 16 * q;
+      ox[h][q] = r < D ? (r * D + kx) * 8 : kBeyond;
+      if (TRANSA) { const int i = R0 + (tid & 31); oa[h][q] = i < D ? (((tid >> 5) + 8 * q) * D + i) * 8 : kBeyond; }
+      else oa[h][q] = ox[h][q];
+    }
+  // two register sets (prefetch distance two) of RAW loads: the mid-point average and the k-edge select happen when a set moves to
+  // LDS, one k-tile later -- next to the loads they would wait for them on the spot
+  struct Regs { double a[2][2], b[2][2], x[2][2]; };          // [I | J][q]
+  Regs r0, r1;
+  auto load_tiles = [&](int k0, Regs& r) {
+    // (scalar offsets: stated, or the loop's strength reduction carries them in vector registers and every load becomes a waterfall loop)
+    const int sx = __builtin_amdgcn_readfirstlane(k0 * 8), sa_ = TRANSA ? __builtin_amdgcn_readfirstlane(k0 * D * 8) : sx;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        r.x[h][q] = buf_load(rX, ox[h][q], sx);
+        r.a[h][q] = buf_load(rM0, oa[h][q], sa_);
+        if (MID) r.b[h][q] = buf_load(rM1, oa[h][q], sa_);
+      }
+  };
+  auto store_tiles = [&](int buf, int k0, const Regs& r) {
+    const bool kxok = k0 + kx < D;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double v = MID ? 0.5 * (r.a[h][q] + r.b[h][q]) : r.a[h][q];
+        sX[buf][h][((tid >> 4) + 16 * q) * LDR + (tid & 15)] = kxok ? r.x[h][q] : 0.0;
+        if (TRANSA) sA[buf][h][((tid >> 5) + 8 * q) * LDT + (tid & 31)] = v;
+        else sA[buf][h][((tid >> 4) + 16 * q) * LDR + (tid & 15)] = kxok ? v : 0.0;
+      }
+  };
+  d4 w1 = d4{0.0, 0.0, 0.0, 0.0}, w2 = d4{0.0, 0.0, 0.0, 0.0};
+  auto compute = [&](int cur) {
+    // MFMA operands: A-side lane (i = fi, k = fk), B-side lane (k = fk, j = fi)
+    const double* aI = TRANSA ? sA[cur][0] + fk * LDT + 16 * wm + fi : sA[cur][0] + (16 * wm + fi) * LDR + fk;
+    const double* aJ = TRANSA ? sA[cur][1] + fk * LDT + 16 * wn + fi : sA[cur][1] + (16 * wn + fi) * LDR + fk;
+    const double* xI = sX[cur][0] + (16 * wm + fi) * LDR + fk;
+    const double* xJ = sX[cur][1] + (16 * wn + fi) * LDR + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      const int ko = TRANSA ? kk * 4 * LDT : kk * 4;
+      const double vaI = aI[ko], vaJ = aJ[ko], vxI = xI[kk * 4], vxJ = xJ[kk * 4];
+      w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vaI, vxJ, w1, 0, 0, 0);       // (A X)[I, J]   | (A^T Psi)[I, J]
+      w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vxI, vaJ, w2, 0, 0, 0);       // (X A^T)[I, J] | (Psi A)[I, J]
+    }
+  };
+  const int nk = (D + BK - 1) / BK;
+  load_tiles(0, r0);
+  store_tiles(0, 0, r0);
+  load_tiles(BK, r1);
+  // operands of the element-wise stage: requested before the k loop, consumed behind it (C col = lane & 15, row = (lane >> 4) + 4 r).
+  // Absent operands (no mid-point partner, no jump) read a valid address and are dropped by a select: no branch around a load.
+  size_t eo[4]; bool eok[4];
+  double e0[4], e1[4], bs[4], jp[4];
+  const double* E1 = a.mid_e ? a.E1 : a.E0;
+  const double* Jp = (a.final && a.has_j) ? a.J : a.base;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; r4++) {
+    const int r = I0 + 16 * wm + (lane >> 4) + 4 * r4, j = J0 + 16 * wn + (lane & 15);
+    eok[r4] = r < D && j < D;
+    eo[r4] = (size_t)min(r, D - 1) * D + min(j, D - 1);
+    e0[r4] = a.E0[eo[r4]]; e1[r4] = E1[eo[r4]]; bs[r4] = a.base[eo[r4]]; jp[r4] = Jp[eo[r4]];
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // (loads and LDS stores of tiles beyond the last one are issued like any other -- the descriptor's range check makes them
+    //  harmless -- because a load under a branch leaves the wait counts of the two paths to be merged: the consumer of the OTHER
+    //  register set then waits for the loads just issued)
+    load_tiles((kt + 2) * BK, r0);
+    compute(0);
+    store_tiles(1, (kt + 1) * BK, r1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    load_tiles((kt + 3) * BK, r1);
+    compute(1);
+    store_tiles(0, (kt + 2) * BK, r0);
+    __syncthreads();
+  }
+
+  // the Runge-Kutta slots: written by the previous stage kernels of this step (the same thread, the same element)
+  const double sgn = a.fwd ? 1.0 : -1.0;
+  double k1[4], k23[4];
+#pragma unroll
+  for (int r4 = 0; r4 < 4; r4++) { k1[r4] = a.K1[eo[r4]]; k23[r4] = a.K23[eo[r4]]; }
+#pragma unroll
+  for (int r4 = 0; r4 < 4; r4++) {
+    const int rr = 16 * wm + (lane >> 4) + 4 * r4, cc = 16 * wn + (lane & 15);
+    const double w = w1[r4], wt = w2[r4];
+    const double e = a.mid_e ? 0.5 * (e1[r4] + e0[r4]) : e0[r4];
+    const double rv = a.fwd ? ((-w - wt) + e) : ((-e + wt) + w);
+    const double jump = (a.final && a.has_j) ? jp[r4] : 0.0;
+    const double res = stage_combine(rv, bs[r4], a.final >= 2 ? k1[r4] : 0.0, a.final == 3 ? k23[r4] : 0.0, a.final, a.cx, a.cf, sgn, jump);
+    if (eok[r4]) {
+      if (a.kstore == 1) a.K1[eo[r4]] = rv;
+      else if (a.kstore == 2) a.K23[eo[r4]] = rv;
+      else if (a.kstore == 3) a.K23[eo[r4]] = k23[r4] + rv;
+      if (!diag || rr <= cc) a.out[eo[r4]] = res;
+    }
+    tc[rr][cc] = res;
+  }
+  __syncthreads();
+  const int tx = tid & 31, ty = tid >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {                          // the mirror tile (diagonal pair: its strictly lower part)
+    const int rr = ty + 8 * q;
+    const int r2 = J0 + rr, j2 = I0 + tx;
+    if (r2 < D && j2 < D && (!diag || rr > tx)) a.out[(size_t)r2 * D + j2] = tc[tx][rr];
   }
 }
+
+static const int stage_prod_max_d = [] {
+  const char* e = getenv("VGPA_STAGE_FUSED");       // 0: the two-kernel stages at every D; <n>: one-kernel stages up to D = n
+  return e ? atoi(e) : kStageProdMaxD;
+}();
 
 static const bool stage_sym_off = [] { const char* e = getenv("VGPA_STAGE_FULL"); return e && e[0] == '1'; }();
 
@@ -728,8 +898,39 @@ struct StageSpec {
   int kstore, final_mode; double cx, cf;
 };
 
+StageArgs stage_args(int D, const Work& w, const StageSpec& s) {
+  StageArgs a{};
+  a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
+  a.sym_ok = literal_products ? 0 : 1;
+  a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
+  a.W = w.W; a.Wcol = literal_products ? w.W2 : w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
+  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
+  a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr; a.jv = s.jv; a.vbase = s.vbase;
+  a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout;
+  if (g_batch.nb > 1) {
+    a.nb = g_batch.nb;
+    a.zW = zs(a.W); a.zE = zs(a.E0); a.zJ = zs(a.J); a.zBase = zs(a.base); a.zK = zs(a.K1); a.zOut = zs(a.out);
+    a.zA = zs(a.A0); a.zX = zs(a.x); a.zEv = zs(a.e0); a.zJv = zs(a.jv); a.zVb = zs(a.vbase); a.zKv = zs(a.k1v); a.zVo = zs(a.vout);
+  }
+  return a;
+}
+
 hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, MidCache* mc = nullptr) {
   const double *ga0 = s.Am0, *ga1 = s.Am1;
+  if (!use_library_gemm && !literal_products && D <= stage_prod_max_d) {       // one kernel: products + element-wise stage
+    StageArgs a = stage_args(D, w, s);
+    a.M0 = s.Am0; a.M1 = s.Am1; a.Xm = s.X; a.zM = zs(s.Am0); a.zXm = zs(s.X);
+    const int nt = (D + TS - 1) / TS, nvec = (D + (NT / 64) - 1) / (NT / 64);
+    const dim3 grid(nt * (nt + 1) / 2 + nvec, 1, a.nb);
+    if (s.fwd) {
+      if (a.M1) hipLaunchKernelGGL((k_stage_prod<false, true>), grid, dim3(NT), 0, st, a);
+      else hipLaunchKernelGGL((k_stage_prod<false, false>), grid, dim3(NT), 0, st, a);
+    } else {
+      if (a.M1) hipLaunchKernelGGL((k_stage_prod<true, true>), grid, dim3(NT), 0, st, a);
+      else hipLaunchKernelGGL((k_stage_prod<true, false>), grid, dim3(NT), 0, st, a);
+    }
+    return hipGetLastError();
+  }
   if (ga1 && mc) {
     if (mc->a0 != ga0 || mc->a1 != ga1) {
       const size_t n = (size_t)D * D;
@@ -763,19 +964,7 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
     e = launch_gemm(!s.fwd, g2, st);
     if (e != hipSuccess) return e;
   }
-  StageArgs a{};
-  a.D = D; a.row0 = 0; a.Mp = D; a.cw = D; a.fwd = s.fwd ? 1 : 0; a.kstore = s.kstore; a.final = s.final_mode;
-  a.sym_ok = literal_products ? 0 : 1;
-  a.mid_e = s.E1 != nullptr; a.has_j = s.J != nullptr; a.cx = s.cx; a.cf = s.cf;
-  a.W = w.W; a.Wcol = literal_products ? w.W2 : w.W; a.E0 = s.E0; a.E1 = s.E1; a.J = s.J; a.base = s.base; a.K1 = w.K1; a.K23 = w.K23; a.out = s.out;
-  a.A0 = s.Av0; a.A1 = s.Av1; a.lda = D; a.mid_a = s.Av1 != nullptr; a.x = s.xv;
-  a.e0 = s.e0; a.e1 = s.e1; a.mid_ev = s.e1 != nullptr; a.jv = s.jv; a.vbase = s.vbase;
-  a.k1v = w.k1v; a.k23v = w.k23v; a.vout = s.vout;
-  if (g_batch.nb > 1) {
-    a.nb = g_batch.nb;
-    a.zW = zs(a.W); a.zE = zs(a.E0); a.zJ = zs(a.J); a.zBase = zs(a.base); a.zK = zs(a.K1); a.zOut = zs(a.out);
-    a.zA = zs(a.A0); a.zX = zs(a.x); a.zEv = zs(a.e0); a.zJv = zs(a.jv); a.zVb = zs(a.vbase); a.zKv = zs(a.k1v); a.zVo = zs(a.vout);
-  }
+  const StageArgs a = stage_args(D, w, s);
   return launch_stage(a, st);
 }
 }  // namespace
