@@ -307,6 +307,47 @@ def test_large_d_fused_sweep(d, n, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("version", ["wide", "two-kernel"])
+@pytest.mark.parametrize("d,n,method,batch", [(72, 9, "rk4", 1), (100, 7, "heun", 1), (130, 6, "rk2", 1), (96, 8, "euler", 1), (160, 6, "rk4", 1),
+                                              (96, 7, "rk4", 3)])
+def test_stage_kernel_versions_above_64(d, n, method, batch, version, monkeypatch):
+    """The three implementations of a Runge-Kutta stage above D = 64 (large_d.hip: k_stage_prod up to D = 512 by default, k_stage_wide
+    above, GEMM + k_stage_sym beyond that or on request) at the SAME small sizes -- ragged edge tiles, an odd number of diagonal
+    tiles, a batch -- against the oracle.  VGPA_STAGE_FUSED / VGPA_STAGE_WIDE are read per call."""
+    from test_gpu_edge_cases import make_problem, gpu_context
+    monkeypatch.setenv("VGPA_STAGE_FUSED", "0")
+    if version == "two-kernel":
+        monkeypatch.setenv("VGPA_STAGE_WIDE", "0")
+    p, x = make_problem("L96", d, n, method=method)
+    ctx = gpu_context(p, batch=batch)
+    rng = np.random.default_rng(5)
+    xs = np.stack([x + 0.01 * rng.standard_normal(x.size) for _ in range(batch)])
+    f, g = ctx.sweep(xs if batch > 1 else xs[0])
+    f, g = np.atleast_1d(f), np.asarray(g).reshape(batch, -1)
+    for q in range(batch):
+        f_ref, g_ref, st = vo.sweep(p, xs[q], faithful=False)
+        assert abs(f[q] - f_ref) <= TOL * abs(f_ref), (q, f[q], f_ref)
+        assert rel_err(g[q], g_ref) < TOL, q
+    for key in ("mt", "st", "lamt", "psit"):
+        got = np.asarray(ctx.fetch(key))
+        got = got[batch - 1] if batch > 1 else got
+        assert rel_err(got.reshape(np.shape(st[key])), st[key]) < TOL, key
+    s_t = np.asarray(ctx.fetch("st"))
+    s_t = s_t[0] if batch > 1 else s_t
+    assert np.array_equal(s_t, np.swapaxes(s_t, -1, -2))          # exactly symmetric S_t (pairs and diagonal tiles alike)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,method", [(544, 4, "rk4"), (530, 4, "heun"), (578, 4, "rk2")])
+def test_throughput_stage_kernel_above_512(d, n, method):
+    """k_stage_wide at its own sizes: 17 tiles (an odd number of diagonal tiles), ragged edge tiles (530 = 16 x 32 + 18)."""
+    from test_gpu_edge_cases import make_problem, check
+    p, x = make_problem("L96", d, n, method=method)
+    check(p, x)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("d,n,method,batch", [(72, 9, "rk4", 1), (128, 7, "heun", 1), (96, 8, "rk2", 1), (80, 11, "euler", 1), (96, 9, "rk4", 3)])
 def test_repeated_sweeps_on_one_context_above_64(d, n, method, batch):
     """An optimiser's use of a context above D = 64: sweep after sweep on the same device buffers, every one on another

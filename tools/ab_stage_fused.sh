@@ -1,9 +1,8 @@
-set -e
-python -m pytest tests/test_large_d.py tests/test_gpu_edge_cases.py -q -m gpu -x 2>&1 | tail -3
-for mode in 0 512; do
-  for cfg in "96 401 1" "128 401 1" "256 401 1" "512 201 1" "128 401 8" "1024 41 1"; do
-    echo "VGPA_STAGE_FUSED=$mode $cfg"
-    VGPA_STAGE_FUSED=$mode python tools/bench_large_d_sweep.py $cfg
-  done
+# A/B of the stage implementations above D = 64 (large_d.hip) on one box: the fused sweep per size and version.
+run() { echo "FUSED=$1 WIDE=$2 : $3"; VGPA_STAGE_FUSED=$1 VGPA_STAGE_WIDE=$2 python tools/bench_large_d_sweep.py $3; }
+for cfg in "72 401 1" "96 401 1" "128 401 1" "200 401 1" "256 401 1" "384 201 1" "512 201 1" "128 401 8"; do
+  run 0 0 "$cfg"; run 4096 0 "$cfg"; run 0 4096 "$cfg"
 done
-VGPA_STAGE_FUSED=1024 python tools/bench_large_d_sweep.py 1024 41 1
+for cfg in "640 101 1" "768 101 1" "1000 81 1" "1024 81 1" "1536 41 1" "2048 21 1"; do
+  run 0 0 "$cfg"; run 4096 0 "$cfg"; run 0 4096 "$cfg"
+done
