@@ -658,6 +658,12 @@ __global__ void __launch_bounds__(NT) k_stage_sym(StageArgs a) {
 // Four launches per RK4 step instead of nine; every tile product is still computed exactly once per stage.
 // By symmetry of X every operand tile is a set of ROW segments: forward all four tiles are [32 rows][16 k] (rows I / J of A
 // and of X); backward the A tiles are [16 k][32 columns I / J] and the Psi tiles [32 rows][16 k].
+// register sets of operand loads in flight in k_stage_prod (fused sweep, same box, 2 / 4 / 6 sets: D = 72 26.5 / 31.5 / 29.4 ms,
+// 128 31.2 / 32.3 / 40.9, 200 45.9 / 50.4 / 55.4, 256 50.7 / 51.2 / 56.1: the tiles a deeper pipeline multiplies beyond the last one
+// cost more than its depth hides)
+#ifndef VGPA_PROD_PF
+#define VGPA_PROD_PF 2
+#endif
 constexpr int kStageProdMaxD = 512;
 constexpr int kStageProdMaxPairs = 64;
 constexpr int kStageWideMaxD = 1536;
@@ -720,7 +726,8 @@ __global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
   // two register sets (prefetch distance two) of RAW loads: the mid-point average and the k-edge select happen when a set moves to
   // LDS, one k-tile later -- next to the loads they would wait for them on the spot
   struct Regs { double a[2][2], b[2][2], x[2][2]; };          // [I | J][q]
-  Regs r0, r1;
+  constexpr int PF = VGPA_PROD_PF;
+  Regs rs[PF];
   auto load_tiles = [&](Regs& r) {            // the NEXT k-tile (tiles are requested in order)
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -760,9 +767,9 @@ __global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
     }
   };
   const int nk = (D + BK - 1) / BK;
-  load_tiles(r0);
-  store_tiles(0, 0, r0);
-  load_tiles(r1);
+#pragma unroll
+  for (int u = 0; u < PF; u++) load_tiles(rs[u]);              // tiles 0 .. PF - 1
+  store_tiles(0, 0, rs[0]);
   // operands of the element-wise stage: requested before the k loop, consumed behind it (C col = lane & 15, row = (lane >> 4) + 4 r).
   // Absent operands (no mid-point partner, no jump) read a valid address and are dropped by a select: no branch around a load.
   size_t eo[4]; bool eok[4];
@@ -777,19 +784,20 @@ __global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
     e0[r4] = a.E0[eo[r4]]; e1[r4] = E1[eo[r4]]; bs[r4] = a.base[eo[r4]]; jp[r4] = Jp[eo[r4]];
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    // (loads and LDS stores of tiles beyond the last one are issued like any other -- the descriptor's range check makes them
-    //  harmless -- because a load under a branch leaves the wait counts of the two paths to be merged: the consumer of the OTHER
-    //  register set then waits for the loads just issued)
-    load_tiles(r0);
-    compute(0);
-    store_tiles(1, (kt + 1) * BK, r1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    load_tiles(r1);
-    compute(1);
-    store_tiles(0, (kt + 2) * BK, r0);
-    __syncthreads();
+  static_assert(PF % 2 == 0, "LDS buffer parity is static in the unrolled loop");
+  // step kt: the register set that held tile kt (in LDS since the previous step) takes tile kt + PF; tile kt is multiplied; tile
+  // kt + 1 moves to the other LDS buffer.  No branch inside: loads, LDS stores and products of tiles beyond the last one (up to
+  // PF - 1 of them) are issued like any other -- they are zeros (range check, k-edge select) -- because a load under a branch, or
+  // an exit from the unrolled body, leaves the wait counts of the paths to be merged to the most conservative one: the LDS store
+  // of one register set then waits for the loads just issued into another.
+  for (int kt = 0; kt < nk; kt += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      load_tiles(rs[u]);
+      compute(u & 1);
+      store_tiles((u + 1) & 1, (kt + u + 1) * BK, rs[(u + 1) % PF]);
+      __syncthreads();
+    }
   }
 
   // the Runge-Kutta slots: written by the previous stage kernels of this step (the same thread, the same element)
