@@ -61,6 +61,10 @@ extern "C" {
    VGPA_DS_PACKED=0           ... dEsde_dS as upper triangles of whole matrices (default: packed lower triangles)
    VGPA_SHARD_CHUNKS=<n>      row-sharded recursion: sub-blocks of the pipelined gather (default 4; 0 = the serial schedule);
                               per shard: vgpa_shard_set_option
+   VGPA_STAGE_FUSED=<n>       D > 64, one GPU: the latency version of the one-kernel Runge-Kutta stage up to D = n (0: never; default 512, and
+                              only while a launch has at most 64 tile pairs)
+   VGPA_STAGE_WIDE=<n>        ... the throughput version up to D = n (0: never; default 1536, not at D = 1024); with both 0: GEMM + stage
+                              kernel as in rounds 1-4.  Read per call (tests run all three at one size)
    VGPA_STAGE_FULL=1          D > 64: the stage kernel over whole tiles instead of symmetric tile pairs
    VGPA_GEMM_SCALAR_LOADS=1   D > 64: the 8-byte-load GEMM kernels also for full tiles
    VGPA_DIAG_REPEAT=<phase>:<n>  launch one phase (fwd|energy|bwd|grad) of the fused sweep n times (clock / power samples under one
