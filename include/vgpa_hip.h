@@ -63,10 +63,12 @@ extern "C" {
                               per shard: vgpa_shard_set_option
    VGPA_STAGE_FUSED=<n>       D > 64, one GPU: the latency version of the one-kernel Runge-Kutta stage up to D = n (0: never; default 512, and
                               only while a launch has at most 64 tile pairs)
-   VGPA_STAGE_WIDE=<n>        ... the throughput version up to D = n (0: never; default 1536, not at D = 1024); with both 0: GEMM + stage
+   VGPA_STAGE_WIDE=<n>        ... the throughput version up to D = n (0: never; default 2048, and not where D >= 384 is a multiple of 64); with both 0: GEMM + stage
                               kernel as in rounds 1-4.  Read per call (tests run all three at one size)
    VGPA_STAGE_FULL=1          D > 64: the stage kernel over whole tiles instead of symmetric tile pairs
    VGPA_GEMM_SCALAR_LOADS=1   D > 64: the 8-byte-load GEMM kernels also for full tiles
+   VGPA_GEMM_PF=0             D > 64: the two-register-set loop of the stage products (default: four sets, no load under a branch)
+   VGPA_GEMM_BM=32|64|128     D > 64: rows of the product's block tile (default: by the number of workgroups)
    VGPA_DIAG_REPEAT=<phase>:<n>  launch one phase (fwd|energy|bwd|grad) of the fused sweep n times (clock / power samples under one
                               kernel, tools/power_per_kernel.sh); every phase is a pure function of its inputs
    Only in builds with -DVGPA_EXPERIMENTS (vgpa_abi_version() carries VGPA_ABI_DIAGNOSTIC_BUILD; never the product build):

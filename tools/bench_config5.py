@@ -141,7 +141,8 @@ def fused_sweep(args, rec, a, b, m0, gen, rank, world, dev):
         f, ga, gb = once()
     barrier()
     elapsed = par.max_over_ranks((time.perf_counter() - t0) / args.reps, device="cuda")
-    chk = torch.tensor([float(ga.abs().sum()), float(gb.abs().sum())], **f64)
+    ga_t, gb_t = (torch.as_tensor(v, device=dev) for v in (ga, gb))      # (DeviceArray: __cuda_array_interface__, no copy)
+    chk = torch.tensor([float(ga_t.abs().sum()), float(gb_t.abs().sum())], **f64)
     if world > 1:
         dist.all_reduce(chk)
     if rank == 0:

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(NT) k_gemm(GemmArgs g) {
 //                             18 i (mod 32) runs over the even residues and the two k of a 32-lane group fill the odd ones
 //   TN (A stored  [k][i]):    As[k][BM + 16] as in k_gemm (k-major), b128 stores of 16 consecutive pairs
 //   B  (row-major [k][j]):    Bs[k][LDBS], b128 stores
-template <bool TRANSA, bool MID, int BM, bool SEG = false>
+template <bool TRANSA, bool MID, int BM, bool SEG = false, int PFU = 0>
 __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   if (g.nb > 1) { const size_t z = blockIdx.z; g.A0 += z * g.zA; if (MID) g.A1 += z * g.zA; g.B += z * g.zB; g.C += z * g.zC; }
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -276,21 +276,24 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   int seg_cnt = 0;
 
   d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
+  int advances = g.K / BK - 1;                            // (PFU: loads are unconditional; behind the last tile the pointers stay)
   auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {      // loads the NEXT k-tile (tiles are requested in order)
+    const size_t as_ = (PFU > 0 && advances <= 0) ? 0 : astep, bs_ = (PFU > 0 && advances <= 0) ? 0 : bstep;
+    if (PFU > 0) advances--;
 #pragma unroll
     for (int q = 0; q < AV; q++) {
       const d2 v0 = *reinterpret_cast<const d2*>(pA[q]);
-      pA[q] += astep;
+      pA[q] += as_;
       if (MID) {
         const d2 v1 = *reinterpret_cast<const d2*>(pA1[q]);
-        pA1[q] += astep;
+        pA1[q] += as_;
         ra[q] = d2{0.5 * (v0[0] + v1[0]), 0.5 * (v0[1] + v1[1])};
       } else {
         ra[q] = v0;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bstep; }
+    for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bs_; }
     if (SEG) {
       if (++seg_cnt == g.seg_tiles) {
         seg_cnt = 0;
@@ -348,7 +351,25 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
     }
   };
-  if constexpr (BM < 128) {
+  if constexpr (PFU > 0) {
+    // PFU register sets, no load or LDS store under a branch (K / BK a multiple of PFU): a branch makes the wait counts of its two
+    // paths merge to the conservative one -- the LDS stores of one set then wait for the loads just issued into another
+    static_assert(PFU % 2 == 0 && !SEG && !MID, "");
+    d2 sa_[PFU][AV], sb_[PFU][2];
+#pragma unroll
+    for (int u = 0; u < PFU; u++) load_tiles(sa_[u], sb_[u]);
+    store_tiles(0, sa_[0], sb_[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += PFU) {
+#pragma unroll
+      for (int u = 0; u < PFU; u++) {
+        load_tiles(sa_[u], sb_[u]);
+        compute(u & 1);
+        store_tiles((u + 1) & 1, sa_[(u + 1) % PFU], sb_[(u + 1) % PFU]);
+        __syncthreads();
+      }
+    }
+  } else if constexpr (BM < 128) {
     load_tiles(ra0, rb0);
     store_tiles(0, ra0, rb0);
     if (nk > 1) load_tiles(ra1, rb1);
@@ -541,6 +562,15 @@ template <int BM>
 static void launch_gemm_bm_v(bool transa, const GemmArgs& g, hipStream_t st) {
   dim3 grid(g.N / BN, g.M / BM, g.nb);
   const bool mid = g.A1 != nullptr;
+  // four register sets of loads in flight and no load under a branch (k_gemm_v, PFU) when the k-tile count allows it: D = 1024
+  // 44.6 -> 39.6 us per product (47 -> 54 TFLOP/s; 2 sets 44.1, 8 sets 40.1), D = 2048 forward recursion 44.0 -> 47.7 TFLOP/s;
+  // VGPA_GEMM_PF=0: the two-set loop of rounds 2-4
+  static const bool pfu = [] { const char* e = getenv("VGPA_GEMM_PF"); return !(e && e[0] == '0'); }();
+  if (!mid && pfu && (g.K / BK) % 4 == 0) {
+    if (transa) hipLaunchKernelGGL((k_gemm_v<true, false, BM, false, 4>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_v<false, false, BM, false, 4>), grid, dim3(NT), 0, st, g);
+    return;
+  }
   if (transa) {
     if (mid) hipLaunchKernelGGL((k_gemm_v<true, true, BM>), grid, dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((k_gemm_v<true, false, BM>), grid, dim3(NT), 0, st, g);
@@ -573,8 +603,9 @@ hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
   // 128-row tiles reuse B twice as much; fall back to 64-row tiles when they would leave CUs without a workgroup
   const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128) * g.nb;
   const long long wg64 = (long long)((g.N + BN - 1) / BN) * ((g.M + 63) / 64) * g.nb;
-  if (wg128 >= 2 * 256) launch_gemm_bm<128>(transa, g, st);
-  else if (wg64 >= 2 * 256) launch_gemm_bm<64>(transa, g, st);
+  static const int force_bm = [] { const char* e = getenv("VGPA_GEMM_BM"); return e ? atoi(e) : 0; }();     // (diagnostic: 32 / 64 / 128)
+  if (force_bm == 128 || (!force_bm && wg128 >= 2 * 256)) launch_gemm_bm<128>(transa, g, st);
+  else if (force_bm == 64 || (!force_bm && wg64 >= 2 * 256)) launch_gemm_bm<64>(transa, g, st);
   else launch_gemm_bm<32>(transa, g, st);      // D = 1024: 512 workgroups, two per CU hide each other's k-tile latency
   return hipGetLastError();
 }
@@ -666,8 +697,8 @@ __global__ void __launch_bounds__(NT) k_stage_sym(StageArgs a) {
 #endif
 constexpr int kStageProdMaxD = 512;
 constexpr int kStageProdMaxPairs = 64;
-constexpr int kStageWideMaxD = 1536;
-constexpr int kStageWideSkipD = 1024;
+constexpr int kStageWideMaxD = 2048;
+constexpr int kStageWideFullTileD = 384;
 // Operand tiles come through buffer descriptors (raw_buffer_load: a per-thread 32-bit offset, advanced by one k-tile after every
 // load): no 64-bit address arithmetic per tile -- with addresses recomputed per tile the register allocator recycles the destination
 // registers of the loads in flight for them and every prefetch waits for the previous one (seen in the ISA of the first version of
@@ -840,12 +871,12 @@ __global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
 //   * 16-byte loads and LDS stores (one per thread and operand tile), the mid-point operand formed once per step by k_mid;
 //   * the element-wise operands are read behind the k loop (37 / 43 KB of LDS -- the transposition buffers alias the operand
 //     tiles -- three workgroups per CU).
-// Where the time goes at D = 1024 (profiles/r05_stage_{two-kernel,wide}_D1024_kernel_stats.csv): 58-60 us per launch against 45 + 12 us of GEMM + k_stage_sym
-// (+ 3 us more of launch gaps for those): the k loop takes ~50 us, 64 k-tiles of 8 MFMAs per wave at two waves per SIMD = 27 us of
-// MFMA time at 2.4 GHz -- at THIS size (512 workgroups, two per CU, one round) neither prefetch depth (2 / 4 / 6 register sets),
-// nor the order of LDS stores and products, nor the XCD-aware tile order moved it by more than 1 %; per-k-tile barriers with two
-// waves per SIMD leave the MFMA pipe idle about as long as in the GEMM (0.70 us per k-tile there, 0.78 here with 16 instead of
-// 12 fragment reads per 8 MFMAs).  Away from it both levers pay (below).
+// Where the time goes at D = 1024 (profiles/r05b_stage_{two-kernel,wide}_D1024_*.csv): 60 / 57 us per launch (forward / backward)
+// against 40 + 12 us of GEMM + k_stage_sym (+ 3 us more of launch gaps for those): the k loop takes ~50 us, 64 k-tiles of 8 MFMAs
+// per wave at two waves per SIMD = 27 us of MFMA time at 2.4 GHz, matrix pipe busy 0.52 / 0.55 of the SIMD-cycles (GEMM: 0.76) --
+// 16 instead of 12 fragment reads per 8 MFMAs, four instead of three 16-byte loads and LDS stores per k-tile.  At THIS size (512
+// workgroups, two per CU, one round) neither prefetch depth (2 / 4 / 6 register sets), nor the order of LDS stores and products,
+// nor the XCD-aware tile order moved it by more than 1 %; away from it the latter two pay (below).
 #ifndef VGPA_WIDE_PF
 #define VGPA_WIDE_PF 4
 #endif
@@ -1200,15 +1231,17 @@ StageArgs stage_args(int D, const Work& w, const StageSpec& s) {
 
 hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, MidCache* mc = nullptr) {
   const double *ga0 = s.Am0, *ga1 = s.Am1;
-  // Which implementation of the stage (measured on one box, fused sweep, ms: two kernels / k_stage_prod / k_stage_wide --
-  // D = 72: 40.8 / 24.9 / 38.5; 128: 41.6 / 31.3 / 36.8; 256: 58.5 / 51.2 / 51.6; 384: 38.6 / 36.2 / 35.0; 512: 48.9 / 47.3 / 44.9;
-  // 8 x D = 128: 58.4 / 54.4 / 51.6; 768: 43.1 / 47.0 / 42.3; 1000: 61.6 / 78.6 / 53.7; 1024: 50.7 / 76.7 / 51.7; 1536: 77.8 / 93.2 /
-  // 73.6; 2048: 78.7 / 113.6 / 81.3): the latency version while the launch has at most kStageProdMaxPairs tile pairs (a quarter of
-  // the CUs), the throughput version from there up to D = 1536 -- not at D = 1024 itself, where the GEMM's full-tile path and two
-  // workgroups per CU are at par with it -- and the two-kernel stage beyond.
+  // Which implementation of the stage (measured on one box, fused sweep, ms: two kernels / k_stage_prod / k_stage_wide,
+  // profiles/r05b_stage_versions_ab.txt -- D = 72: 40.7 / 26.5 / 39.0; 128: 41.2 / 31.0 / 37.3; 200: 63.6 / 46.0 / 54.2; 256: 54.2 / 50.6 /
+  // 52.3; 384: 35.1 / 35.5 / 35.3; 512: 44.2 / 46.5 / 45.2; 8 x D = 128: 56.9 / 53.9 / 52.2; 640: 26.4 / 29.3 / 28.7; 768: 39.8 / 46.5 /
+  // 42.6; 1000: 61.4 / 74.1 / 53.9; 1024: 47.1 / 70.6 / 51.9; 1536: 74.7 / 91.5 / 73.5; 2048: 74.2 / 112.9 / 82.7): the latency version
+  // while the launch has at most kStageProdMaxPairs tile pairs (a quarter of the CUs); beyond that the two-kernel stage where the
+  // product runs on its full-tile path (D a multiple of 64: 16-byte loads, four register sets) and D >= 384, the throughput version
+  // for everything else that is eligible -- ragged D, whose product is the bounds-checked 8-byte kernel, and batched contexts of
+  // mid-size problems.
   const bool fused_ok = !use_library_gemm && !literal_products;
   const int nt_ = (D + TS - 1) / TS;
-  const bool wide = fused_ok && D % 2 == 0 && D <= stage_wide_max_d() && (D != kStageWideSkipD || getenv("VGPA_STAGE_WIDE")) && (size_t)D * D * 8 < 0x7ff00000u &&
+  const bool wide = fused_ok && D % 2 == 0 && D <= stage_wide_max_d() && (D % 64 != 0 || D < kStageWideFullTileD || getenv("VGPA_STAGE_WIDE")) && (size_t)D * D * 8 < 0x7ff00000u &&
                     (reinterpret_cast<uintptr_t>(s.X) & 15u) == 0 && (reinterpret_cast<uintptr_t>(s.Am0) & 15u) == 0 &&
                     (!s.Am1 || (reinterpret_cast<uintptr_t>(s.Am1) & 15u) == 0) && zs(s.X) % 2 == 0 && zs(s.Am0) % 2 == 0;
   if (fused_ok && D <= stage_prod_max_d() && ((long long)nt_ * (nt_ + 1) / 2 * g_batch.nb <= kStageProdMaxPairs || !wide)) {
