@@ -1244,7 +1244,8 @@ hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, M
   const bool wide = fused_ok && D % 2 == 0 && D <= stage_wide_max_d() && (D % 64 != 0 || D < kStageWideFullTileD || getenv("VGPA_STAGE_WIDE")) && (size_t)D * D * 8 < 0x7ff00000u &&
                     (reinterpret_cast<uintptr_t>(s.X) & 15u) == 0 && (reinterpret_cast<uintptr_t>(s.Am0) & 15u) == 0 &&
                     (!s.Am1 || (reinterpret_cast<uintptr_t>(s.Am1) & 15u) == 0) && zs(s.X) % 2 == 0 && zs(s.Am0) % 2 == 0;
-  if (fused_ok && D <= stage_prod_max_d() && ((long long)nt_ * (nt_ + 1) / 2 * g_batch.nb <= kStageProdMaxPairs || !wide)) {
+  // (more pairs than that and no throughput version -- odd D: the latency version still beats the bounds-checked product)
+  if (fused_ok && D <= stage_prod_max_d() && ((long long)nt_ * (nt_ + 1) / 2 * g_batch.nb <= kStageProdMaxPairs || (!wide && D % 64 != 0))) {
     StageArgs a = stage_args(D, w, s);
     a.M0 = s.Am0; a.M1 = s.Am1; a.Xm = s.X; a.zM = zs(s.Am0); a.zXm = zs(s.X);
     const int nvec = (D + (NT / 64) - 1) / (NT / 64);
