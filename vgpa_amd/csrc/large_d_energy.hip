@@ -180,18 +180,25 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
     sb[q] = k * LDBS + 2 * j2;
   }
   const long long astep = TA ? (long long)BK * g.lda : (long long)BK, bstep = (long long)BK * g.ldb;
-  d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
-  auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {       // loads the NEXT k-tile
+  // PF register sets of loads in flight, none under a branch (ld::k_gemm_v: a branch makes the wait counts of its two paths merge
+  // to the conservative one -- the LDS stores of one set then wait for the loads just issued into another); behind the last tile of
+  // this workgroup's k range the pointers stay (the surplus loads re-read that tile and are never multiplied)
+  constexpr int PF = 4;
+  d2 ra[PF][AV], rb[PF][2];
+  int advances = 0;
+  auto load_tiles = [&](d2 (&xa)[AV], d2 (&xb)[2]) {       // loads the NEXT k-tile
+    const long long as_ = advances > 0 ? astep : 0, bs_ = advances > 0 ? bstep : 0;
+    advances--;
 #pragma unroll
-    for (int q = 0; q < AV; q++) { ra[q] = *reinterpret_cast<const d2*>(pA[q]); pA[q] += astep; }
+    for (int q = 0; q < AV; q++) { xa[q] = *reinterpret_cast<const d2*>(pA[q]); pA[q] += as_; }
 #pragma unroll
-    for (int q = 0; q < 2; q++) { rb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bstep; }
+    for (int q = 0; q < 2; q++) { xb[q] = *reinterpret_cast<const d2*>(pB[q]); pB[q] += bs_; }
   };
-  auto store_tiles = [&](int buf, const d2 (&ra)[AV], const d2 (&rb)[2]) {
+  auto store_tiles = [&](int buf, const d2 (&xa)[AV], const d2 (&xb)[2]) {
 #pragma unroll
-    for (int q = 0; q < AV; q++) *reinterpret_cast<d2*>(&As[buf][sa[q]]) = ra[q];
+    for (int q = 0; q < AV; q++) *reinterpret_cast<d2*>(&As[buf][sa[q]]) = xa[q];
 #pragma unroll
-    for (int q = 0; q < 2; q++) *reinterpret_cast<d2*>(&Bs[buf][sb[q]]) = rb[q];
+    for (int q = 0; q < 2; q++) *reinterpret_cast<d2*>(&Bs[buf][sb[q]]) = xb[q];
   };
   d4 acc[MT][2];
 #pragma unroll
@@ -199,8 +206,10 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
   auto compute = [&](int cur) {
-    const double* as = TA ? As[cur] + fk * LDT + (BM / 2) * wm + fi : As[cur] + ((BM / 2) * wm + fi) * LDK + fk;
-    const double* bs = Bs[cur] + fk * LDBS + 32 * wn + fi;
+    // (volatile, address space stated: plain ds_read_b64 -- 2 LDS cycles, 64 banks -- instead of the compiler's ds_read2_b64 pairs, see large_d.hip)
+    typedef const volatile double __attribute__((address_space(3)))* frag_ptr;
+    frag_ptr as = (frag_ptr)(TA ? As[cur] + fk * LDT + (BM / 2) * wm + fi : As[cur] + ((BM / 2) * wm + fi) * LDK + fk);
+    frag_ptr bs = (frag_ptr)(Bs[cur] + fk * LDBS + 32 * wn + fi);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
       double af[MT], bf[2];
@@ -224,22 +233,31 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   for (int q = 0; q < AV; q++) pA[q] += (long long)kt0 * astep;
 #pragma unroll
   for (int q = 0; q < 2; q++) pB[q] += (long long)kt0 * bstep;
-  if (kt0 < nk) {
-    load_tiles(ra0, rb0);
-    store_tiles(0, ra0, rb0);
-    if (kt0 + 1 < nk) load_tiles(ra1, rb1);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_tiles(ra0, rb0);
-    compute(0);
-    if (kt + 1 < nk) store_tiles(1, ra1, rb1);
+  const int ntile = nk - kt0;                              // k-tiles of this workgroup (k_tri: its triangular operand starts later)
+  if (ntile > 0) {
+    static_assert(PF % 2 == 0, "LDS buffer parity is static in the unrolled loop");
+    advances = ntile - 1;
+#pragma unroll
+    for (int u = 0; u < PF; u++) load_tiles(ra[u], rb[u]);
+    store_tiles(0, ra[0], rb[0]);
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_tiles(ra1, rb1);
-    compute(1);
-    if (kt + 2 < nk) store_tiles(0, ra0, rb0);
-    __syncthreads();
+    const int main_tiles = ntile / PF * PF;
+    for (int t = 0; t < main_tiles; t += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        load_tiles(ra[u], rb[u]);
+        compute(u & 1);
+        store_tiles((u + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF - 1; u++) {                     // the last ntile % PF tiles: already in the register sets
+      if (main_tiles + u >= ntile) break;
+      compute(u & 1);
+      store_tiles((u + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
