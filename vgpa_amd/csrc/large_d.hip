@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   d2 ra0[AV], rb0[2], ra1[AV], rb1[2];
   int advances = g.K / BK - 1;                            // (PFU: loads are unconditional; behind the last tile the pointers stay)
   auto load_tiles = [&](d2 (&ra)[AV], d2 (&rb)[2]) {      // loads the NEXT k-tile (tiles are requested in order)
-    const size_t as_ = (PFU > 0 && advances <= 0) ? 0 : astep, bs_ = (PFU > 0 && advances <= 0) ? 0 : bstep;
+    const bool adv = !(PFU > 0 && advances <= 0);
+    const size_t as_ = adv ? astep : 0, bs_ = adv ? bstep : 0;
     if (PFU > 0) advances--;
 #pragma unroll
     for (int q = 0; q < AV; q++) {
@@ -297,10 +298,11 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
     if (SEG) {
       if (++seg_cnt == g.seg_tiles) {
         seg_cnt = 0;
+        const size_t ak = adv ? askip : 0, bk = adv ? bskip : 0;
 #pragma unroll
-        for (int q = 0; q < AV; q++) { pA[q] += askip; if (MID) pA1[q] += askip; }
+        for (int q = 0; q < AV; q++) { pA[q] += ak; if (MID) pA1[q] += ak; }
 #pragma unroll
-        for (int q = 0; q < 2; q++) pB[q] += bskip;
+        for (int q = 0; q < 2; q++) pB[q] += bk;
       }
     }
   };
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(NT) k_gemm_v(GemmArgs g) {
   if constexpr (PFU > 0) {
     // PFU register sets, no load or LDS store under a branch (K / BK a multiple of PFU): a branch makes the wait counts of its two
     // paths merge to the conservative one -- the LDS stores of one set then wait for the loads just issued into another
-    static_assert(PFU % 2 == 0 && !SEG && !MID, "");
+    static_assert(PFU % 2 == 0 && !MID, "");
     d2 sa_[PFU][AV], sb_[PFU][2];
 #pragma unroll
     for (int u = 0; u < PFU; u++) load_tiles(sa_[u], sb_[u]);
@@ -590,6 +592,12 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
     GemmArgs h = g;
     if (!h.seg_tiles) { h.seg_tiles = h.K / BK; h.seg_stride = h.K; }
     dim3 grid(g.N / BN, g.M / BM, g.nb);
+    static const bool pfu = [] { const char* e = getenv("VGPA_GEMM_PF"); return !(e && e[0] == '0'); }();
+    if (pfu && (h.K / BK) % 4 == 0) {        // four register sets of loads in flight (launch_gemm_bm_v)
+      if (transa) hipLaunchKernelGGL((k_gemm_v<true, false, BM, true, 4>), grid, dim3(NT), 0, st, h);
+      else hipLaunchKernelGGL((k_gemm_v<false, false, BM, true, 4>), grid, dim3(NT), 0, st, h);
+      return;
+    }
     if (transa) hipLaunchKernelGGL((k_gemm_v<true, false, BM, true>), grid, dim3(NT), 0, st, h);
     else hipLaunchKernelGGL((k_gemm_v<false, false, BM, true>), grid, dim3(NT), 0, st, h);
     return;
