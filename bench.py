@@ -16,6 +16,8 @@ launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script starts its N 
 process, before this process has made any GPU call -- and exits with the child's code; a WORLD_SIZE that disagrees with --gpus is
 an error, never a silent one-GPU run.
 
+Secondary block `config4` (rank 0; --no-config4 skips it): BASELINE configs[3]'s matrix size -- ONE Lorenz-96 problem, D = 1024, RK4, the
+resident fused sweep on a 33-point grid, checked against the committed oracle anchors of that size.
 Secondary block `config5` (every N; --no-config5 skips it): BASELINE configs[4]'s matrix size -- ONE Lorenz-96 problem, D = 4096,
 RK4, short grid -- through vgpa_shard_sweep_sharded: S_t / Psi_t row-sharded over the N ranks with RCCL collectives per RK stage,
 energy / gradient phases time-parallel, x and the gradient memory-sharded.  The problem is fixed, so the per-N values of
@@ -63,6 +65,7 @@ def parse():
     ap.add_argument("--config5-dim", type=int, default=4096)
     ap.add_argument("--config5-timeout", type=float, default=300.0, help="N > 1: seconds the config-5 child processes may take")
     ap.add_argument("--config5-child", action="store_true", help=argparse.SUPPRESS)     # internal: see config5_children
+    ap.add_argument("--no-config4", action="store_true", help="skip the secondary D = 1024 block (BASELINE configs[3]'s matrix size on a short grid)")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary Lorenz-63 block (BASELINE configs[1], the HBM-bound small-D path)")
     ap.add_argument("--config2-batch", type=int, default=65536, help="independent Lorenz-63 problems of the config-2 block: 1024 waves of 64 -- "
                     "one per SIMD, what the lane kernels' registers admit (any multiple fills the chip evenly)")
@@ -221,6 +224,54 @@ def config2_block(args, local_rank):
                 "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "sweeps/s", "cores": 1, "kind": "port", "seconds": t_cpu,
                                  "sample": "one full sweep of problem 0, numpy oracle", "gpu_vs_cpu_F_rel_err": abs(f[0] - f_cpu) / abs(f_cpu)},
                 "parity_check_rel_err_F": err_f, "parity_check_rel_err_grad_norm": err_g,
+                "parity_ok": bool(max(err_f, err_g) < 1e-9)}
+    except Exception as exc:                                 # noqa: BLE001 - the headline line must still be printed
+        return {"error": repr(exc)}
+
+
+def config4_block(args, local_rank):
+    """BASELINE configs[3]'s matrix size: ONE Lorenz-96 problem, D = 1024, RK4, on a grid of 33 points (the full grid, Np = 10 001,
+    is 252 GB resident and 6 s per sweep: tools/bench_config4.py, profiles/*config4_D1024_Np10001.json) -- the resident fused sweep
+    through the per-stage kernels of large_d.hip (fp64-MFMA stage products + the element-wise stage), inputs resident in HBM.
+    The inputs are the seeded ones of tests/golden/anchors_d1024_np33.json (tools/gen_d4096_anchor.inputs_grid): F and per-grid-
+    point gradient norms must reproduce those oracle anchors.  Roofline: fp64 matrix pipe, nominal 2 x 4 x 2 D^3 flop per step of
+    the two recursions.  Never raises."""
+    try:
+        import vgpa_amd as va
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from gen_d4096_anchor import inputs_grid
+        a = json.load(open(os.path.join(ROOT, "tests", "golden", "anchors_d1024_np33.json")))
+        d, n = a["D"], a["Np"]
+        x, m0, s0, sig, obs_t, obs_y, rdiag = inputs_grid(d, n)
+        ctx = va.Context("L96", a["method"], d, n, a["dt"], sigma=np.diag(sig), theta=[8.0], m0=m0, s0=s0, obs_t=obs_t, obs_y=obs_y,
+                         obs_noise=np.diag(rdiag), e0=0.0, device=local_rank)
+        x_dev, g_dev = ctx.alloc(x.size), ctx.alloc(x.size)
+        x_dev.upload(x)
+        ctx.sweep_dev(x_dev, g_dev)
+        reps = 4
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f = ctx.sweep_dev(x_dev, g_dev)
+        secs = (time.perf_counter() - t0) / reps
+        pr = ctx.profile_end()
+        f = float(np.atleast_1d(f)[0])
+        g = g_dev.download_at(0, x.size)
+        ga = g[:n * d * d].reshape(n, d, d)
+        err_f = abs(f - a["F_minus_E0"]) / abs(a["F_minus_E0"])
+        err_g = max(abs(float(np.linalg.norm(ga[t])) - a["grad_a_fro"][t]) / a["grad_a_fro"][t] for t in range(n))
+        ctx.close()
+        flop_rec = (n - 1) * 4 * 2.0 * d ** 3
+        fwd_s, bwd_s = pr["fwd_ms"] / reps * 1e-3, pr["bwd_ms"] / reps * 1e-3
+        return {"workload": f"Lorenz96 D={d}, RK4, Np={n}: ONE problem, resident fused sweep (BASELINE configs[3]'s matrix size; the full "
+                            "grid: tools/bench_config4.py)",
+                "ms_per_sweep": 1e3 * secs, "sweeps_per_s": 1.0 / secs,
+                "phase_ms": {"fwd": 1e3 * fwd_s, "energy+obs": pr["energy_ms"] / reps, "bwd": 1e3 * bwd_s, "grad": pr["grad_ms"] / reps},
+                "roofline": {"bound": "mfma", "kernel": "forward recursion (k_gemm_v + k_stage_sym per RK stage)", "achieved": flop_rec / fwd_s / 1e12,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_rec / fwd_s / 1e12 / FP64_PEAK_TFLOPS,
+                             "bwd_achieved": flop_rec / bwd_s / 1e12,
+                             "note": "nominal 2 D^3 flop per stage product; kernel stats and matrix-pipe counters: profiles/r05b_stage_two-kernel_D1024_*.csv"},
+                "parity_check_rel_err_F": err_f, "parity_check_max_rel_err_grad_norm_per_grid_point": err_g,
                 "parity_ok": bool(max(err_f, err_g) < 1e-9)}
     except Exception as exc:                                 # noqa: BLE001 - the headline line must still be printed
         return {"error": repr(exc)}
@@ -549,6 +600,13 @@ def main():
         del x_dev, g_dev
         ctx = None
         c2 = config2_block(args, local_rank)
+    c4 = None
+    if rank == 0 and not args.no_config4 and not args.generic:
+        if ctx is not None:
+            ctx.close()
+            del x_dev, g_dev
+            ctx = None
+        c4 = config4_block(args, local_rank)
 
     # ---- secondary block: BASELINE configs[4]'s matrix size through the row-sharded driver (every rank takes part)
     # (one rank: in this process, behind the headline measurement; N > 1: already measured, in child processes -- see above)
@@ -693,6 +751,8 @@ def main():
     }
     if c2 is not None:
         out["config2"] = c2
+    if c4 is not None:
+        out["config4"] = c4
     if c5 is not None:
         out["config5"] = c5
 

@@ -1,7 +1,7 @@
 # usage: ab.sh name1 name2 ...  ("default" = product lib)
 for rep in 1 2; do for n in "$@"; do
   if [ $n = default ]; then L=""; else L="VGPA_LIB=$PWD/vgpa_amd/lib/variants/libvgpa_hip_$n.so"; fi
-  env $L python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-config2 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err
+  env $L python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-config4 --no-config2 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err
   python3 - $n <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/ab_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 # fp64 matrix pipe (78.6 TFLOP/s at 2.4 GHz) is worth on a box under this load.  Writes gpurun_out/<tag>_clock_under_load.txt
 TAG=${1:-r03}
 out=gpurun_out/${TAG}_clock_under_load.txt
-python bench.py --batch ${BATCH:-512} --steps ${STEPS:-900} --warmup 3 --no-cpu-baseline --no-config5 --no-config2 --no-single-problem > gpurun_out/${TAG}_clock_bench.json 2> gpurun_out/${TAG}_clock_bench.err &
+python bench.py --batch ${BATCH:-512} --steps ${STEPS:-900} --warmup 3 --no-cpu-baseline --no-config5 --no-config4 --no-config2 --no-single-problem > gpurun_out/${TAG}_clock_bench.json 2> gpurun_out/${TAG}_clock_bench.err &
 pid=$!
 sleep 9      # import + context + warm-up
 : > $out

@@ -7,7 +7,7 @@ cat gpurun_out/pmc_avail.txt | tr '\n' ' '
 for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf gpurun_out/prof_$tag
-  rocprofv3 --pmc $set -d gpurun_out/prof_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-problem --no-config5 --no-config2 --batch $BATCH > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
+  rocprofv3 --pmc $set -d gpurun_out/prof_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-problem --no-config5 --no-config4 --no-config2 --batch $BATCH > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
   DB=$(find gpurun_out/prof_$tag -name "*results.db" | head -1)
   python3 - "$DB" <<'PY'
 import sqlite3, sys, collections
