@@ -648,7 +648,7 @@ def main():
     traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
                       "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-single-problem "
                              "--no-cpu-baseline --no-config5` (tools/profile_bench.sh), bytes = 2 x FETCH_SIZE (gfx950 correction, "
-                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r05z_pmc_fetch_write_B512.csv"}
+                             "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch; raw counters: profiles/r05c_pmc_fetch_write_B512.csv"}
 
     # streams of the default batched path (33 <= D <= 40, RK2 / RK4, Sigma = sigma^2 I, B > #CUs): the backward kernel writes
     # Q''_t = A_t / sigma^2 - 2 Psi_t where Psi_t would be, the gradient assembly reads Q''_t and S_t only, and dEsde_dS exists as its
