@@ -15,7 +15,8 @@ for o in $root/vgpa_amd/build/*.o; do
   for s in $srcs; do [ "${s%.*}" = "$b" ] && hit=1; done
   if [ $hit = 1 ]; then
     src=$root/vgpa_amd/csrc/$b.hip; [ -f $src ] || src=$root/vgpa_amd/csrc/$b.cpp
-    /opt/rocm/bin/hipcc -x hip -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $flags -c $src -o $obj/$b.o
+    ff=""; case $b in large_d_stage|large_d_energy) ff="-mllvm -amdgpu-mfma-vgpr-form";; esac      # per-file flags of vgpa_amd/build.py (FILE_CFLAGS)
+    /opt/rocm/bin/hipcc -x hip -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $ff $flags -c $src -o $obj/$b.o
     objs="$objs $obj/$b.o"
   else
     objs="$objs $o"

@@ -16,12 +16,17 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvgpa_hip.so")
 SOURCES = ["vgpa_api.hip", "ode_generic.hip", "ode_mfma.hip", "ode_mfma_m0.hip", "ode_mfma_m1.hip", "ode_mfma_m2.hip",
-           "ode_mfma_m3.hip", "ode_small.hip", "ode_wave.hip", "energy.hip", "assemble.hip", "large_d.hip", "large_d_energy.hip", "vecops.hip", "host_linalg.cpp", "lib_gemm.cpp", "sharded_rccl.cpp"]
+           "ode_mfma_m3.hip", "ode_small.hip", "ode_wave.hip", "energy.hip", "assemble.hip", "large_d.hip", "large_d_stage.hip", "large_d_energy.hip", "vecops.hip", "host_linalg.cpp", "lib_gemm.cpp", "sharded_rccl.cpp"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-ffp-contract=off"]
 
+
+# per-file flags.  -amdgpu-mfma-vgpr-form: fp64-MFMA accumulators in VGPRs throughout (no v_accvgpr copies around the k loops); measured per
+# translation unit -- the one-kernel stages and the energy-phase kernels above D = 64 gain 4 %, the stage products and the D <= 64 kernels
+# do not (large_d_stage.hip)
+FILE_CFLAGS = {"large_d_stage.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "large_d_energy.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 # experiments: extra compiler flags (e.g. -DVGPA_SYM_SPLIT_C_FWD=1) without editing the sources; never set by the package itself
 CFLAGS += os.environ.get("VGPA_EXTRA_CFLAGS", "").split()
@@ -45,7 +50,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer(src, obj, headers):
-            cmd = [HIPCC, *CFLAGS, "-c", src, "-o", obj]
+            cmd = [HIPCC, *CFLAGS, *FILE_CFLAGS.get(s, []), "-c", src, "-o", obj]
             if s.endswith(".cpp"):
                 cmd.insert(1, "-x"); cmd.insert(2, "hip")
             if verbose:
