@@ -499,13 +499,30 @@ static void launch_gemm_bm(bool transa, const GemmArgs& g, hipStream_t st) {
 }
 
 hipError_t launch_gemm(bool transa, const GemmArgs& g, hipStream_t st) {
-  // 128-row tiles reuse B twice as much; fall back to 64-row tiles when they would leave CUs without a workgroup
-  const long long wg128 = (long long)((g.N + BN - 1) / BN) * ((g.M + 127) / 128) * g.nb;
-  const long long wg64 = (long long)((g.N + BN - 1) / BN) * ((g.M + 63) / 64) * g.nb;
+  // Rows of the block tile: the height whose launch fills the chip most evenly, weighted by what the height itself is worth.  Measured
+  // with the four-set loop (forward recursion, TFLOP/s, 32 / 64 / 128 rows -- D = 1536: 41.0 / 35.1 / 27.6; 1792: 42.3 / 38.5 / 37.3;
+  // 2048: 47.5 / 49.3 / 47.6; 2560: 47.5 / 46.4 / 40.0; 3072: 49.4 / 52.6 / 46.2; one-rank D = 4096 sweep 0.309 / 0.293 / 0.297 s; one
+  // rank's 512 x 4096 x 4096 product of configs[4]: 299 / 294 us): every one of these orderings follows from
+  //     score = W / (ceil(W / 256) 256)  x  {0.95, 1.0, 0.966}[height]  x  min(1, (W / 512)^0.22),      W = workgroups of the launch,
+  // i.e. the balance of the last round over 256 CUs, 5 % for the smaller reuse of 32-row tiles, 3.4 % for the two (instead of four)
+  // resident workgroups of 128-row tiles, and what a CU loses below two workgroups (halving them costs 16 %: D = 1024 at 64 rows
+  // 44.0 against 39.6 us, D = 768 / 896 at 64 rows 11.8 / 11.6 against 10.7 / 10.5 ms).  The rounds-2-to-4 rule (the tallest tile
+  // with at least 512 workgroups) lost 10-19 % at D = 1536 ... 3072.
   static const int force_bm = [] { const char* e = getenv("VGPA_GEMM_BM"); return e ? atoi(e) : 0; }();     // (diagnostic: 32 / 64 / 128)
-  if (force_bm == 128 || (!force_bm && wg128 >= 2 * 256)) launch_gemm_bm<128>(transa, g, st);
-  else if (force_bm == 64 || (!force_bm && wg64 >= 2 * 256)) launch_gemm_bm<64>(transa, g, st);
-  else launch_gemm_bm<32>(transa, g, st);      // D = 1024: 512 workgroups, two per CU hide each other's k-tile latency
+  int best = force_bm;
+  if (!best) {
+    double best_score = -1.0;
+    const int heights[3] = {32, 64, 128};
+    const double worth[3] = {0.95, 1.0, 0.966};
+    for (int h = 0; h < 3; h++) {
+      const long long w = (long long)((g.N + BN - 1) / BN) * ((g.M + heights[h] - 1) / heights[h]) * g.nb;
+      const double score = (double)w / (double)((w + 255) / 256 * 256) * worth[h] * (w < 512 ? std::pow((double)w / 512.0, 0.22) : 1.0);
+      if (score >= best_score) { best_score = score; best = heights[h]; }      // (ties: the taller tile)
+    }
+  }
+  if (best == 128) launch_gemm_bm<128>(transa, g, st);
+  else if (best == 64) launch_gemm_bm<64>(transa, g, st);
+  else launch_gemm_bm<32>(transa, g, st);
   return hipGetLastError();
 }
 
