@@ -270,7 +270,7 @@ def config4_block(args, local_rank):
                 "roofline": {"bound": "mfma", "kernel": "forward recursion (k_gemm_v + k_stage_sym per RK stage)", "achieved": flop_rec / fwd_s / 1e12,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_rec / fwd_s / 1e12 / FP64_PEAK_TFLOPS,
                              "bwd_achieved": flop_rec / bwd_s / 1e12,
-                             "note": "nominal 2 D^3 flop per stage product; kernel stats and matrix-pipe counters: profiles/r05b_stage_two-kernel_D1024_*.csv"},
+                             "note": "nominal 2 D^3 flop per stage product; kernel stats and matrix-pipe counters: profiles/r05d_stage_two-kernel_D1024_*.csv"},
                 "parity_check_rel_err_F": err_f, "parity_check_max_rel_err_grad_norm_per_grid_point": err_g,
                 "parity_ok": bool(max(err_f, err_g) < 1e-9)}
     except Exception as exc:                                 # noqa: BLE001 - the headline line must still be printed

@@ -715,13 +715,14 @@ StageArgs stage_args(int D, const Work& w, const StageSpec& s) {
 hipError_t run_stage(int D, const Work& w, const StageSpec& s, hipStream_t st, MidCache* mc = nullptr) {
   const double *ga0 = s.Am0, *ga1 = s.Am1;
   // Which implementation of the stage (measured on one box, fused sweep, ms: two kernels / k_stage_prod / k_stage_wide,
-  // profiles/r05b_stage_versions_ab.txt -- D = 72: 40.7 / 26.5 / 39.0; 128: 41.2 / 31.0 / 37.3; 200: 63.6 / 46.0 / 54.2; 256: 54.2 / 50.6 /
-  // 52.3; 384: 35.1 / 35.5 / 35.3; 512: 44.2 / 46.5 / 45.2; 8 x D = 128: 56.9 / 53.9 / 52.2; 640: 26.4 / 29.3 / 28.7; 768: 39.8 / 46.5 /
-  // 42.6; 1000: 61.4 / 74.1 / 53.9; 1024: 47.1 / 70.6 / 51.9; 1536: 74.7 / 91.5 / 73.5; 2048: 74.2 / 112.9 / 82.7): the latency version
-  // while the launch has at most kStageProdMaxPairs tile pairs (a quarter of the CUs); beyond that the two-kernel stage where the
-  // product runs on its full-tile path (D a multiple of 64: 16-byte loads, four register sets) and D >= 384, the throughput version
-  // for everything else that is eligible -- ragged D, whose product is the bounds-checked 8-byte kernel, and batched contexts of
-  // mid-size problems.
+  // profiles/r05d_stage_versions_ab.txt -- D = 72: 40.4 / 25.4 / 38.4; 128: 39.9 / 29.7 / 36.9; 200: 63.5 / 43.3 / 52.9; 256: 54.1 / 47.9 /
+  // 50.7; 384: 35.1 / - / 34.4; 512: 44.0 / - / 44.0; 8 x D = 128: 57.0 / - / 51.3; 640: 26.3 / - / 27.8; 768: 39.5 / - / 38.3; 1000:
+  // 61.1 / 68.7 / 51.4; 1024: 46.7 / - / 49.0; 1536: 68.4 / - / 69.0; 2048: 71.3 / - / 78.2; more sizes in EXPERIMENTS.md s.13): the
+  // latency version while the launch has at most kStageProdMaxPairs tile pairs (a quarter of the CUs); beyond that the two-kernel
+  // stage where the product runs on its full-tile path (D a multiple of 64: 16-byte loads, four register sets) and D >= 384 -- the
+  // throughput version leads there by 2-3 % at D = 384 and 768 only and trails by 4-8 % at ten other sizes -- and the throughput
+  // version for everything else that is eligible: ragged D, whose product is the bounds-checked 8-byte kernel, and batched contexts
+  // of mid-size problems.
   const bool fused_ok = !use_library_gemm && !literal_products;
   const int nt_ = (D + TS - 1) / TS;
   const bool wide = fused_ok && D % 2 == 0 && D <= stage_wide_max_d() && (D % 64 != 0 || D < kStageWideFullTileD || getenv("VGPA_STAGE_WIDE")) && (size_t)D * D * 8 < 0x7ff00000u &&

@@ -204,9 +204,9 @@ __global__ void __launch_bounds__(NT) k_stage_prod(StageArgs a) {
 //   * 16-byte loads and LDS stores (one per thread and operand tile), the mid-point operand formed once per step by k_mid;
 //   * the element-wise operands are read behind the k loop (37 / 43 KB of LDS -- the transposition buffers alias the operand
 //     tiles -- three workgroups per CU).
-// Where the time goes at D = 1024 (profiles/r05b_stage_{two-kernel,wide}_D1024_*.csv): 60 / 57 us per launch (forward / backward)
+// Where the time goes at D = 1024 (profiles/r05d_stage_{two-kernel,wide}_D1024_*.csv): 55 us per launch
 // against 40 + 12 us of GEMM + k_stage_sym (+ 3 us more of launch gaps for those): the k loop takes ~50 us, 64 k-tiles of 8 MFMAs
-// per wave at two waves per SIMD = 27 us of MFMA time at 2.4 GHz, matrix pipe busy 0.52 / 0.55 of the SIMD-cycles (GEMM: 0.76) --
+// per wave at two waves per SIMD = 27 us of MFMA time at 2.4 GHz, matrix pipe busy 0.58 / 0.59 of the SIMD-cycles (GEMM: 0.77) --
 // 16 instead of 12 fragment reads per 8 MFMAs, four instead of three 16-byte loads and LDS stores per k-tile.  At THIS size (512
 // workgroups, two per CU, one round) neither prefetch depth (2 / 4 / 6 register sets), nor the order of LDS stores and products,
 // nor the XCD-aware tile order moved it by more than 1 %; away from it the latter two pay (below).
