@@ -1501,7 +1501,7 @@ hipError_t shard_sweep(ShardCtx& c, int Np, SweepBuffers& B, const SweepProblem&
   double* et_mine = B.et_all + (size_t)c.rank * pad;
   if (n_own > 0)
     LD_TRY(lde_energy(D, n_own, p.theta, p.isg, a_own, b_own, B.m_own, B.S_own, et_mine, B.Ef_own, nullptr, gm_mine, B.gs_own, B.status,
-                      B.lde_ws, B.lde_nb, st));
+                      B.lde_ws, B.lde_nb, st, nullptr, c.cs));      // (cs is idle here: the recursion ended joined, and lde_energy joins again)
   LD_TRY(mark(3));
   if (world > 1) {
     SH_COMM(c, group_begin(c));

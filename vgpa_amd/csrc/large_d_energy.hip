@@ -31,7 +31,19 @@ struct GemmB {
                                           // triangular): the k loop of a tile starts at its first column; 2 = also
                                           // op(A)[i][k] = 0 for k < i: it starts at max(first row, first column).
                                           // Only exact zeros are skipped, so the result is bit-identical.
+                                          // 3 = op(B) as in 1 is NOT assumed; op(A)[i][k] = 0 for k > i (A lower triangular,
+                                          // whole 64-blocks): the k loop of a tile ends behind its last row.
+  int nb1;                                // > 0: two batch levels, blockIdx.z = z2 * nb1 + z1 (z1: grid point, strides sA / sB / sC;
+  long long sA2, sB2, sC2;                //      z2: independent sub-problem of the same grid point, strides sA2 / sB2 / sC2)
 };
+
+__device__ __forceinline__ void batch_origin(const GemmB& g, const double*& A, const double*& B, double*& C) {
+  long long z1 = blockIdx.z, z2 = 0;
+  if (g.nb1 > 0) { z2 = blockIdx.z / g.nb1; z1 = blockIdx.z - z2 * g.nb1; }
+  A = g.A + z1 * g.sA + z2 * g.sA2;
+  B = g.B + z1 * g.sB + z2 * g.sB2;
+  C = g.C + z1 * g.sC + z2 * g.sC2;
+}
 
 template <bool TA, bool TB, int BM>
 __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
@@ -45,9 +57,9 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   if (g.lower_only && j0 >= i0 + BM) return;
-  const double* A = g.A + (long long)blockIdx.z * g.sA;
-  const double* B = g.B + (long long)blockIdx.z * g.sB;
-  double* C = g.C + (long long)blockIdx.z * g.sC;
+  const double *A, *B;
+  double* C;
+  batch_origin(g, A, B, C);
   const int fi = lane & 15, fk = lane >> 4;
   double ra[AQ], rb[4];
   auto load_tiles = [&](int k0) {
@@ -89,7 +101,8 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
-  const int nk = (g.K + BK - 1) / BK;
+  int nk = (g.K + BK - 1) / BK;
+  if (g.k_tri == 3 && (i0 + BM) / BK < nk) nk = (i0 + BM) / BK;
   int kt0 = 0;
   if (g.k_tri == 1) kt0 = j0 / BK;
   else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
@@ -141,10 +154,12 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
 // Full 64 x 64 tiles, op(B) = B, 16-byte global loads, prefetch distance two (the treatment of ld::k_gemm_v, large_d.hip:
 // the A tile keeps its HBM orientation in LDS -- [i][18] for row-major A, k-major for A^T).  Same k order per output
 // element as k_gemm_b, i.e. the same bits.
-template <bool TA>
+// (BM = 128 -- 57 KB of LDS, two workgroups per CU -- measured slower than 64 for every product of the energy phase: D = 1024, 33 grid
+//  points: energy terms 4.57 against 4.26 ms, gradient 1.50 against 1.39 ms; not dispatched)
+template <bool TA, int BM = 64>
 __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int BM = 64, LDK = 18, LDT = BM + 16, LDBS = BN + 16;
+  constexpr int LDK = 18, LDT = BM + 16, LDBS = BN + 16;
   constexpr int ASZ = TA ? BK * LDT : BM * LDK;
   constexpr int MT = BM / 32, AV = BM * BK / 2 / NT;
   __shared__ __attribute__((aligned(16))) double As[2][ASZ];
@@ -153,9 +168,9 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   if (g.lower_only && j0 >= i0 + BM) return;
-  const double* A = g.A + (long long)blockIdx.z * g.sA;
-  const double* B = g.B + (long long)blockIdx.z * g.sB;
-  double* C = g.C + (long long)blockIdx.z * g.sC;
+  const double *A, *B;
+  double* C;
+  batch_origin(g, A, B, C);
   const int fi = lane & 15, fk = lane >> 4;
   // persistent operand pointers, advanced by one k-tile per load (see ld::k_gemm_v)
   const double* pA[AV];
@@ -224,7 +239,8 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
     }
   };
-  const int nk = g.K / BK;
+  int nk = g.K / BK;
+  if (g.k_tri == 3 && (i0 + BM) / BK < nk) nk = (i0 + BM) / BK;
   int kt0 = 0;
   if (g.k_tri == 1) kt0 = j0 / BK;
   else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
@@ -274,13 +290,16 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
     }
 }
 
-hipError_t gemm_b(bool ta, bool tb, const GemmB& g, int nb, hipStream_t st) {
-  if (g.M <= 0 || g.N <= 0 || nb <= 0) return hipSuccess;
-  dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb);
+// nb: grid points; nsub > 1: that many independent sub-problems per grid point (GemmB::nb1 and the second-level strides are set here)
+hipError_t gemm_b(bool ta, bool tb, GemmB g, int nb, hipStream_t st, int nsub = 1) {
+  if (g.M <= 0 || g.N <= 0 || nb <= 0 || nsub <= 0) return hipSuccess;
+  g.nb1 = nsub > 1 ? nb : 0;
+  dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb * nsub);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   static const bool scalar_loads = [] { const char* e = getenv("VGPA_GEMM_SCALAR_LOADS"); return e && e[0] == '1'; }();
   const bool vec = !tb && !scalar_loads && g.M % 64 == 0 && g.N % BN == 0 && g.K % BK == 0 && g.lda % 2 == 0 &&
-                   g.ldb % 2 == 0 && g.sA % 2 == 0 && g.sB % 2 == 0 && al16(g.A) && al16(g.B);
+                   g.ldb % 2 == 0 && g.sA % 2 == 0 && g.sB % 2 == 0 && al16(g.A) && al16(g.B) &&
+                   (nsub == 1 || (g.sA2 % 2 == 0 && g.sB2 % 2 == 0));
   if (vec) {
     if (ta) hipLaunchKernelGGL((k_gemm_bv<true>), grid, dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((k_gemm_bv<false>), grid, dim3(NT), 0, st, g);
@@ -431,12 +450,38 @@ __global__ void __launch_bounds__(NT) k_matvec(int D, int ta, const double* A, l
   if (lane == 0) y[(long long)blockIdx.y * sy + i] = scale * s;
 }
 
+// y = scale * A^T x with coalesced row reads: block = 64 columns (lane = column), its four waves take the rows k = wave (mod 4), four
+// independent partial sums each; (the one-wave-per-output form above reads a column with one cache line per lane: 285 us per 33 grid
+// points at D = 1024 against 73 us for A x)
+__global__ void __launch_bounds__(NT) k_matvec_t(int D, const double* A, long long sA, const double* x, long long sx, double* y,
+                                                 long long sy, double scale) {
+  __shared__ double red[NT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 64 + lane;
+  const int ic = i < D ? i : D - 1;
+  const double* a = A + (long long)blockIdx.y * sA + ic;
+  const double* xv = x + (long long)blockIdx.y * sx;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  int k = wave;
+  for (; k + 12 < D; k += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) s[u] = __builtin_fma(a[(long long)(k + 4 * u) * D], xv[k + 4 * u], s[u]);
+  }
+  for (; k < D; k += 4) s[0] = __builtin_fma(a[(long long)k * D], xv[k], s[0]);
+  red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (wave == 0 && i < D) y[(long long)blockIdx.y * sy + i] = scale * ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+}
+
 __device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
-// v_p for every sigma point p (thread = sigma point, sequential sliding window over i)
+// v_p for every sigma point p (thread = sigma point, sequential sliding window over the components i of ONE segment: gridDim.z
+// segments of `seg` components each -- one thread per sigma point walked all D rows of L and G with a memory round trip per row:
+// 529 us per 33 grid points at D = 1024, 3.8 x the time its bytes take).  nseg > 1: the partial sums go to vpart[seg][t][p] and
+// k_vsum adds them in the order of the segments.
 __global__ void __launch_bounds__(NT) k_resid(int D, double theta, const double* L, const double* G, long long sW,
                                               const double* m, const double* b, long long sb, const double* am,
-                                              const double* isg, double* v, long long sv) {
+                                              const double* isg, double* v, long long sv, int seg) {
   const int M = 2 * D + 1;
   const int p = blockIdx.x * NT + threadIdx.x;
   if (p >= M) return;
@@ -452,9 +497,12 @@ __global__ void __launch_bounds__(NT) k_resid(int D, double theta, const double*
   const int rp = col_of(p);
   const double sp = sgn_of(p);
   const int pm = wrapi(p - 1, M), pp = wrapi(p + 1, M);
-  double xm2 = chi(pm, D - 2), xm1 = chi(pm, D - 1), x0 = chi(p, 0), x1 = chi(p, 1);
+  // flat roll (quirk Q1): component i - 2 / i - 1 of the first two rows belong to sigma point p - 1, i + 1 of the last row to p + 1
+  auto at = [&](int i) { return i < 0 ? chi(pm, i + D) : (i < D ? chi(p, i) : chi(pp, i - D)); };
+  const int i0 = blockIdx.z * seg, i1 = (i0 + seg < D) ? (i0 + seg) : D;
+  double xm2 = at(i0 - 2), xm1 = at(i0 - 1), x0 = at(i0), x1 = at(i0 + 1);
   double acc = 0.0;
-  for (int i = 0; i < D; i++) {
+  for (int i = i0; i < i1; i++) {
     const double lin = av[i] + sp * Gm[(long long)i * D + rp];
     const double res = ((x1 - xm2) * xm1 - x0 + theta) + lin - bv[i];
     acc = __builtin_fma(isg[i], res * res, acc);
@@ -462,7 +510,16 @@ __global__ void __launch_bounds__(NT) k_resid(int D, double theta, const double*
     const int in = i + 2;
     x1 = (in < D) ? chi(p, in) : chi(pp, in - D);
   }
-  v[(long long)t * sv + p] = acc;
+  v[((long long)blockIdx.z * gridDim.y + t) * sv + p] = acc;
+}
+
+// v[t][p] = sum over the segments, in their order
+__global__ void __launch_bounds__(NT) k_vsum(int M, int nseg, int nb, const double* vpart, double* v) {
+  const long long e = (long long)blockIdx.x * NT + threadIdx.x;
+  if (e >= (long long)nb * M) return;
+  double s = vpart[e];
+  for (int q = 1; q < nseg; q++) s += vpart[(long long)q * nb * M + e];
+  v[e] = s;
 }
 
 // e_t, delta, q from v; also <f> (E96_drift)
@@ -628,6 +685,18 @@ __global__ void __launch_bounds__(NT) k_grad_fin(int D, double dt, const double*
   }
 }
 
+// two events of the look-ahead in lde_energy (destroyed on every return path)
+struct EventPair {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool create() {
+    return hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess;
+  }
+  ~EventPair() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
 }  // namespace lde
 
 namespace ld {
@@ -650,13 +719,19 @@ int lde_batch(int D, double budget_bytes) {
 // Energy terms of Np grid points of ONE problem.  Edf may be nullptr.
 hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
                       const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
-                      double* ws, int nbmax, hipStream_t st, double* hyp) {
+                      double* ws, int nbmax, hipStream_t st, double* hyp, hipStream_t side) {
   using namespace lde;
   const long long DD = (long long)D * D;
   const int T = (D + NBLK - 1) / NBLK, M = 2 * D + 1;
   const double kappa = 1.05 * D, c = D + kappa;
   const size_t lds_diag = sizeof(double) * (2 * NBLK * (NBLK + 1) + NBLK);
   (void)hipFuncSetAttribute((const void*)k_diag64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+  static const bool no_ahead = [] { const char* e = getenv("VGPA_LDE_AHEAD"); return e && e[0] == '0'; }();
+  static const bool by_rows = [] { const char* e = getenv("VGPA_LDE_INVERSE"); return e && e[0] == 'r'; }();
+  const bool ahead = side != nullptr && side != st && T > 2 && !no_ahead;
+  EventPair evs;                                      // (destroyed on every return path)
+  if (ahead && !evs.create()) return hipErrorOutOfMemory;
+  hipEvent_t evP = evs.a, evB = evs.b;
   for (int t0 = 0; t0 < Np; t0 += nbmax) {
     const int nb = (Np - t0 < nbmax) ? (Np - t0) : nbmax;
     double* C = ws;                                   // [nb][D][D]  c*S -> L -> diag(q) X
@@ -674,7 +749,11 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     const double* bt = b + (size_t)t0 * D;
     const int eg = (int)((DD + NT * 8 - 1) / (NT * 8));
     hipLaunchKernelGGL(k_prep, dim3(eg, nb), dim3(NT), 0, st, D, c, St, C, X, DD);
-    // ---- blocked Cholesky
+    // ---- blocked Cholesky.  With a side stream (`ahead`) the trailing update of panel J is issued in two parts: block column J + 1
+    // on the main stream -- all the next diagonal block and panel wait for -- and the rest on the side stream, beside them: the
+    // one-wave-per-grid-point chain of k_diag64 (D / 64 launches of 50-70 us that do not shrink with the batch) runs in the shadow of
+    // the update instead of between two of them.  Same tiles, same k order per element: the same bits as the one-launch update.
+    bool b_pending = false;
     for (int J = 0; J < T; J++) {
       hipLaunchKernelGGL(k_diag64, dim3(nb), dim3(64), lds_diag, st, D, J, C, X, DD, DD, status, 30);
       const int r1 = (J + 1) * NBLK;
@@ -691,22 +770,75 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
       u.M = Mr; u.N = Mr; u.K = kw; u.A = C + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
       u.B = u.A; u.ldb = D; u.sB = DD; u.C = C + (size_t)r1 * D + r1; u.ldc = D; u.sC = DD; u.alpha = -1.0; u.beta = 1.0;
       u.lower_only = 1;
-      LDE_TRY(gemm_b(false, true, u, nb, st));
+      // (a record / wait pair costs the main stream ~20 us: only where the side-stream part is longer than the chain it hides --
+      //  measured at D = 1024, 33 grid points: 117 us at J = 0, 61 us at J = 3)
+      const double side_flop = (double)(Mr - NBLK) * (Mr - NBLK) * kw * nb;
+      if (!ahead || Mr <= NBLK || side_flop < 1.5e9) {
+        if (b_pending) { LDE_TRY(hipStreamWaitEvent(st, evB, 0)); b_pending = false; }
+        LDE_TRY(gemm_b(false, true, u, nb, st));
+        continue;
+      }
+      LDE_TRY(hipEventRecord(evP, st));                        // panel J is final
+      // block column J + 1 (rows r1 ..): the previous step's side-stream part updated it too
+      if (b_pending) LDE_TRY(hipStreamWaitEvent(st, evB, 0));
+      GemmB ua = u;
+      ua.N = NBLK; ua.lower_only = 0;
+      LDE_TRY(gemm_b(false, true, ua, nb, st));
+      // the rest (rows and columns from r1 + 64): side stream, behind panel J and behind its own previous part
+      GemmB ub = u;
+      ub.M = ub.N = Mr - NBLK;
+      ub.A = ub.B = u.A + (size_t)NBLK * D;
+      ub.C = u.C + (size_t)NBLK * D + NBLK;
+      LDE_TRY(hipStreamWaitEvent(side, evP, 0));
+      LDE_TRY(gemm_b(false, true, ub, nb, side));
+      LDE_TRY(hipEventRecord(evB, side));
+      b_pending = true;
     }
+    if (b_pending) LDE_TRY(hipStreamWaitEvent(st, evB, 0));
     hipLaunchKernelGGL(k_zero_upper, dim3(eg, nb), dim3(NT), 0, st, D, C, DD);
-    // ---- X = L^-1 by block rows
-    for (int I = 1; I < T; I++) {
-      const int r0 = I * NBLK;
-      const int Mi = (D - r0 < NBLK) ? (D - r0) : NBLK;
-      GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
-      a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = C + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = X; a1.ldb = D; a1.sB = DD;
-      a1.C = T1; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
-      a1.k_tri = 1;                                  // X[0:r0, 0:r0] is lower triangular
-      LDE_TRY(gemm_b(false, false, a1, nb, st));
-      GemmB a2{};  // X[I, 0:r0] = -X_II T1
-      a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = X + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = T1; a2.ldb = D;
-      a2.sB = (long long)NBLK * D; a2.C = X + (size_t)r0 * D; a2.ldc = D; a2.sC = DD; a2.alpha = -1.0; a2.beta = 0.0;
-      LDE_TRY(gemm_b(false, false, a2, nb, st));
+    // ---- X = L^-1 by halves: with X_11, X_22 known, X_21 = -X_22 (L_21 X_11).  Level h (h = 1, 2, 4 ... blocks) joins the
+    // neighbouring groups of h blocks; the groups of a level are independent and go into ONE launch per product (second batch level of
+    // GemmB), so D / 64 = 16 | 64 takes 8 | 12 launches of growing products instead of 30 | 126 of one 64-row block each.  The
+    // intermediate L_21 X_11 sits in G (free until G = A L) at the place of X_21.
+    if (by_rows) {      // the block-row form of rounds 1-4, kept for the A/B measurement (VGPA_LDE_INVERSE=rows)
+      for (int I = 1; I < T; I++) {
+        const int r0 = I * NBLK;
+        const int Mi = (D - r0 < NBLK) ? (D - r0) : NBLK;
+        GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
+        a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = C + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = X; a1.ldb = D; a1.sB = DD;
+        a1.C = T1; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
+        a1.k_tri = 1;                                  // X[0:r0, 0:r0] is lower triangular
+        LDE_TRY(gemm_b(false, false, a1, nb, st));
+        GemmB a2{};  // X[I, 0:r0] = -X_II T1
+        a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = X + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = T1; a2.ldb = D;
+        a2.sB = (long long)NBLK * D; a2.C = X + (size_t)r0 * D; a2.ldc = D; a2.sC = DD; a2.alpha = -1.0; a2.beta = 0.0;
+        LDE_TRY(gemm_b(false, false, a2, nb, st));
+      }
+    }
+    for (int h = 1; h < T && !by_rows; h *= 2) {
+      const int hs = h * NBLK;
+      const int ngr = (T - h + 2 * h - 1) / (2 * h);           // groups whose second half exists
+      const long long step2 = (long long)2 * hs * (D + 1);     // from one group's blocks to the next group's
+      auto rows_of = [&](int g) { const int mid = (2 * g + 1) * hs, hi = (2 * g + 2) * hs; return (hi < D ? hi : D) - mid; };
+      const int nfull = (rows_of(ngr - 1) == hs) ? ngr : ngr - 1;
+      for (int part = 0; part < 2; part++) {
+        const int g0 = part == 0 ? 0 : nfull, ng = part == 0 ? nfull : ngr - nfull;
+        if (ng <= 0) continue;
+        const int Mi = rows_of(g0);
+        const size_t org = (size_t)g0 * (size_t)step2;
+        GemmB a1{};  // T = L_21 X_11
+        a1.M = Mi; a1.N = hs; a1.K = hs; a1.A = C + org + (size_t)hs * D; a1.lda = D; a1.sA = DD; a1.sA2 = step2;
+        a1.B = X + org; a1.ldb = D; a1.sB = DD; a1.sB2 = step2;
+        a1.C = G + org + (size_t)hs * D; a1.ldc = D; a1.sC = DD; a1.sC2 = step2; a1.alpha = 1.0; a1.beta = 0.0;
+        a1.k_tri = 1;                                          // X_11 is lower triangular
+        LDE_TRY(gemm_b(false, false, a1, nb, st, ng));
+        GemmB a2{};  // X_21 = -X_22 T
+        a2.M = Mi; a2.N = hs; a2.K = Mi; a2.A = X + org + (size_t)hs * (D + 1); a2.lda = D; a2.sA = DD; a2.sA2 = step2;
+        a2.B = G + org + (size_t)hs * D; a2.ldb = D; a2.sB = DD; a2.sB2 = step2;
+        a2.C = X + org + (size_t)hs * D; a2.ldc = D; a2.sC = DD; a2.sC2 = step2; a2.alpha = -1.0; a2.beta = 0.0;
+        a2.k_tri = 3;                                          // X_22 is lower triangular
+        LDE_TRY(gemm_b(false, false, a2, nb, st, ng));
+      }
     }
     // ---- G = A L ; A m
     GemmB gg{};
@@ -716,16 +848,23 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     LDE_TRY(gemm_b(false, false, gg, nb, st));
     hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 0, At, DD, mt, (long long)D, am, (long long)D, 1.0);
     // ---- residuals, scalars
-    hipLaunchKernelGGL(k_resid, dim3((M + NT - 1) / NT, nb), dim3(NT), 0, st, D, theta, C, G, DD, mt, bt, (long long)D, am,
-                       isg, vv, (long long)M);
+    {
+      // segments of >= 128 components (D <= 255: one, the sums of rounds 1-4 bit for bit); the partial sums take T1's place
+      const int nseg = D / 128 < 1 ? 1 : (D / 128 > 16 ? 16 : D / 128);
+      const int seg = (D + nseg - 1) / nseg;
+      hipLaunchKernelGGL(k_resid, dim3((M + NT - 1) / NT, nb, nseg), dim3(NT), 0, st, D, theta, C, G, DD, mt, bt, (long long)D, am,
+                         isg, nseg > 1 ? T1 : vv, (long long)M, seg);
+      if (nseg > 1)
+        hipLaunchKernelGGL(k_vsum, dim3((unsigned)(((long long)nb * M + NT - 1) / NT)), dim3(NT), 0, st, M, nseg, nb, T1, vv);
+    }
     hipLaunchKernelGGL(k_finish, dim3(nb), dim3(NT), 0, st, D, theta, vv, (long long)M, St, mt, e_t + t0, dl, qq,
                        Ef + (size_t)t0 * D);
     if (hyp)
       hipLaunchKernelGGL(k_hyper, dim3((D + NT - 1) / NT, nb), dim3(NT), 0, st, D, theta, C, G, DD, mt, bt, (long long)D, am,
                          Ef + (size_t)t0 * D, hyp + (size_t)t0 * 2 * D);
     // ---- dE/dm = c/2 X^T delta ; dE/dS = c/2 X^T diag(q) X
-    hipLaunchKernelGGL(k_matvec, dim3((D + 3) / 4, nb), dim3(NT), 0, st, D, 1, X, DD, dl, (long long)D,
-                       dEm + (size_t)t0 * D, (long long)D, 0.5 * c);
+    hipLaunchKernelGGL(k_matvec_t, dim3((D + 63) / 64, nb), dim3(NT), 0, st, D, X, DD, dl, (long long)D, dEm + (size_t)t0 * D,
+                       (long long)D, 0.5 * c);
     hipLaunchKernelGGL(k_scale_rows, dim3(eg, nb), dim3(NT), 0, st, D, X, qq, C, DD);
     GemmB sy{};
     sy.M = D; sy.N = D; sy.K = D; sy.A = X; sy.lda = D; sy.sA = DD; sy.B = C; sy.ldb = D; sy.sB = DD;

@@ -20,6 +20,7 @@ struct vgpa_ctx {
   size_t DD = 0, len_x = 0;
   bool single = false, full = false, sigma_diag = true, sym_inputs = true;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // side stream of the D > 64 energy terms (lde_energy's look-ahead), created on first use
   std::string err;
   double theta[kMaxTheta] = {0, 0, 0, 0};
   // device buffers
@@ -351,6 +352,10 @@ static EnergyArgs energy_args(vgpa_ctx* c, double* edf, bool ds_upper = false) {
 }
 
 static int ensure_lde_ws(vgpa_ctx* c) {
+  if (!c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
+    c->stream2 = nullptr;               // (lde_energy then runs on the one stream)
+    (void)hipGetLastError();
+  }
   if (c->d_lde_ws) return VGPA_OK;
   c->lde_nb = ld::lde_batch(c->D, c->lde_budget);
   if (c->lde_nb > c->Np) c->lde_nb = c->Np;
@@ -371,7 +376,7 @@ static int run_energy(vgpa_ctx* c, double* edf, bool ds_upper = false, bool ds_p
       hipError_t e = ld::lde_energy(c->D, c->Np, c->theta[0], c->d_isg, ctx_A(c) + p * c->len_x, ctx_b(c) + p * c->len_x, c->d_m + p * NpD,
                                     c->d_S + p * NpDD, c->d_et + (size_t)p * c->Np, c->d_Ef + p * NpD, edf ? edf + p * NpDD : nullptr,
                                     c->d_dEm + p * NpD, c->d_dEs + p * NpDD, c->d_status + p, c->d_lde_ws, c->lde_nb, c->stream,
-                                    c->hyp_on ? c->d_hyp + (size_t)p * c->Np * 2 * c->D : nullptr);
+                                    c->hyp_on ? c->d_hyp + (size_t)p * c->Np * 2 * c->D : nullptr, c->stream2);
       if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
     }
     return VGPA_OK;
@@ -469,7 +474,7 @@ static int stream_pass(vgpa_ctx* c, double* g_dev) {
     const int n = t1 - t0 + 1;
     hipError_t e = ld::lde_energy(D, n, c->theta[0], c->d_isg, A + (size_t)t0 * DD, b + (size_t)t0 * D, c->d_m + (size_t)t0 * D,
                                   c->d_S + (size_t)t0 * DD, c->d_et + t0, c->d_Ef + (size_t)t0 * D, nullptr,
-                                  c->d_dEm + (size_t)t0 * D, c->d_dEs_c, c->d_status, c->d_lde_ws, c->lde_nb, st);
+                                  c->d_dEm + (size_t)t0 * D, c->d_dEs_c, c->d_status, c->d_lde_ws, c->lde_nb, st, nullptr, c->stream2);
     if (e != hipSuccess) return fail(c, VGPA_ERR_DEVICE, "large-D energy failed: %s", hipGetErrorString(e));
     if (g_dev) {
       // Psi_{t1} sits in slot n-1: zero at the very end of the grid, else carried over from slot 0 of the previous chunk
@@ -734,6 +739,7 @@ void vgpa_destroy(vgpa_ctx* c) {
   if (c->h_fs) (void)hipHostFree(c->h_fs);
   for (auto& e : c->ev_coef) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

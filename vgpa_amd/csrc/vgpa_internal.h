@@ -253,7 +253,7 @@ size_t lde_workspace_doubles(int D, int nb);
 int lde_batch(int D, double budget_bytes);
 hipError_t lde_energy(int D, int Np, double theta, const double* isg, const double* A, const double* b, const double* m,
                       const double* S, double* e_t, double* Ef, double* Edf, double* dEm, double* dEs, int32_t* status,
-                      double* ws, int nbmax, hipStream_t st, double* hyp = nullptr)   /* hyp: [Np][2 D] integrands of dEsde_dtheta | dEsde_dSigma, or nullptr */;
+                      double* ws, int nbmax, hipStream_t st, double* hyp = nullptr, hipStream_t side = nullptr)   /* hyp: [Np][2 D] integrands of dEsde_dtheta | dEsde_dSigma, or nullptr */;
 hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A, const double* b, const double* m,
                     const double* S, const double* lam, const double* psi, const double* Ef, double* gA, double* gB,
                     double* ws, int nbmax, hipStream_t st, const double* isig_dense = nullptr);   // [D][D] Sigma^-1 when it is not diagonal
