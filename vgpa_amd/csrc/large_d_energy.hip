@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "vgpa_internal.h"
+#include "chol_wave.h"
 
 namespace vgpa {
 namespace lde {
@@ -411,6 +412,113 @@ __global__ void __launch_bounds__(64) k_diag64(int D, int J, double* Cb, double*
   }
 }
 
+// The same block on the matrix cores: the one-wave Cholesky and blocked forward substitution of the D <= 64 energy kernel
+// (energy.hip::k_energy_l96 phases 1 and 4, NB = 16; chol_wave.h) -- panel updates and the rows of L^-1 as chains of
+// v_mfma_f64_4x4x4_4b, every lane factoring the 4 x 4 diagonal block of its panel itself.  The vector-ALU form above walks
+// ~2 x 1 900 dependent fused multiply-adds per lane behind LDS reads: 63 us per launch, and D / 64 launches in sequence whatever the
+// batch; this one takes a quarter of that.
+__global__ void __launch_bounds__(64) k_diag64m(int D, int J, double* Cb, double* Xb, long long strideC, long long strideX,
+                                                int32_t* status, int status_stride_log) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NB = NBLK / 4, LD = NBLK + 1;
+  double* Lm = smem;             // [64][65]
+  double* Xm = Lm + NBLK * LD;   // [64][65]
+  double* xdiag = Xm + NBLK * LD;      // [16][16]: inverses of the 4 x 4 diagonal blocks
+  double* rdv = xdiag + 16 * NB;       // [64]: 1 / L[i][i]
+  const int l = threadIdx.x, bi = blockIdx.x;
+  double* C = Cb + (long long)bi * strideC;
+  double* X = Xb + (long long)bi * strideX;
+  const int r0 = J * NBLK;
+  const int nv = (D - r0 < NBLK) ? (D - r0) : NBLK;      // valid rows / columns of this block
+  for (int e = l; e < NBLK * NBLK; e += 64) {
+    const int r = e >> 6, c = e & 63;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nv && c < nv) v = C[(long long)(r0 + r) * D + r0 + c];
+    Lm[r * LD + c] = v;
+  }
+  wave_sync();
+  const int r4 = l >> 4, c4 = l & 3, b = (l >> 2) & 3;
+  double myrd = 1.0;                       // 1 / L[l][l]
+  const double* lrow_b = Lm + (4 * b + c4) * LD + r4;      // + 4 (p + 4u) LD: A-operand rows of block b
+  double* lout_b = Lm + (4 * b + r4) * LD + c4;            // + 4 (p + 4u) LD + 4p: output position of block b
+#pragma unroll
+  for (int p = 0; p < NB; p++) {
+    const int j0 = 4 * p;
+    if (p > 0) {
+      const double* brow = Lm + (j0 + c4) * LD + r4;
+#pragma unroll
+      for (int u = 0; p + 4 * u < NB; u++) {
+        const bool full = p + 4 * u + 3 < NB;                // compile-time: all four block-rows of the unit exist
+        const bool rowok = full || (p + 4 * u + b < NB);
+        const double* arow = full ? lrow_b + 4 * (p + 4 * u) * LD : Lm + (4 * (rowok ? p + 4 * u + b : NB - 1) + c4) * LD + r4;
+        double uacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < p; kk++) uacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * kk], brow[4 * kk], uacc, 0, 0, 0);
+        if (rowok) lout_b[4 * (p + 4 * u) * LD + j0] -= uacc;
+      }
+      wave_sync();
+    }
+    cholw::chol_panel_pivots<LD>(Lm, myrd, j0, l, l, true);
+    wave_sync();
+  }
+  if (__any(!(myrd > 0.0 && myrd < __builtin_inf()))) {
+    if (l == 0) atomicOr(status + (bi >> status_stride_log), 1);
+    return;
+  }
+  rdv[l] = myrd;
+  wave_sync();
+  if (l < NB) {
+    const double* tb = Lm + (4 * l) * LD + 4 * l;
+    const double x00 = rdv[4 * l], x11 = rdv[4 * l + 1], x22 = rdv[4 * l + 2], x33 = rdv[4 * l + 3];
+    const double t10 = tb[LD], t20 = tb[2 * LD], t21 = tb[2 * LD + 1], t30 = tb[3 * LD], t31 = tb[3 * LD + 1], t32 = tb[3 * LD + 2];
+    const double x10 = -(t10 * x00) * x11;
+    const double x21 = -(t21 * x11) * x22;
+    const double x32 = -(t32 * x22) * x33;
+    const double x20 = -(t20 * x00 + t21 * x10) * x22;
+    const double x31 = -(t31 * x11 + t32 * x21) * x33;
+    const double x30 = -(t30 * x00 + t31 * x10 + t32 * x20) * x33;
+    double* xo = xdiag + 16 * l;
+    xo[0] = x00; xo[1] = 0.0; xo[2] = 0.0; xo[3] = 0.0;
+    xo[4] = x10; xo[5] = x11; xo[6] = 0.0; xo[7] = 0.0;
+    xo[8] = x20; xo[9] = x21; xo[10] = x22; xo[11] = 0.0;
+    xo[12] = x30; xo[13] = x31; xo[14] = x32; xo[15] = x33;
+  }
+  wave_sync();
+  // X = L^-1 by blocked forward substitution: for block-row I and the unit of column blocks J_b = 4u + b, T_b = sum_{K < I}
+  // L[I][K] X[K][J_b] accumulates in the MFMA result register, which is laid out as the B-operand of X[I][J_b] = -inv(L[I][I]) T_b
+  const double* l4_a = Lm + c4 * LD + r4;                  // + 4 I LD + 4 K : A-operand L[4I + c4][4K + r4]
+  const double* xd_a = xdiag + 4 * c4 + r4;                // + 16 I
+  const double* xd_d = xdiag + 4 * r4 + c4;
+#pragma unroll
+  for (int I = 0; I < NB; I++) {
+    const double* arow = l4_a + 4 * I * LD;
+    const double xd = xd_a[16 * I];
+    const double xdd = xd_d[16 * I];
+#pragma unroll
+    for (int u = 0; 4 * u < NB; u++) {
+      const int Jb = 4 * u + b;
+      double* xcol = Xm + r4 * LD + 4 * Jb + c4;
+      double xo = 0.0;
+      if (4 * u <= I) {                                      // compile-time: some block of the unit is on / below the diagonal
+        double tacc = 0.0;
+#pragma unroll
+        for (int K = 4 * u; K < I; K++) tacc = __builtin_amdgcn_mfma_f64_4x4x4f64(arow[4 * K], xcol[4 * K * LD], tacc, 0, 0, 0);
+        const double prod = __builtin_amdgcn_mfma_f64_4x4x4f64(xd, tacc, 0.0, 0, 0, 0);
+        xo = (Jb < I) ? -prod : ((Jb == I) ? xdd : 0.0);
+      }
+      xcol[4 * I * LD] = xo;                                 // X[4I + r4][4 J_b + c4]
+    }
+    wave_sync();
+  }
+  for (int e = l; e < NBLK * NBLK; e += 64) {
+    const int r = e >> 6, c = e & 63;
+    if (r < nv && c < nv) {
+      C[(long long)(r0 + r) * D + r0 + c] = Lm[r * LD + c];
+      X[(long long)(r0 + r) * D + r0 + c] = Xm[r * LD + c];
+    }
+  }
+}
+
 // ---- small batched kernels ---------------------------------------------------------------------------------------
 // C = c * S_t ; X = 0
 __global__ void __launch_bounds__(NT) k_prep(int D, double cfac, const double* S, double* C, double* X, long long sW) {
@@ -685,7 +793,7 @@ __global__ void __launch_bounds__(NT) k_grad_fin(int D, double dt, const double*
   }
 }
 
-// two events of the look-ahead in lde_energy (destroyed on every return path)
+// fork / join events of lde_energy's two streams (destroyed on every return path)
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
   bool create() {
@@ -725,12 +833,15 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
   const int T = (D + NBLK - 1) / NBLK, M = 2 * D + 1;
   const double kappa = 1.05 * D, c = D + kappa;
   const size_t lds_diag = sizeof(double) * (2 * NBLK * (NBLK + 1) + NBLK);
+  const size_t lds_diagm = sizeof(double) * (2 * NBLK * (NBLK + 1) + 16 * (NBLK / 4) + NBLK);
   (void)hipFuncSetAttribute((const void*)k_diag64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
-  static const bool no_ahead = [] { const char* e = getenv("VGPA_LDE_AHEAD"); return e && e[0] == '0'; }();
+  (void)hipFuncSetAttribute((const void*)k_diag64m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diagm);
+  static const bool diag_valu = [] { const char* e = getenv("VGPA_LDE_DIAG"); return e && e[0] == 'v'; }();
+  static const bool no_halves = [] { const char* e = getenv("VGPA_LDE_TWO_STREAMS"); return e && e[0] == '0'; }();
   static const bool by_rows = [] { const char* e = getenv("VGPA_LDE_INVERSE"); return e && e[0] == 'r'; }();
-  const bool ahead = side != nullptr && side != st && T > 2 && !no_ahead;
+  const bool two_halves = side != nullptr && side != st && !no_halves;
   EventPair evs;                                      // (destroyed on every return path)
-  if (ahead && !evs.create()) return hipErrorOutOfMemory;
+  if (two_halves && !evs.create()) return hipErrorOutOfMemory;
   hipEvent_t evP = evs.a, evB = evs.b;
   for (int t0 = 0; t0 < Np; t0 += nbmax) {
     const int nb = (Np - t0 < nbmax) ? (Np - t0) : nbmax;
@@ -749,53 +860,46 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     const double* bt = b + (size_t)t0 * D;
     const int eg = (int)((DD + NT * 8 - 1) / (NT * 8));
     hipLaunchKernelGGL(k_prep, dim3(eg, nb), dim3(NT), 0, st, D, c, St, C, X, DD);
-    // ---- blocked Cholesky.  With a side stream (`ahead`) the trailing update of panel J is issued in two parts: block column J + 1
-    // on the main stream -- all the next diagonal block and panel wait for -- and the rest on the side stream, beside them: the
-    // one-wave-per-grid-point chain of k_diag64 (D / 64 launches of 50-70 us that do not shrink with the batch) runs in the shadow of
-    // the update instead of between two of them.  Same tiles, same k order per element: the same bits as the one-launch update.
-    bool b_pending = false;
+    // ---- blocked Cholesky and X = L^-1, both chains of short launches: k_diag64 is ONE wave per grid point and 50-70 us whatever the
+    // batch (D / 64 of them in sequence), the panels and the first levels of the inverse are a few workgroups each.  With a side stream
+    // the batch goes through them as two halves on two streams, so that one half's chain runs beside the other half's products (a
+    // one-step look-ahead inside one batch was built first: a record / wait pair per step costs the main stream ~20 us, as much as it
+    // hid at D = 1024).  Per grid point the same launches in the same order: the same bits.
+    const int nh = (two_halves && nb >= 2) ? 2 : 1;
+    const hipStream_t hs_[2] = {st, side};
+    const int hb_[3] = {0, nh == 2 ? nb - nb / 2 : nb, nb};
+    if (nh == 2) {
+      LDE_TRY(hipEventRecord(evP, st));                      // fork behind k_prep
+      LDE_TRY(hipStreamWaitEvent(side, evP, 0));
+    }
     for (int J = 0; J < T; J++) {
-      hipLaunchKernelGGL(k_diag64, dim3(nb), dim3(64), lds_diag, st, D, J, C, X, DD, DD, status, 30);
       const int r1 = (J + 1) * NBLK;
-      if (r1 >= D) break;
       const int Mr = D - r1;
       const int kw = (D - J * NBLK < NBLK) ? (D - J * NBLK) : NBLK;
-      GemmB p{};   // L[R,J] = C[R,J] X_JJ^T   (in place)
-      p.M = Mr; p.N = kw; p.K = kw; p.A = C + (size_t)r1 * D + J * NBLK; p.lda = D; p.sA = DD;
-      p.B = X + (size_t)(J * NBLK) * D + J * NBLK; p.ldb = D; p.sB = DD;
-      p.C = C + (size_t)r1 * D + J * NBLK; p.ldc = D; p.sC = DD; p.alpha = 1.0; p.beta = 0.0;
-      // in place: every workgroup owns a 64-row block of the panel, reads all of it before its epilogue writes it
-      LDE_TRY(gemm_b(false, true, p, nb, st));
-      GemmB u{};   // C[R,R] -= L[R,J] L[R,J]^T  (lower tiles)
-      u.M = Mr; u.N = Mr; u.K = kw; u.A = C + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
-      u.B = u.A; u.ldb = D; u.sB = DD; u.C = C + (size_t)r1 * D + r1; u.ldc = D; u.sC = DD; u.alpha = -1.0; u.beta = 1.0;
-      u.lower_only = 1;
-      // (a record / wait pair costs the main stream ~20 us: only where the side-stream part is longer than the chain it hides --
-      //  measured at D = 1024, 33 grid points: 117 us at J = 0, 61 us at J = 3)
-      const double side_flop = (double)(Mr - NBLK) * (Mr - NBLK) * kw * nb;
-      if (!ahead || Mr <= NBLK || side_flop < 1.5e9) {
-        if (b_pending) { LDE_TRY(hipStreamWaitEvent(st, evB, 0)); b_pending = false; }
-        LDE_TRY(gemm_b(false, true, u, nb, st));
-        continue;
+      for (int hh = nh - 1; hh >= 0; hh--) {
+        const hipStream_t sh = hs_[hh];
+        const int n = hb_[hh + 1] - hb_[hh];
+        double* Ch = C + (size_t)hb_[hh] * DD;
+        double* Xh = X + (size_t)hb_[hh] * DD;
+        if (diag_valu) hipLaunchKernelGGL(k_diag64, dim3(n), dim3(64), lds_diag, sh, D, J, Ch, Xh, DD, DD, status, 30);
+        else hipLaunchKernelGGL(k_diag64m, dim3(n), dim3(64), lds_diagm, sh, D, J, Ch, Xh, DD, DD, status, 30);
+        if (r1 >= D) continue;
+        GemmB p{};   // L[R,J] = C[R,J] X_JJ^T   (in place)
+        p.M = Mr; p.N = kw; p.K = kw; p.A = Ch + (size_t)r1 * D + J * NBLK; p.lda = D; p.sA = DD;
+        p.B = Xh + (size_t)(J * NBLK) * D + J * NBLK; p.ldb = D; p.sB = DD;
+        p.C = Ch + (size_t)r1 * D + J * NBLK; p.ldc = D; p.sC = DD; p.alpha = 1.0; p.beta = 0.0;
+        // in place: every workgroup owns a 64-row block of the panel, reads all of it before its epilogue writes it
+        LDE_TRY(gemm_b(false, true, p, n, sh));
+        GemmB u{};   // C[R,R] -= L[R,J] L[R,J]^T  (lower tiles)
+        u.M = Mr; u.N = Mr; u.K = kw; u.A = Ch + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
+        u.B = u.A; u.ldb = D; u.sB = DD; u.C = Ch + (size_t)r1 * D + r1; u.ldc = D; u.sC = DD; u.alpha = -1.0; u.beta = 1.0;
+        u.lower_only = 1;
+        LDE_TRY(gemm_b(false, true, u, n, sh));
       }
-      LDE_TRY(hipEventRecord(evP, st));                        // panel J is final
-      // block column J + 1 (rows r1 ..): the previous step's side-stream part updated it too
-      if (b_pending) LDE_TRY(hipStreamWaitEvent(st, evB, 0));
-      GemmB ua = u;
-      ua.N = NBLK; ua.lower_only = 0;
-      LDE_TRY(gemm_b(false, true, ua, nb, st));
-      // the rest (rows and columns from r1 + 64): side stream, behind panel J and behind its own previous part
-      GemmB ub = u;
-      ub.M = ub.N = Mr - NBLK;
-      ub.A = ub.B = u.A + (size_t)NBLK * D;
-      ub.C = u.C + (size_t)NBLK * D + NBLK;
-      LDE_TRY(hipStreamWaitEvent(side, evP, 0));
-      LDE_TRY(gemm_b(false, true, ub, nb, side));
-      LDE_TRY(hipEventRecord(evB, side));
-      b_pending = true;
+      if (r1 >= D) break;
     }
-    if (b_pending) LDE_TRY(hipStreamWaitEvent(st, evB, 0));
-    hipLaunchKernelGGL(k_zero_upper, dim3(eg, nb), dim3(NT), 0, st, D, C, DD);
+    for (int hh = nh - 1; hh >= 0; hh--)
+      hipLaunchKernelGGL(k_zero_upper, dim3(eg, hb_[hh + 1] - hb_[hh]), dim3(NT), 0, hs_[hh], D, C + (size_t)hb_[hh] * DD, DD);
     // ---- X = L^-1 by halves: with X_11, X_22 known, X_21 = -X_22 (L_21 X_11).  Level h (h = 1, 2, 4 ... blocks) joins the
     // neighbouring groups of h blocks; the groups of a level are independent and go into ONE launch per product (second batch level of
     // GemmB), so D / 64 = 16 | 64 takes 8 | 12 launches of growing products instead of 30 | 126 of one 64-row block each.  The
@@ -804,15 +908,21 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
       for (int I = 1; I < T; I++) {
         const int r0 = I * NBLK;
         const int Mi = (D - r0 < NBLK) ? (D - r0) : NBLK;
-        GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
-        a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = C + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = X; a1.ldb = D; a1.sB = DD;
-        a1.C = T1; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
-        a1.k_tri = 1;                                  // X[0:r0, 0:r0] is lower triangular
-        LDE_TRY(gemm_b(false, false, a1, nb, st));
-        GemmB a2{};  // X[I, 0:r0] = -X_II T1
-        a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = X + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = T1; a2.ldb = D;
-        a2.sB = (long long)NBLK * D; a2.C = X + (size_t)r0 * D; a2.ldc = D; a2.sC = DD; a2.alpha = -1.0; a2.beta = 0.0;
-        LDE_TRY(gemm_b(false, false, a2, nb, st));
+        for (int hh = nh - 1; hh >= 0; hh--) {
+          const int n = hb_[hh + 1] - hb_[hh];
+          double* Ch = C + (size_t)hb_[hh] * DD;
+          double* Xh = X + (size_t)hb_[hh] * DD;
+          double* Th = T1 + (size_t)hb_[hh] * NBLK * D;
+          GemmB a1{};  // T1 = L[I, 0:r0] X[0:r0, 0:r0]
+          a1.M = Mi; a1.N = r0; a1.K = r0; a1.A = Ch + (size_t)r0 * D; a1.lda = D; a1.sA = DD; a1.B = Xh; a1.ldb = D; a1.sB = DD;
+          a1.C = Th; a1.ldc = D; a1.sC = (long long)NBLK * D; a1.alpha = 1.0; a1.beta = 0.0;
+          a1.k_tri = 1;                                  // X[0:r0, 0:r0] is lower triangular
+          LDE_TRY(gemm_b(false, false, a1, n, hs_[hh]));
+          GemmB a2{};  // X[I, 0:r0] = -X_II T1
+          a2.M = Mi; a2.N = r0; a2.K = Mi; a2.A = Xh + (size_t)r0 * D + r0; a2.lda = D; a2.sA = DD; a2.B = Th; a2.ldb = D;
+          a2.sB = (long long)NBLK * D; a2.C = Xh + (size_t)r0 * D; a2.ldc = D; a2.sC = DD; a2.alpha = -1.0; a2.beta = 0.0;
+          LDE_TRY(gemm_b(false, false, a2, n, hs_[hh]));
+        }
       }
     }
     for (int h = 1; h < T && !by_rows; h *= 2) {
@@ -825,20 +935,27 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
         const int g0 = part == 0 ? 0 : nfull, ng = part == 0 ? nfull : ngr - nfull;
         if (ng <= 0) continue;
         const int Mi = rows_of(g0);
-        const size_t org = (size_t)g0 * (size_t)step2;
-        GemmB a1{};  // T = L_21 X_11
-        a1.M = Mi; a1.N = hs; a1.K = hs; a1.A = C + org + (size_t)hs * D; a1.lda = D; a1.sA = DD; a1.sA2 = step2;
-        a1.B = X + org; a1.ldb = D; a1.sB = DD; a1.sB2 = step2;
-        a1.C = G + org + (size_t)hs * D; a1.ldc = D; a1.sC = DD; a1.sC2 = step2; a1.alpha = 1.0; a1.beta = 0.0;
-        a1.k_tri = 1;                                          // X_11 is lower triangular
-        LDE_TRY(gemm_b(false, false, a1, nb, st, ng));
-        GemmB a2{};  // X_21 = -X_22 T
-        a2.M = Mi; a2.N = hs; a2.K = Mi; a2.A = X + org + (size_t)hs * (D + 1); a2.lda = D; a2.sA = DD; a2.sA2 = step2;
-        a2.B = G + org + (size_t)hs * D; a2.ldb = D; a2.sB = DD; a2.sB2 = step2;
-        a2.C = X + org + (size_t)hs * D; a2.ldc = D; a2.sC = DD; a2.sC2 = step2; a2.alpha = -1.0; a2.beta = 0.0;
-        a2.k_tri = 3;                                          // X_22 is lower triangular
-        LDE_TRY(gemm_b(false, false, a2, nb, st, ng));
+        for (int hh = nh - 1; hh >= 0; hh--) {
+          const int n = hb_[hh + 1] - hb_[hh];
+          const size_t org = (size_t)g0 * (size_t)step2 + (size_t)hb_[hh] * DD;
+          GemmB a1{};  // T = L_21 X_11
+          a1.M = Mi; a1.N = hs; a1.K = hs; a1.A = C + org + (size_t)hs * D; a1.lda = D; a1.sA = DD; a1.sA2 = step2;
+          a1.B = X + org; a1.ldb = D; a1.sB = DD; a1.sB2 = step2;
+          a1.C = G + org + (size_t)hs * D; a1.ldc = D; a1.sC = DD; a1.sC2 = step2; a1.alpha = 1.0; a1.beta = 0.0;
+          a1.k_tri = 1;                                          // X_11 is lower triangular
+          LDE_TRY(gemm_b(false, false, a1, n, hs_[hh], ng));
+          GemmB a2{};  // X_21 = -X_22 T
+          a2.M = Mi; a2.N = hs; a2.K = Mi; a2.A = X + org + (size_t)hs * (D + 1); a2.lda = D; a2.sA = DD; a2.sA2 = step2;
+          a2.B = G + org + (size_t)hs * D; a2.ldb = D; a2.sB = DD; a2.sB2 = step2;
+          a2.C = X + org + (size_t)hs * D; a2.ldc = D; a2.sC = DD; a2.sC2 = step2; a2.alpha = -1.0; a2.beta = 0.0;
+          a2.k_tri = 3;                                          // X_22 is lower triangular
+          LDE_TRY(gemm_b(false, false, a2, n, hs_[hh], ng));
+        }
       }
+    }
+    if (nh == 2) {
+      LDE_TRY(hipEventRecord(evB, side));                      // join
+      LDE_TRY(hipStreamWaitEvent(st, evB, 0));
     }
     // ---- G = A L ; A m
     GemmB gg{};
