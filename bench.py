@@ -327,8 +327,11 @@ def config5_block(args, rank, world, local_rank, rehearse):
         reps = 2
         sync()
         t0 = time.perf_counter()
+        each = []
         for _ in range(reps):
+            t1 = time.perf_counter()
             f, ga, gb = once()
+            each.append(time.perf_counter() - t1)           # (a sweep ends with the ranks' agreement: the host has waited for it)
         sync()
         secs = par.max_over_ranks((time.perf_counter() - t0) / reps, device="cpu" if rehearse else "cuda")
         # (the driver returns library-owned device arrays; torch wraps them without a copy through __cuda_array_interface__)
@@ -366,7 +369,7 @@ def config5_block(args, rank, world, local_rank, rehearse):
                 "n_gpus": world, "rccl_ranks": rccl_ranks, "rccl_communicators": rccl_comms, "rccl_ranks_how": "ncclCommCount of the shard's communicator (0: one rank or host-staged rehearsal)",
                 "grid_points_per_rank": [int(v) for v in npts.tolist()],
                 "transport": "host-staged gloo (REHEARSAL: not a measurement)" if comm is not None else ("RCCL" if world > 1 else "none"),
-                "scaling": "strong", "s_per_sweep": secs,
+                "scaling": "strong", "s_per_sweep": secs, "s_each_sweep_rank0": each,
                 "recursion_steps_per_s": 2 * (n - 1) / secs, "aggregate_tflops_nominal": flop / secs / 1e12,
                 "frac_of_fp64_peak_per_gpu": flop / secs / 1e12 / world / FP64_PEAK_TFLOPS,
                 "schedule": f"pipelined gather, {chunks} sub-blocks, second stream" if chunks else

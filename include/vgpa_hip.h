@@ -69,6 +69,13 @@ extern "C" {
    VGPA_GEMM_SCALAR_LOADS=1   D > 64: the 8-byte-load GEMM kernels also for full tiles
    VGPA_GEMM_PF=0             D > 64: the two-register-set loop of the stage products (default: four sets, no load under a branch)
    VGPA_GEMM_BM=32|64|128     D > 64: rows of the product's block tile (default: by the number of workgroups)
+   VGPA_LDE_TWO_STREAMS=0     D > 64, energy terms: Cholesky + inverse of a batch on one stream (default: two half-batches on two streams)
+   VGPA_LDE_INVERSE=rows      ... the inverse of L block row by block row (default: by halves, log2(D / 64) levels)
+   VGPA_LDE_DIAG=valu         ... the 64 x 64 diagonal blocks on the vector ALU (default: matrix cores, k_diag64m)
+   VGPA_LDE_TILE_MAP=0        ... workgroup -> tile of the batched products as launched (default: XCD-balanced maps)
+   VGPA_LDE_SYRK_MIRROR=0     ... dEsde_dS from all its tiles (default: tiles on and below the diagonal, mirrored on the way out)
+                              (the five: A/B measurements of round 5, tools/trace_lde.sh; same results to 1e-9, the first, fourth and
+                              fifth bit for bit)
    VGPA_DIAG_REPEAT=<phase>:<n>  launch one phase (fwd|energy|bwd|grad) of the fused sweep n times (clock / power samples under one
                               kernel, tools/power_per_kernel.sh); every phase is a pure function of its inputs
    Only in builds with -DVGPA_EXPERIMENTS (vgpa_abi_version() carries VGPA_ABI_DIAGNOSTIC_BUILD; never the product build):

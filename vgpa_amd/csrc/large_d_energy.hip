@@ -34,9 +34,32 @@ struct GemmB {
                                           // Only exact zeros are skipped, so the result is bit-identical.
                                           // 3 = op(B) as in 1 is NOT assumed; op(A)[i][k] = 0 for k > i (A lower triangular,
                                           // whole 64-blocks): the k loop of a tile ends behind its last row.
+  int mirror;                             // symmetric result (beta = 0, lower_only): the tiles below the diagonal are stored a second
+                                          // time, transposed, above it -- a . b = b . a and the same k order: the bits the skipped
+                                          // tile's own product would have had
+  int tile_map;                           // which tile a workgroup takes (set by gemm_b).  Workgroup n of a launch runs on XCD n mod 8,
+                                          // and with 16 column tiles per row every XCD would always get the same two columns: 2.4 x the
+                                          // work on XCD 0 for a triangular operand (k_tri), 24 against 10 live tiles for lower_only.
+                                          // 1 = column tile (x + y) mod gridDim.x; 2 = blockIdx.x counts the tiles on and below the
+                                          // diagonal row by row (M = N, no idle workgroups)
   int nb1;                                // > 0: two batch levels, blockIdx.z = z2 * nb1 + z1 (z1: grid point, strides sA / sB / sC;
   long long sA2, sB2, sC2;                //      z2: independent sub-problem of the same grid point, strides sA2 / sB2 / sC2)
 };
+
+__device__ __forceinline__ bool tile_origin(const GemmB& g, int BM, int& i0, int& j0) {
+  int ti = blockIdx.y, tj = blockIdx.x;
+  if (g.tile_map == 1) {
+    tj = (tj + ti) % (int)gridDim.x;
+  } else if (g.tile_map == 2) {
+    const int t = blockIdx.x;
+    int r = (int)((__builtin_sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= t) r++;
+    while (r * (r + 1) / 2 > t) r--;
+    ti = r; tj = t - r * (r + 1) / 2;
+  }
+  i0 = ti * BM; j0 = tj * BN;
+  return !(g.lower_only && j0 >= i0 + BM);
+}
 
 __device__ __forceinline__ void batch_origin(const GemmB& g, const double*& A, const double*& B, double*& C) {
   long long z1 = blockIdx.z, z2 = 0;
@@ -56,8 +79,8 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
   __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-  if (g.lower_only && j0 >= i0 + BM) return;
+  int i0, j0;
+  if (!tile_origin(g, BM, i0, j0)) return;
   const double *A, *B;
   double* C;
   batch_origin(g, A, B, C);
@@ -147,6 +170,7 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
           double* cp = C + (long long)gi * g.ldc + gj;
           const double v = g.alpha * acc[mt][nt][r];
           *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
+          if (g.mirror && i0 != j0) C[(long long)gj * g.ldc + gi] = v;
         }
       }
     }
@@ -167,8 +191,8 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDBS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-  if (g.lower_only && j0 >= i0 + BM) return;
+  int i0, j0;
+  if (!tile_origin(g, BM, i0, j0)) return;
   const double *A, *B;
   double* C;
   batch_origin(g, A, B, C);
@@ -287,6 +311,7 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
         double* cp = C + (long long)gi * g.ldc + gj;
         const double v = g.alpha * acc[mt][nt][r];
         *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
+        if (g.mirror && i0 != j0) C[(long long)gj * g.ldc + gi] = v;
       }
     }
 }
@@ -296,6 +321,15 @@ hipError_t gemm_b(bool ta, bool tb, GemmB g, int nb, hipStream_t st, int nsub = 
   if (g.M <= 0 || g.N <= 0 || nb <= 0 || nsub <= 0) return hipSuccess;
   g.nb1 = nsub > 1 ? nb : 0;
   dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb * nsub);
+  static const bool plain_map = [] { const char* e = getenv("VGPA_LDE_TILE_MAP"); return e && e[0] == '0'; }();
+  g.tile_map = 0;
+  if (!plain_map && g.lower_only && g.M == g.N) {
+    g.tile_map = 2;
+    grid.x = grid.y * (grid.y + 1) / 2;
+    grid.y = 1;
+  } else if (!plain_map && g.k_tri != 0 && grid.x > 1) {
+    g.tile_map = 1;
+  }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   static const bool scalar_loads = [] { const char* e = getenv("VGPA_GEMM_SCALAR_LOADS"); return e && e[0] == '1'; }();
   const bool vec = !tb && !scalar_loads && g.M % 64 == 0 && g.N % BN == 0 && g.K % BK == 0 && g.lda % 2 == 0 &&
@@ -838,6 +872,7 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
   (void)hipFuncSetAttribute((const void*)k_diag64m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diagm);
   static const bool diag_valu = [] { const char* e = getenv("VGPA_LDE_DIAG"); return e && e[0] == 'v'; }();
   static const bool no_halves = [] { const char* e = getenv("VGPA_LDE_TWO_STREAMS"); return e && e[0] == '0'; }();
+  static const bool no_mirror = [] { const char* e = getenv("VGPA_LDE_SYRK_MIRROR"); return e && e[0] == '0'; }();
   static const bool by_rows = [] { const char* e = getenv("VGPA_LDE_INVERSE"); return e && e[0] == 'r'; }();
   const bool two_halves = side != nullptr && side != st && !no_halves;
   EventPair evs;                                      // (destroyed on every return path)
@@ -987,6 +1022,8 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
     sy.M = D; sy.N = D; sy.K = D; sy.A = X; sy.lda = D; sy.sA = DD; sy.B = C; sy.ldb = D; sy.sB = DD;
     sy.C = dEs + (size_t)t0 * DD; sy.ldc = D; sy.sC = DD; sy.alpha = 0.5 * c; sy.beta = 0.0;
     sy.k_tri = 2;                                    // X^T[i][k] = X[k][i] = 0 for k < i and (q X)[k][j] = 0 for k < j
+    sy.lower_only = no_mirror ? 0 : 1;               // the result is symmetric: the tiles on and below the diagonal, mirrored on the way out
+    sy.mirror = sy.lower_only;
     LDE_TRY(gemm_b(true, false, sy, nb, st));
     if (Edf) hipLaunchKernelGGL(k_edf, dim3(eg, nb), dim3(NT), 0, st, D, mt, Edf + (size_t)t0 * DD);
     LDE_TRY(hipGetLastError());
