@@ -281,9 +281,11 @@ def test_single_rank_driver_with_standin_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,n", [(72, 9), (96, 8), (128, 7), (160, 6)])
+@pytest.mark.parametrize("d,n", [(72, 9), (96, 8), (128, 7), (160, 6), (330, 5), (448, 4), (520, 3)])
 def test_large_d_lorenz96_energy_terms(d, n):
-    """vgpa_energy at D > 64 (batched blocked Cholesky / inverse / GEMMs) vs the oracle's lean L96 energy."""
+    """vgpa_energy at D > 64 (batched blocked Cholesky / inverse / GEMMs) vs the oracle's lean L96 energy.  D = 330, 448, 520: six
+    (the last one of 10 rows), seven and nine (8 rows) diagonal blocks -- every level of the inverse by halves has a ragged or a missing
+    last group -- two to four segments of the residual sums, uneven halves of the batch on the two streams."""
     import vgpa_amd as va
     from test_gpu_edge_cases import make_problem, gpu_context
     p, x = make_problem("L96", d, n)
@@ -295,6 +297,56 @@ def test_large_d_lorenz96_energy_terms(d, n):
     assert abs(esde - esde_o) <= TOL * abs(esde_o)
     assert rel_err(ef, ef_o) < TOL and rel_err(edf, edf_o) < TOL
     assert rel_err(dm, dm_o) < TOL and rel_err(ds, ds_o) < TOL
+
+
+@pytest.mark.gpu
+def test_energy_term_schedules_above_64_agree():
+    """The round-5 schedule of lde_energy (two half-batches on two streams, inverse by halves, diagonal blocks on the matrix cores,
+    XCD-balanced tile maps, mirrored dEsde_dS) against the round-4 one (VGPA_LDE_* switches, read once per process: a child process) at
+    D = 330 and 192: the same energy terms to 1e-11, and dEsde_dS symmetric in every bit between different tiles (mirrored stores)."""
+    import json
+    import subprocess
+    import vgpa_amd as va
+    from test_gpu_edge_cases import make_problem
+    cases = ((330, 5), (192, 4))
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import vgpa_amd as va\n"
+        "from test_gpu_edge_cases import make_problem\n"
+        "from oracle import vgpa_oracle as vo\n"
+        "out = []\n"
+        "for d, n in %r:\n"
+        "    p, x = make_problem('L96', d, n)\n"
+        "    a, b = p.split(x)\n"
+        "    mt, st = vo.solve_fwd(p.method, p.dt, False, a, b, p.m0, p.s0, p.sigma)\n"
+        "    ctx = va.Context('L96', 'rk4', d, n, p.dt, sigma=p.sigma, theta=[8.0])\n"
+        "    esde, ef, edf, dm, ds = ctx.energy(a, b, mt, st)\n"
+        "    out.append({'esde': float(esde), 'ef': np.asarray(ef).ravel().tolist(), 'dm': np.asarray(dm).ravel().tolist(),\n"
+        "                'ds': np.asarray(ds).ravel().tolist()})\n"
+        "    ctx.close()\n"
+        "print(json.dumps(out))\n" % (os.path.dirname(__file__), cases))
+    env = dict(os.environ)
+    env.update({"VGPA_LDE_TWO_STREAMS": "0", "VGPA_LDE_INVERSE": "rows", "VGPA_LDE_DIAG": "valu", "VGPA_LDE_TILE_MAP": "0",
+                "VGPA_LDE_SYRK_MIRROR": "0", "VGPA_LDE_PANEL": "1", "PYTHONPATH": os.pathsep.join([ROOT, env.get("PYTHONPATH", "")])})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    old = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])
+    for (d, n), ref in zip(cases, old):
+        p, x = make_problem("L96", d, n)
+        a, b = p.split(x)
+        mt, st = vo.solve_fwd(p.method, p.dt, False, a, b, p.m0, p.s0, p.sigma)
+        ctx = va.Context("L96", "rk4", d, n, p.dt, sigma=p.sigma, theta=[8.0])
+        esde, ef, edf, dm, ds = ctx.energy(a, b, mt, st)
+        ctx.close()
+        assert abs(esde - ref["esde"]) <= 1e-12 * abs(esde)
+        assert rel_err(np.asarray(ef).ravel(), np.asarray(ref["ef"])) < 1e-12
+        assert rel_err(np.asarray(dm).ravel(), np.asarray(ref["dm"])) < 1e-11
+        assert rel_err(np.asarray(ds).ravel(), np.asarray(ref["ds"])) < 1e-11
+        ds = np.asarray(ds).reshape(n, d, d)       # mirrored stores: symmetric in every bit between different 64 x 64 tiles
+        blk = np.arange(d) // 64
+        off = blk[:, None] != blk[None, :]
+        assert np.array_equal(ds[:, off], ds.transpose(0, 2, 1)[:, off])
 
 
 @pytest.mark.gpu

@@ -35,8 +35,8 @@ struct GemmB {
                                           // 3 = op(B) as in 1 is NOT assumed; op(A)[i][k] = 0 for k > i (A lower triangular,
                                           // whole 64-blocks): the k loop of a tile ends behind its last row.
   int mirror;                             // symmetric result (beta = 0, lower_only): the tiles below the diagonal are stored a second
-                                          // time, transposed, above it -- a . b = b . a and the same k order: the bits the skipped
-                                          // tile's own product would have had
+                                          // time, transposed, above it (the skipped tile's own product associates q_k with the other
+                                          // factor: equal to it up to rounding, and now symmetric in every bit between tiles)
   int tile_map;                           // which tile a workgroup takes (set by gemm_b).  Workgroup n of a launch runs on XCD n mod 8,
                                           // and with 16 column tiles per row every XCD would always get the same two columns: 2.4 x the
                                           // work on XCD 0 for a triangular operand (k_tri), 24 against 10 live tiles for lower_only.
@@ -873,6 +873,7 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
   static const bool diag_valu = [] { const char* e = getenv("VGPA_LDE_DIAG"); return e && e[0] == 'v'; }();
   static const bool no_halves = [] { const char* e = getenv("VGPA_LDE_TWO_STREAMS"); return e && e[0] == '0'; }();
   static const bool no_mirror = [] { const char* e = getenv("VGPA_LDE_SYRK_MIRROR"); return e && e[0] == '0'; }();
+  static const int wpan = [] { const char* e = getenv("VGPA_LDE_PANEL"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
   static const bool by_rows = [] { const char* e = getenv("VGPA_LDE_INVERSE"); return e && e[0] == 'r'; }();
   const bool two_halves = side != nullptr && side != st && !no_halves;
   EventPair evs;                                      // (destroyed on every return path)
@@ -925,11 +926,23 @@ hipError_t lde_energy(int D, int Np, double theta, const double* isg, const doub
         p.C = Ch + (size_t)r1 * D + J * NBLK; p.ldc = D; p.sC = DD; p.alpha = 1.0; p.beta = 0.0;
         // in place: every workgroup owns a 64-row block of the panel, reads all of it before its epilogue writes it
         LDE_TRY(gemm_b(false, true, p, n, sh));
-        GemmB u{};   // C[R,R] -= L[R,J] L[R,J]^T  (lower tiles)
-        u.M = Mr; u.N = Mr; u.K = kw; u.A = Ch + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
+        // Trailing update in two levels: panel J updates the block columns of its own OUTER panel (`wpan` blocks) only; behind the outer
+        // panel's last block everything right of it gets ONE update with all its columns (K = 64 wpan instead of wpan updates with
+        // K = 64: the update is bound by reading and writing C -- 8 flop per byte at K = 64 -- and this is a quarter of the traffic).
+        const int pend = ((J / wpan + 1) * wpan < T) ? (J / wpan + 1) * wpan * NBLK : D;      // first column behind the outer panel
+        GemmB u{};   // C[R, r1:pend] -= L[R,J] L[r1:pend,J]^T  (lower tiles)
+        u.M = Mr; u.N = pend - r1; u.K = kw; u.A = Ch + (size_t)r1 * D + J * NBLK; u.lda = D; u.sA = DD;
         u.B = u.A; u.ldb = D; u.sB = DD; u.C = Ch + (size_t)r1 * D + r1; u.ldc = D; u.sC = DD; u.alpha = -1.0; u.beta = 1.0;
         u.lower_only = 1;
         LDE_TRY(gemm_b(false, true, u, n, sh));
+        if (r1 == pend && pend < D) {   // J was the outer panel's last block: C[R2,R2] -= L[R2,P] L[R2,P]^T
+          const int p0 = (J / wpan) * wpan * NBLK;
+          GemmB w{};
+          w.M = D - pend; w.N = D - pend; w.K = pend - p0; w.A = Ch + (size_t)pend * D + p0; w.lda = D; w.sA = DD;
+          w.B = w.A; w.ldb = D; w.sB = DD; w.C = Ch + (size_t)pend * D + pend; w.ldc = D; w.sC = DD; w.alpha = -1.0; w.beta = 1.0;
+          w.lower_only = 1;
+          LDE_TRY(gemm_b(false, true, w, n, sh));
+        }
       }
       if (r1 >= D) break;
     }
