@@ -34,6 +34,7 @@ struct GemmB {
                                           // Only exact zeros are skipped, so the result is bit-identical.
                                           // 3 = op(B) as in 1 is NOT assumed; op(A)[i][k] = 0 for k > i (A lower triangular,
                                           // whole 64-blocks): the k loop of a tile ends behind its last row.
+  int k_down;                             // k_tri = 1 in the 16-byte-load kernel: the k loop runs down from the common end (set by gemm_b)
   int mirror;                             // symmetric result (beta = 0, lower_only): the tiles below the diagonal are stored a second
                                           // time, transposed, above it (the skipped tile's own product associates q_k with the other
                                           // factor: equal to it up to rounding, and now symmetric in every bit between tiles)
@@ -219,7 +220,12 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
     pB[q] = B + (long long)k * g.ldb + j0 + 2 * j2;
     sb[q] = k * LDBS + 2 * j2;
   }
-  const long long astep = TA ? (long long)BK * g.lda : (long long)BK, bstep = (long long)BK * g.ldb;
+  // k_tri = 1 (op(B) lower triangular: the k range of a tile starts at its first column): the k loop runs DOWN from the common end.  The
+  // workgroups of a tile row share the row's A tiles; going up, each starts at its own k and they never read the same A tile at the same
+  // time (D = 4096: up to 113 GB of A reads for 3.5 GB of A); going down they start together like the workgroups of a full product.
+  const bool desc = g.k_tri == 1 && g.k_down;
+  const long long astep0 = TA ? (long long)BK * g.lda : (long long)BK, bstep0 = (long long)BK * g.ldb;
+  const long long astep = desc ? -astep0 : astep0, bstep = desc ? -bstep0 : bstep0;
   // PF register sets of loads in flight, none under a branch (ld::k_gemm_v: a branch makes the wait counts of its two paths merge
   // to the conservative one -- the LDS stores of one set then wait for the loads just issued into another); behind the last tile of
   // this workgroup's k range the pointers stay (the surplus loads re-read that tile and are never multiplied)
@@ -270,10 +276,11 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   if (g.k_tri == 1) kt0 = j0 / BK;
   else if (g.k_tri == 2) kt0 = (i0 > j0 ? i0 : j0) / BK;
   if (kt0 > nk) kt0 = nk;
+  const int kfirst = desc ? nk - 1 : kt0;                  // (nk - kt0 tiles either way)
 #pragma unroll
-  for (int q = 0; q < AV; q++) pA[q] += (long long)kt0 * astep;
+  for (int q = 0; q < AV; q++) pA[q] += (long long)kfirst * astep0;
 #pragma unroll
-  for (int q = 0; q < 2; q++) pB[q] += (long long)kt0 * bstep;
+  for (int q = 0; q < 2; q++) pB[q] += (long long)kfirst * bstep0;
   const int ntile = nk - kt0;                              // k-tiles of this workgroup (k_tri: its triangular operand starts later)
   if (ntile > 0) {
     static_assert(PF % 2 == 0, "LDS buffer parity is static in the unrolled loop");
@@ -322,6 +329,8 @@ hipError_t gemm_b(bool ta, bool tb, GemmB g, int nb, hipStream_t st, int nsub = 
   g.nb1 = nsub > 1 ? nb : 0;
   dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, nb * nsub);
   static const bool plain_map = [] { const char* e = getenv("VGPA_LDE_TILE_MAP"); return e && e[0] == '0'; }();
+  static const bool k_up = [] { const char* e = getenv("VGPA_LDE_K_DOWN"); return e && e[0] == '0'; }();
+  g.k_down = k_up ? 0 : 1;
   g.tile_map = 0;
   if (!plain_map && g.lower_only && g.M == g.N) {
     g.tile_map = 2;
