@@ -75,8 +75,9 @@ extern "C" {
    VGPA_LDE_TILE_MAP=0        ... workgroup -> tile of the batched products as launched (default: XCD-balanced maps)
    VGPA_LDE_SYRK_MIRROR=0     ... dEsde_dS from all its tiles (default: tiles on and below the diagonal, mirrored on the way out)
    VGPA_LDE_K_DOWN=0          ... products with a lower-triangular right operand: k loop upwards from each tile's own start (default: down)
+   VGPA_LDE_GRAD_EPILOGUE=0   D > 64, gradient: the rank-one term and dt in a pass over the product Q S (default: in the product's epilogue)
    VGPA_LDE_PANEL=<blocks>    ... outer panel of the blocked Cholesky: one trailing update per <blocks> diagonal blocks (default 4; 1: one per block)
-                              (the seven: A/B measurements of round 5, tools/trace_lde.sh; same results to 1e-9, the first and the fourth
+                              (the eight: A/B measurements of round 5, tools/trace_lde.sh; same results to 1e-9, the first and the fourth
                               bit for bit)
    VGPA_DIAG_REPEAT=<phase>:<n>  launch one phase (fwd|energy|bwd|grad) of the fused sweep n times (clock / power samples under one
                               kernel, tools/power_per_kernel.sh); every phase is a pure function of its inputs

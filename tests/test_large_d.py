@@ -328,7 +328,7 @@ def test_energy_term_schedules_above_64_agree():
         "print(json.dumps(out))\n" % (os.path.dirname(__file__), cases))
     env = dict(os.environ)
     env.update({"VGPA_LDE_TWO_STREAMS": "0", "VGPA_LDE_INVERSE": "rows", "VGPA_LDE_DIAG": "valu", "VGPA_LDE_TILE_MAP": "0",
-                "VGPA_LDE_SYRK_MIRROR": "0", "VGPA_LDE_PANEL": "1", "VGPA_LDE_K_DOWN": "0", "PYTHONPATH": os.pathsep.join([ROOT, env.get("PYTHONPATH", "")])})
+                "VGPA_LDE_SYRK_MIRROR": "0", "VGPA_LDE_PANEL": "1", "VGPA_LDE_K_DOWN": "0", "VGPA_LDE_GRAD_EPILOGUE": "0", "PYTHONPATH": os.pathsep.join([ROOT, env.get("PYTHONPATH", "")])})
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     old = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])

@@ -34,6 +34,9 @@ struct GemmB {
                                           // Only exact zeros are skipped, so the result is bit-identical.
                                           // 3 = op(B) as in 1 is NOT assumed; op(A)[i][k] = 0 for k > i (A lower triangular,
                                           // whole 64-blocks): the k loop of a tile ends behind its last row.
+  const double* epi_u;                    // != nullptr: C = alpha (op(A) op(B) - u v^T), u = epi_u + z1 epi_s, v = epi_v + z1 epi_s (the gradient's
+  const double* epi_v;                    // rank-one term in the product's epilogue instead of a pass over the result; beta = 0)
+  long long epi_s;
   int k_down;                             // k_tri = 1 in the 16-byte-load kernel: the k loop runs down from the common end (set by gemm_b)
   int mirror;                             // symmetric result (beta = 0, lower_only): the tiles below the diagonal are stored a second
                                           // time, transposed, above it (the skipped tile's own product associates q_k with the other
@@ -62,12 +65,13 @@ __device__ __forceinline__ bool tile_origin(const GemmB& g, int BM, int& i0, int
   return !(g.lower_only && j0 >= i0 + BM);
 }
 
-__device__ __forceinline__ void batch_origin(const GemmB& g, const double*& A, const double*& B, double*& C) {
+__device__ __forceinline__ long long batch_origin(const GemmB& g, const double*& A, const double*& B, double*& C) {
   long long z1 = blockIdx.z, z2 = 0;
   if (g.nb1 > 0) { z2 = blockIdx.z / g.nb1; z1 = blockIdx.z - z2 * g.nb1; }
   A = g.A + z1 * g.sA + z2 * g.sA2;
   B = g.B + z1 * g.sB + z2 * g.sB2;
   C = g.C + z1 * g.sC + z2 * g.sC2;
+  return z1;
 }
 
 template <bool TA, bool TB, int BM>
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
   if (!tile_origin(g, BM, i0, j0)) return;
   const double *A, *B;
   double* C;
-  batch_origin(g, A, B, C);
+  const long long z1 = batch_origin(g, A, B, C);
   const int fi = lane & 15, fk = lane >> 4;
   double ra[AQ], rb[4];
   auto load_tiles = [&](int k0) {
@@ -169,7 +173,8 @@ __global__ void __launch_bounds__(NT) k_gemm_b(GemmB g) {
         const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
         if (gi < g.M) {
           double* cp = C + (long long)gi * g.ldc + gj;
-          const double v = g.alpha * acc[mt][nt][r];
+          double v = g.alpha * acc[mt][nt][r];
+          if (g.epi_u) v = g.alpha * (acc[mt][nt][r] - g.epi_u[z1 * g.epi_s + gi] * g.epi_v[z1 * g.epi_s + gj]);
           *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
           if (g.mirror && i0 != j0) C[(long long)gj * g.ldc + gi] = v;
         }
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
   if (!tile_origin(g, BM, i0, j0)) return;
   const double *A, *B;
   double* C;
-  batch_origin(g, A, B, C);
+  const long long z1 = batch_origin(g, A, B, C);
   const int fi = lane & 15, fk = lane >> 4;
   // persistent operand pointers, advanced by one k-tile per load (see ld::k_gemm_v)
   const double* pA[AV];
@@ -316,7 +321,8 @@ __global__ void __launch_bounds__(NT) k_gemm_bv(GemmB g) {
       for (int r = 0; r < 4; r++) {
         const int gi = i0 + (BM / 2) * wm + 16 * mt + (lane >> 4) + 4 * r;
         double* cp = C + (long long)gi * g.ldc + gj;
-        const double v = g.alpha * acc[mt][nt][r];
+        double v = g.alpha * acc[mt][nt][r];
+        if (g.epi_u) v = g.alpha * (acc[mt][nt][r] - g.epi_u[z1 * g.epi_s + gi] * g.epi_v[z1 * g.epi_s + gj]);
         *cp = (g.beta == 0.0) ? v : (v + g.beta * (*cp));
         if (g.mirror && i0 != j0) C[(long long)gj * g.ldc + gi] = v;
       }
@@ -836,6 +842,17 @@ __global__ void __launch_bounds__(NT) k_grad_fin(int D, double dt, const double*
   }
 }
 
+// u_i = isg_i (-Ef_i - (A m)_i + b_i) + lam_i ; gB = dt u  (the rank-one term itself rides in the epilogue of the product Q S: GemmB::epi_u)
+__global__ void __launch_bounds__(NT) k_grad_u(int D, double dt, const double* isg, const double* am, const double* b, const double* lam,
+                                               const double* Ef, double* u, double* gB) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= D) return;
+  const long long vo = (long long)blockIdx.y * D;
+  const double uv = isg[i] * (-Ef[vo + i] - am[vo + i] + b[vo + i]) + lam[vo + i];
+  u[vo + i] = uv;
+  gB[vo + i] = dt * uv;
+}
+
 // fork / join events of lde_energy's two streams (destroyed on every return path)
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
@@ -1094,9 +1111,17 @@ hipError_t lde_grad(int D, int Np, double dt, const double* isg, const double* A
     GemmB g{};
     g.M = D; g.N = D; g.K = D; g.A = Q; g.lda = D; g.sA = DD; g.B = S + (size_t)t0 * DD; g.ldb = D; g.sB = DD;
     g.C = gA + (size_t)t0 * DD; g.ldc = D; g.sC = DD; g.alpha = 1.0; g.beta = 0.0;
-    LDE_TRY(gemm_b(false, false, g, nb, st));
-    hipLaunchKernelGGL(k_grad_fin, dim3(eg, nb), dim3(NT), 0, st, D, dt, isg, am, b + (size_t)t0 * D, m + (size_t)t0 * D,
-                       lam + (size_t)t0 * D, Ef + (size_t)t0 * D, gA + (size_t)t0 * DD, gB + (size_t)t0 * D);
+    static const bool fin_pass = [] { const char* e = getenv("VGPA_LDE_GRAD_EPILOGUE"); return e && e[0] == '0'; }();
+    if (fin_pass) {      // rounds 1-4: the rank-one term and dt in a pass over the product (kept for the A/B measurement)
+      LDE_TRY(gemm_b(false, false, g, nb, st));
+      hipLaunchKernelGGL(k_grad_fin, dim3(eg, nb), dim3(NT), 0, st, D, dt, isg, am, b + (size_t)t0 * D, m + (size_t)t0 * D,
+                         lam + (size_t)t0 * D, Ef + (size_t)t0 * D, gA + (size_t)t0 * DD, gB + (size_t)t0 * D);
+    } else {             // gA = dt (Q S - u m^T) out of the product's epilogue
+      hipLaunchKernelGGL(k_grad_u, dim3((D + NT - 1) / NT, nb), dim3(NT), 0, st, D, dt, isg, am, b + (size_t)t0 * D, lam + (size_t)t0 * D,
+                         Ef + (size_t)t0 * D, u0, gB + (size_t)t0 * D);
+      g.alpha = dt; g.epi_u = u0; g.epi_v = m + (size_t)t0 * D; g.epi_s = D;
+      LDE_TRY(gemm_b(false, false, g, nb, st));
+    }
     LDE_TRY(hipGetLastError());
   }
   return hipSuccess;
