@@ -972,6 +972,19 @@ def test_native_sharded_sweep_with_memory_sharded_x(method, d, n, world, chunks)
         e = abs(f - f_o) / abs(f_o)
         if hi > lo:
             e = max(e, rel_err(ga.cpu().numpy(), ga_o[lo:hi]), rel_err(gb.cpu().numpy(), gb_o[lo:hi]))
+        # as an optimisation calls it: the fixed operands prepared once, the gradient pair of the sweep before written again
+        problem = rec.prepare(p.theta, np.diag(p.sigma), p.m0, p.s0, p.obs_t, p.obs_y, np.diag(p.obs_noise), e0)
+        first = (ga.cpu().numpy(), gb.cpu().numpy())
+        f2, ga2, gb2 = rec.sweep_sharded(a_h[lo:hi], 1.01 * b_h[lo:hi], problem, out=(ga, gb))     # another x: the pair is overwritten
+        assert ga2.data_ptr() == ga.data_ptr() and gb2.data_ptr() == gb.data_ptr() and f2 != f
+        f3, ga3, gb3 = rec.sweep_sharded(a_h[lo:hi], b_h[lo:hi], problem, out=(ga2, gb2))
+        assert abs(f3 - f) <= 1e-12 * abs(f) and ga3.data_ptr() == ga.data_ptr()
+        if hi > lo:
+            assert rel_err(ga3.cpu().numpy(), first[0]) < 1e-12 and rel_err(gb3.cpu().numpy(), first[1]) < 1e-12
+        with pytest.raises(ValueError):
+            rec.sweep_sharded(a_h[lo:hi], b_h[lo:hi], problem, out=(gb3, ga3))
+        with pytest.raises(TypeError):
+            rec.sweep_sharded(a_h[lo:hi], b_h[lo:hi], p.theta)
         rec.close()
         return e
 

@@ -142,6 +142,14 @@ class HostStagedComm:
         return 0
 
 
+class ShardProblem:
+    """What `NativeShardedRecursion.prepare` returns: the vgpa_shard_problem struct of one variational problem and the device arrays
+    its pointers refer to (kept alive with it)."""
+
+    def __init__(self, owner, prob, keep):
+        self.owner, self.prob, self.keep = owner, prob, keep
+
+
 class NativeShardedRecursion:
     """
     The row-sharded recursion with the whole step / stage loop AND its collectives inside libvgpa_hip.so
@@ -318,6 +326,36 @@ class NativeShardedRecursion:
         self._check(self._lib.vgpa_rccl_comm_streams(ctypes.byref(self._comm), ctypes.byref(n)), "vgpa_rccl_comm_streams")
         return int(n.value)
 
+    def prepare(self, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+        """The operands of `sweep` / `sweep_sharded` that do not change between the sweeps of one optimisation (the prior, the
+        noises, the observations: two D x D uploads among them), uploaded ONCE: pass the returned object in place of `theta` and
+        leave the other seven arguments out."""
+        return ShardProblem(self, *self._problem(theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0))
+
+    def _problem_of(self, theta, rest):
+        if isinstance(theta, ShardProblem):
+            if theta.owner is not self:
+                raise ValueError("this ShardProblem was prepared by another recursion")
+            return theta.prob, theta.keep
+        if any(v is None for v in rest[:6]):
+            raise TypeError("sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag are required unless a prepared ShardProblem is passed")
+        return self._problem(theta, *rest)
+
+    def _gradient_arrays(self, out):
+        """(gLa_own, gLb_own): new device arrays, or the caller's `out` pair from an earlier sweep (an optimisation keeps ONE pair:
+        at D = 4096 a rank's gLa_own is gigabytes, and allocating / freeing it per sweep is host time the GPU cannot hide)."""
+        d, n_own = self.D, max(self.time_slice[1] - self.time_slice[0], 1)
+        if out is None:
+            return DeviceArray((n_own, d, d), self.device), DeviceArray((n_own, d), self.device)
+        ga, gb = out
+        for arr, shape in ((ga, (d, d)), (gb, (d,))):
+            if not isinstance(arr, DeviceArray) or arr.device != self.device or tuple(arr.shape[1:]) != shape:
+                raise ValueError("out: the (gLa_own, gLb_own) pair an earlier sweep of this recursion returned is expected")
+        ga, gb = (ga._base or ga), (gb._base or gb)         # (sweeps return [:n_own] views of the arrays they own)
+        if ga.shape[0] != n_own or gb.shape[0] != n_own:
+            raise ValueError("out: the (gLa_own, gLb_own) pair an earlier sweep of this recursion returned is expected")
+        return ga, gb
+
     def _problem(self, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
         from ._lib import VgpaShardProblem
         d = self.D
@@ -338,20 +376,21 @@ class NativeShardedRecursion:
         prob.e0 = float(e0)
         return prob, keep
 
-    def sweep_sharded(self, a_own, b_own, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+    def sweep_sharded(self, a_own, b_own, theta, sigma_diag=None, m0=None, s0=None, obs_t=None, obs_y=None, obs_noise_diag=None,
+                      e0=0.0, *, out=None):
         """
         vgpa_shard_sweep_sharded: the fused sweep with x MEMORY-SHARDED like the gradient -- a_own [n_own, D, D] and b_own
         [n_own, D] are A_t / b_t of the grid points of `time_slice` only (device tensors or host arrays).  Returns
-        (F, gLa_own, gLb_own) like `sweep`.  No rank holds a complete (Np, D, D) array.
+        (F, gLa_own, gLb_own) like `sweep`.  No rank holds a complete (Np, D, D) array.  `theta` may be a `prepare`d problem
+        (then nothing is uploaded but a_own / b_own), `out` the gradient pair of an earlier sweep (written again, returned again).
         """
         d = self.D
         n_own = self.time_slice[1] - self.time_slice[0]
         ad, bd = self._dev(a_own), self._dev(b_own)
         if n_own == 0:
             ad, bd = self._dev(np.zeros((1, d, d))), self._dev(np.zeros((1, d)))
-        prob, keep = self._problem(theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0)
-        ga = DeviceArray((max(n_own, 1), d, d), self.device)
-        gb = DeviceArray((max(n_own, 1), d), self.device)
+        prob, keep = self._problem_of(theta, (sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0))
+        ga, gb = self._gradient_arrays(out)
         f = ctypes.c_double(0.0)
         self._external_ready()
         self._check(self._lib.vgpa_shard_sweep_sharded(self._h, ctypes.byref(prob), ctypes.c_void_p(ad.data_ptr()),
@@ -361,21 +400,20 @@ class NativeShardedRecursion:
         del keep
         return f.value, ga[:n_own], gb[:n_own]
 
-    def sweep(self, x, theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0):
+    def sweep(self, x, theta, sigma_diag=None, m0=None, s0=None, obs_t=None, obs_y=None, obs_noise_diag=None, e0=0.0, *, out=None):
         """
         Free energy and gradient of VarGP (variational.py:141-288) for ONE Lorenz-96 problem on the row-sharded recursion
         (vgpa_shard_sweep): F on every rank, the gradient TIME-sharded -- returns (F, gLa_own [n_own, D, D], gLb_own [n_own, D])
         as device tensors for the grid points of `time_slice`.  x = [A_t | b_t] (host array or device tensor, replicated);
         diagonal system noise `sigma_diag`, diagonal observation noise `obs_noise_diag`, identity observation operator.
         The outcome is collective: every rank raises the same error (LinAlgError when S_t of ANY rank's grid points is not
-        positive definite).
+        positive definite).  `theta` may be a `prepare`d problem, `out` the gradient pair of an earlier sweep (see `sweep_sharded`).
         """
         d = self.D
         xd = self._dev(x)
-        prob, keep = self._problem(theta, sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0)
+        prob, keep = self._problem_of(theta, (sigma_diag, m0, s0, obs_t, obs_y, obs_noise_diag, e0))
         n_own = self.time_slice[1] - self.time_slice[0]
-        ga = DeviceArray((max(n_own, 1), d, d), self.device)
-        gb = DeviceArray((max(n_own, 1), d), self.device)
+        ga, gb = self._gradient_arrays(out)
         f = ctypes.c_double(0.0)
         self._external_ready()
         self._check(self._lib.vgpa_shard_sweep(self._h, ctypes.byref(prob), ctypes.c_void_p(xd.data_ptr()), ctypes.byref(f),
